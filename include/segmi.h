@@ -1,0 +1,167 @@
+/* segmi.h — C ABI of libsegmi.so, the MI355X (gfx950) kernel library behind the drop-in
+ * `models.*`, `utils.losses.*` and `utils.sync_batchnorm.*` modules.
+ *
+ * The reference (yassouali/pytorch-segmentation) has no FFI: every FLOP of its hot path is an ATen
+ * operator reached through nn.Module.  Each entry point below therefore cites the reference call
+ * site(s) whose ATen operator it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch types.  All pointers are DEVICE pointers unless a name ends
+ *    in `_host`.  The caller owns every buffer (activations, workspaces); nothing is allocated,
+ *    freed or synchronised inside the library.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - activations are NHWC fp32: element (n,h,w,c) lives at ((n*H+h)*W+w)*ld + c with ld >= C the
+ *    pixel stride in elements ("ld*" arguments), which lets producers write channel slices of a
+ *    concat buffer in place.  All ld and all base pointers must be multiples of 4 elements (16 B).
+ *  - filters are KRSC fp32 (K output channels, RxS taps, C input channels, C contiguous).
+ *  - return value: SEGMI_OK (0) or a negative segmi_status; segmi_strerror() names it.
+ */
+#ifndef SEGMI_H
+#define SEGMI_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* segmi_stream_t; /* hipStream_t */
+
+enum segmi_status {
+    SEGMI_OK = 0,
+    SEGMI_ERR_BADARG = -1,    /* null pointer, non-positive size, unsupported combination */
+    SEGMI_ERR_ALIGN = -2,     /* ld / channel count / pointer not 16-byte aligned */
+    SEGMI_ERR_WORKSPACE = -3, /* workspace smaller than segmi_*_workspace() reports */
+    SEGMI_ERR_LAUNCH = -4     /* hipGetLastError() after the launch */
+};
+const char* segmi_strerror(int status);
+/* library / ABI version, bumped on any signature change */
+int segmi_abi_version(void);
+
+/* ------------------------------------------------------------------ layout transforms */
+/* NCHW-contiguous -> NHWC(ld) (zero-filling channels C..ld-1) and back.  Used only at the model
+ * boundary (reference: data arrives NCHW from base/base_dataset.py:125-136). */
+int segmi_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, segmi_stream_t stream);
+int segmi_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int ld, segmi_stream_t stream);
+/* dst[row, 0:C] = src[row, 0:C] for `rows` rows with independent row strides; dst columns
+ * C..Cfill-1 are zero-filled (Cfill >= C).  Replaces torch.cat (models/pspnet.py:37,
+ * models/deeplabv3_plus.py:293,329, models/unet.py:56) and pads/crops filter channels. */
+int segmi_copy_rows(const float* src, int ld_src, float* dst, int ld_dst, long rows, int C, int Cfill, segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ dense convolution (K1)
+ * Replaces aten::conv2d / convolution_backward at every nn.Conv2d call site:
+ * models/resnet.py:80-87,137-145,184-185; models/pspnet.py:18,27,61,65,69;
+ * models/deeplabv3_plus.py:21,80,94,143,146,256,275,279,306,312-319; models/unet.py:15,18,77.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged NHWC / KRSC tiles. */
+typedef struct segmi_conv_desc {
+    int N, H, W, C; /* input  x [N,H,W,C], pixel stride ldx; C % 4 == 0 */
+    int K, R, S;    /* filter w [K,R,S,C] */
+    int P, Q;       /* output y [N,P,Q,K], pixel stride ldy; P = (H+2*pad-dil*(R-1)-1)/stride+1 */
+    int stride, pad, dil;
+    int ldx, ldy;
+} segmi_conv_desc;
+
+/* y = conv(x, w) (+ bias[k]) (+ y if accumulate) */
+int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
+                     int accumulate, segmi_stream_t stream);
+/* dx = conv_transpose(dy, w) (+ dx if accumulate).  w_crsk is the filter re-laid as [C,R,S,K]
+ * (segmi_filter_krsc_to_crsk); requires K % 4 == 0 padding handled by the caller via ldy. */
+int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                       segmi_stream_t stream);
+/* dw[K,R,S,C] = sum_{n,p,q} dy (x) x ; deterministic split-K through `workspace`. */
+size_t segmi_conv2d_wgrad_workspace(const segmi_conv_desc* d);
+int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
+                       size_t workspace_bytes, segmi_stream_t stream);
+int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, int S, int C, int Kpad,
+                              segmi_stream_t stream);
+/* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */
+size_t segmi_colsum_workspace(long rows, int C);
+int segmi_colsum(const float* dy, int ld, long rows, int C, float* out, void* workspace, size_t workspace_bytes,
+                 segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ batch norm (K4/K5/K6)
+ * Replaces aten::native_batch_norm(+_backward), relu_/threshold_backward and the residual add_:
+ * every nn.BatchNorm2d call site (61 in PSPNet-R50), F.batch_norm fallback
+ * utils/sync_batchnorm/batchnorm.py:65-68, nn.ReLU(inplace=True), models/resnet.py:118.
+ * stats: per-channel (count, mean, M2) by Welford + Chan merge (matches two-pass F.batch_norm);
+ * SyncBN all-reduces the packed partial [count, mean, M2] between the two calls. */
+size_t segmi_bn_stats_workspace(long rows, int C);
+/* partial[3*C] = {count (replicated per channel), mean, M2} of x[rows, C] */
+int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, void* workspace, size_t workspace_bytes,
+                   segmi_stream_t stream);
+/* Merge `nparts` packed partials (e.g. one per rank after all-gather; nparts = 1 locally) and
+ * produce mean/invstd, scale = gamma*invstd, shift = beta - mean*scale; update running stats
+ * in place with `momentum` (unbiased var) when running_mean != NULL, and bump
+ * *num_batches_tracked (nn.BatchNorm2d bookkeeping) when that pointer is non-NULL.
+ * clamp_mode = 0: invstd = 1/sqrt(var+eps) (nn.BatchNorm2d);  1: clamp(var,eps)^-0.5
+ * (utils/sync_batchnorm/batchnorm.py:145). */
+int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
+                      float momentum, int clamp_mode, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                      segmi_stream_t stream);
+/* eval / frozen BN: scale/shift from running statistics */
+int segmi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                         float eps, int C, float* mean, float* invstd, float* scale, float* shift,
+                         segmi_stream_t stream);
+/* y = x*scale + shift (+ residual) ; relu optional */
+int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, long rows, int C,
+                   const float* scale, const float* shift, int relu, segmi_stream_t stream);
+/* sums[2*C] = {sum dy', sum dy'*xhat},  dy' = relu ? dy*[y>0] : dy  */
+size_t segmi_bn_bwd_reduce_workspace(long rows, int C);
+int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
+                        const float* mean, const float* invstd, int relu, float* sums, void* workspace,
+                        size_t workspace_bytes, segmi_stream_t stream);
+/* dgamma = sums[C:2C], dbeta = sums[0:C];
+ * training: dx = scale*(dy' - sums0/count - xhat*sums1/count); eval (frozen): dx = scale*dy'.
+ * d_residual (optional) = dy'.  `count` is the (global) element count per channel. */
+int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
+                       const float* mean, const float* invstd, const float* scale, const float* sums, float count,
+                       int relu, int training, float* dx, int lddx, float* dres, int lddres, segmi_stream_t stream);
+/* standalone ReLU (models/deeplabv3_plus.py:99-101,210) */
+int segmi_relu_fwd(const float* x, int ldx, float* y, int ldy, long rows, int C, segmi_stream_t stream);
+int segmi_relu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, long rows, int C,
+                   segmi_stream_t stream);
+/* out = a + b (residual sum of Xception blocks models/deeplabv3_plus.py:131; gradient accumulation) */
+int segmi_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, long rows, int C,
+              segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling / resize (K7/K8/K9) */
+/* aten::max_pool2d_with_indices (+bwd): models/resnet.py:151, models/deeplabv3_plus.py:24,
+ * models/unet.py:27.  idx holds the winning tap (r*k+s) per element, 1 byte each. */
+int segmi_maxpool_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, int P,
+                      int Q, int k, int stride, int pad, segmi_stream_t stream);
+int segmi_maxpool_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int N, int H, int W, int C,
+                      int P, int Q, int k, int stride, int pad, segmi_stream_t stream);
+/* aten::adaptive_avg_pool2d (+bwd): models/pspnet.py:26 (bins 1,2,3,6), models/deeplabv3_plus.py:274 */
+int segmi_adaptive_avgpool_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH, int OW,
+                               segmi_stream_t stream);
+int segmi_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int OH,
+                               int OW, int accumulate, segmi_stream_t stream);
+/* aten::upsample_bilinear2d (+bwd), align_corners in {0,1}: models/pspnet.py:35-36,86,91;
+ * models/deeplabv3_plus.py:291,328,361; models/unet.py:46-47.  bwd is the exact transpose in
+ * gather form (deterministic, no atomics). */
+int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH, int OW,
+                       int align_corners, segmi_stream_t stream);
+int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                       int align_corners, segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ dropout (K14)
+ * nn.Dropout2d(0.1) models/pspnet.py:22,68 (per (n,c) mask) and nn.Dropout models/deeplabv3_plus.py:282,318
+ * (per element).  The mask is a counter-based hash of (seed, index): regenerated in backward. */
+int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, int C, float p, int channelwise,
+                  uint64_t seed, segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ per-pixel losses (K10/K11/K12) */
+/* CrossEntropyLoss2d (utils/losses.py:24-31): mean over target != ignore_index of -log_softmax.
+ * fwd writes lse[rows] and loss_out = {loss, n_valid}; bwd recomputes softmax from (logits, lse):
+ * dlogits = (softmax - onehot) * (*grad_out) / n_valid, 0 at ignored pixels. */
+size_t segmi_ce_workspace(long rows);
+int segmi_ce_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
+                 float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
+                 long ignore_index, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
+                 segmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGMI_H */

@@ -1,0 +1,431 @@
+// Batch normalisation (training and frozen), fused ReLU / residual add, and their backward.
+// Replaces aten::native_batch_norm(+_backward), relu_/threshold_backward and add_ at every
+// nn.BatchNorm2d / nn.ReLU(inplace=True) / `out += residual` site of the reference
+// (models/resnet.py:101-121, models/pspnet.py:17-30,64-70, models/unet.py:12-21,
+//  models/deeplabv3_plus.py:70-132,260-330; F.batch_norm fallback utils/sync_batchnorm/batchnorm.py:65-68).
+//
+// All kernels are HBM-bound streams over an NHWC [rows, C] matrix (rows = N*H*W):
+//   bn_stats      1 read          -> packed partial {count, mean, M2} per channel (Welford / Chan)
+//   bn_apply      1 read (+1) 1 write: y = x*scale + shift (+ residual), optional ReLU
+//   bn_bwd_reduce 2-3 reads       -> {sum dy', sum dy'*xhat}
+//   bn_bwd_apply  2-3 reads, 1-2 writes
+// The packed partials are what SyncBN all-reduces over RCCL between stats and finalize
+// (reference semantics: utils/sync_batchnorm/batchnorm.py:105-145, re-expressed with Chan's merge so
+// the multi-GPU result matches single-device global-batch F.batch_norm).
+#include "rowgeom.h"
+
+namespace {
+
+struct Wf4 {  // Welford state for 4 channels sharing one count
+    float n;
+    float4 mean, m2;
+};
+__device__ __forceinline__ void wf_init(Wf4& w) { w.n = 0.f; w.mean = zero4(); w.m2 = zero4(); }
+__device__ __forceinline__ void wf_push(Wf4& w, float4 x) {
+    w.n += 1.f;
+    const float inv = 1.f / w.n;
+    float d;
+    d = x.x - w.mean.x; w.mean.x += d * inv; w.m2.x += d * (x.x - w.mean.x);
+    d = x.y - w.mean.y; w.mean.y += d * inv; w.m2.y += d * (x.y - w.mean.y);
+    d = x.z - w.mean.z; w.mean.z += d * inv; w.m2.z += d * (x.z - w.mean.z);
+    d = x.w - w.mean.w; w.mean.w += d * inv; w.m2.w += d * (x.w - w.mean.w);
+}
+__device__ __forceinline__ void chan1(float na, float& ma, float& qa, float nb, float mb, float qb, float n) {
+    const float d = mb - ma;
+    const float f = nb / n;
+    ma += d * f;
+    qa += qb + d * d * na * f;
+}
+__device__ __forceinline__ void wf_merge(Wf4& a, const Wf4& b) {
+    const float n = a.n + b.n;
+    if (n == 0.f) return;
+    chan1(a.n, a.mean.x, a.m2.x, b.n, b.mean.x, b.m2.x, n);
+    chan1(a.n, a.mean.y, a.m2.y, b.n, b.mean.y, b.m2.y, n);
+    chan1(a.n, a.mean.z, a.m2.z, b.n, b.mean.z, b.m2.z, n);
+    chan1(a.n, a.mean.w, a.m2.w, b.n, b.mean.w, b.m2.w, n);
+    a.n = n;
+}
+
+// part: [gridDim.y][3][C4*4] = {n, mean, m2}
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int ld, long rows, int c4n,
+                                                               float* __restrict__ part) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 < c4n;
+    Wf4 w;
+    wf_init(w);
+    // contiguous row range per block: keeps the per-thread Welford count small and exact
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+    if (cok)
+#pragma unroll 4
+        for (long r = r0 + threadIdx.y; r < r1; r += blockDim.y) wf_push(w, ld4(x + r * ld + c4 * 4));
+    __shared__ Wf4 sm[256];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    sm[t] = w;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            Wf4 a = sm[t];
+            wf_merge(a, sm[t + s * blockDim.x]);
+            sm[t] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const Wf4 a = sm[t];
+        const int C = c4n * 4;
+        float* o = part + (long)blockIdx.y * 3 * C;
+        st4(o + c4 * 4, make_float4(a.n, a.n, a.n, a.n));
+        st4(o + C + c4 * 4, a.mean);
+        st4(o + 2 * C + c4 * 4, a.m2);
+    }
+}
+
+// merge nparts packed partials (stride 3*Cp each) into out[3*Cp]; one thread per channel
+__global__ void bn_stats_merge_kernel(const float* __restrict__ part, int nparts, int Cp, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    float n = 0.f, m = 0.f, q = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        const float* p = part + (long)i * 3 * Cp;
+        const float nb = p[c];
+        if (nb > 0.f) {
+            const float nn = n + nb;
+            chan1(n, m, q, nb, p[Cp + c], p[2 * Cp + c], nn);
+            n = nn;
+        }
+    }
+    out[c] = n; out[Cp + c] = m; out[2 * Cp + c] = q;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int Cp, const float* gamma,
+                                   const float* beta, float eps, float momentum, int clamp_mode, float* running_mean,
+                                   float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                                   float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    float n = 0.f, m = 0.f, q = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        const float* p = part + (long)i * 3 * Cp;
+        const float nb = p[c];
+        if (nb > 0.f) {
+            const float nn = n + nb;
+            chan1(n, m, q, nb, p[Cp + c], p[2 * Cp + c], nn);
+            n = nn;
+        }
+    }
+    const float var = q / n;  // biased
+    const float is = clamp_mode ? 1.f / sqrtf(fmaxf(var, eps)) : 1.f / sqrtf(var + eps);
+    mean[c] = m;
+    invstd[c] = is;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * is;
+    scale[c] = sc;
+    shift[c] = b - m * sc;
+    if (running_mean) {
+        const float unbiased = q / fmaxf(n - 1.f, 1.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
+                                      int C, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = rm[c];
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = b - rm[c] * g * is;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res,
+                                                       int ldr, float* __restrict__ y, int ldy, long rows, int c4n,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const float4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        float4 v = ld4(x + r * ldx + c4 * 4);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (RES) {
+            const float4 q = ld4(res + r * ldr + c4 * 4);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        st4(y + r * ldy + c4 * 4, v);
+    }
+}
+
+// part: [gridDim.y][2][Cp]
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                            int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ part) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 < c4n;
+    float4 s0 = zero4(), s1 = zero4();
+    if (cok) {
+        const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
+        for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+            float4 g = ld4(dy + r * lddy + c4 * 4);
+            const float4 v = ld4(x + r * ldx + c4 * 4);
+            if (RELU) {
+                const float4 o = ld4(y + r * ldy + c4 * 4);
+                g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+            }
+            s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+            s1.x += g.x * (v.x - mu.x) * is.x; s1.y += g.y * (v.y - mu.y) * is.y;
+            s1.z += g.z * (v.z - mu.z) * is.z; s1.w += g.w * (v.w - mu.w) * is.w;
+        }
+    }
+    __shared__ float4 sm0[256], sm1[256];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    sm0[t] = s0; sm1[t] = s1;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            float4 a = sm0[t], b = sm0[t + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm0[t] = a;
+            a = sm1[t]; b = sm1[t + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm1[t] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const int Cp = c4n * 4;
+        float* o = part + (long)blockIdx.y * 2 * Cp;
+        st4(o + c4 * 4, sm0[t]);
+        st4(o + Cp + c4 * 4, sm1[t]);
+    }
+}
+
+__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[(long)p * n + i];
+    out[i] = a;
+}
+
+template <bool RELU, bool TRAIN, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                           int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ sums,
+                                                           float inv_count, float* __restrict__ dx, int lddx,
+                                                           float* __restrict__ dres, int lddres) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const int Cp = c4n * 4;
+    const float4 sc = ld4(scale + c4 * 4);
+    float4 mu = zero4(), is = zero4(), k0 = zero4(), k1 = zero4();
+    if (TRAIN) {
+        mu = ld4(mean + c4 * 4); is = ld4(invstd + c4 * 4);
+        const float4 a = ld4(sums + c4 * 4), b = ld4(sums + Cp + c4 * 4);
+        k0 = make_float4(a.x * inv_count, a.y * inv_count, a.z * inv_count, a.w * inv_count);
+        k1 = make_float4(b.x * inv_count, b.y * inv_count, b.z * inv_count, b.w * inv_count);
+    }
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        float4 g = ld4(dy + r * lddy + c4 * 4);
+        if (RELU) {
+            const float4 o = ld4(y + r * ldy + c4 * 4);
+            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        if (DRES) st4(dres + r * lddres + c4 * 4, g);
+        float4 d;
+        if (TRAIN) {
+            const float4 v = ld4(x + r * ldx + c4 * 4);
+            d.x = sc.x * (g.x - k0.x - (v.x - mu.x) * is.x * k1.x);
+            d.y = sc.y * (g.y - k0.y - (v.y - mu.y) * is.y * k1.y);
+            d.z = sc.z * (g.z - k0.z - (v.z - mu.z) * is.z * k1.z);
+            d.w = sc.w * (g.w - k0.w - (v.w - mu.w) * is.w * k1.w);
+        } else {
+            d = make_float4(sc.x * g.x, sc.y * g.y, sc.z * g.z, sc.w * g.w);
+        }
+        st4(dx + r * lddx + c4 * 4, d);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                       long rows, int c4n) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        float4 v = ld4(x + r * ldx + c4 * 4);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        st4(y + r * ldy + c4 * 4, v);
+    }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
+                                                       int ldy, float* __restrict__ dx, int lddx, long rows, int c4n) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        float4 g = ld4(dy + r * lddy + c4 * 4);
+        const float4 o = ld4(y + r * ldy + c4 * 4);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        st4(dx + r * lddx + c4 * 4, g);
+    }
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                  float* __restrict__ o, int ldo, long rows, int c4n) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        float4 u = ld4(a + r * lda + c4 * 4);
+        const float4 v = ld4(b + r * ldb + c4 * 4);
+        u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+        st4(o + r * ldo + c4 * 4, u);
+    }
+}
+
+constexpr int STATS_MAX_PARTS = 512;
+int stats_parts(long rows) {
+    long p = (rows + 127) / 128;  // >= 128 rows per partial block
+    if (p < 1) p = 1;
+    if (p > STATS_MAX_PARTS) p = STATS_MAX_PARTS;
+    return (int)p;
+}
+bool ld_ok(int ld, int C) { return ld >= ((C + 3) & ~3) && (ld & 3) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t segmi_bn_stats_workspace(long rows, int C) {
+    const int Cp = (C + 3) & ~3;
+    return (size_t)stats_parts(rows) * 3 * Cp * sizeof(float);
+}
+
+int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, void* workspace, size_t workspace_bytes,
+                   segmi_stream_t stream) {
+    if (!x || !partial || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(ld, C)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_bn_stats_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = stats_parts(rows);
+    RowGeom g = row_geom(rows, C, 1, 1);
+    g.grid.y = parts;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
+    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, parts, C, partial);
+    return segmi_launch_status();
+}
+
+int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
+                      float momentum, int clamp_mode, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                      segmi_stream_t stream) {
+    if (!partials || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return SEGMI_ERR_BADARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SEGMI_ERR_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, C,
+                       gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift);
+    return segmi_launch_status();
+}
+
+int segmi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                         float eps, int C, float* mean, float* invstd, float* scale, float* shift,
+                         segmi_stream_t stream) {
+    if (!running_mean || !running_var || C <= 0 || !mean || !invstd || !scale || !shift) return SEGMI_ERR_BADARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                       running_var, gamma, beta, eps, C, mean, invstd, scale, shift);
+    return segmi_launch_status();
+}
+
+int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, long rows, int C,
+                   const float* scale, const float* shift, int relu, segmi_stream_t stream) {
+    if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(ldx, C) || !ld_ok(ldy, C) || (residual && !ld_ok(ldr, C))) return SEGMI_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
+#define LAUNCH_APPLY(R, S) hipLaunchKernelGGL((bn_apply_kernel<R, S>), g.grid, g.block, 0, st, x, ldx, residual, ldr, y, ldy, rows, g.c4, scale, shift)
+    if (relu) { if (residual) LAUNCH_APPLY(true, true); else LAUNCH_APPLY(true, false); }
+    else      { if (residual) LAUNCH_APPLY(false, true); else LAUNCH_APPLY(false, false); }
+#undef LAUNCH_APPLY
+    return segmi_launch_status();
+}
+
+static int bwd_parts(long rows) {
+    long p = (rows + 255) / 256;
+    if (p < 1) p = 1;
+    if (p > STATS_MAX_PARTS) p = STATS_MAX_PARTS;
+    return (int)p;
+}
+size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
+    const int Cp = (C + 3) & ~3;
+    return (size_t)bwd_parts(rows) * 2 * Cp * sizeof(float);
+}
+
+int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
+                        const float* mean, const float* invstd, int relu, float* sums, void* workspace,
+                        size_t workspace_bytes, segmi_stream_t stream) {
+    if (!dy || !x || !mean || !invstd || !sums || rows <= 0 || C <= 0 || (relu && !y)) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_bn_bwd_reduce_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bwd_parts(rows);
+    RowGeom g = row_geom(rows, C, 1, 1);
+    g.grid.y = parts;
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)workspace, parts, 2 * C, sums);
+    return segmi_launch_status();
+}
+
+int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
+                       const float* mean, const float* invstd, const float* scale, const float* sums, float count,
+                       int relu, int training, float* dx, int lddx, float* dres, int lddres, segmi_stream_t stream) {
+    if (!dy || !scale || !dx || rows <= 0 || C <= 0 || (relu && !y)) return SEGMI_ERR_BADARG;
+    if (training && (!x || !mean || !invstd || !sums || count <= 0.f)) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(lddx, C) || (training && !ld_ok(ldx, C)) || (relu && !ld_ok(ldy, C)) ||
+        (dres && !ld_ok(lddres, C)))
+        return SEGMI_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
+    const float inv = training ? 1.f / count : 0.f;
+#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, sums, inv, dx, lddx, dres, lddres)
+    const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
+    switch (key) {
+        case 0: LAUNCH_BA(false, false, false); break;
+        case 1: LAUNCH_BA(false, false, true); break;
+        case 2: LAUNCH_BA(false, true, false); break;
+        case 3: LAUNCH_BA(false, true, true); break;
+        case 4: LAUNCH_BA(true, false, false); break;
+        case 5: LAUNCH_BA(true, false, true); break;
+        case 6: LAUNCH_BA(true, true, false); break;
+        default: LAUNCH_BA(true, true, true); break;
+    }
+#undef LAUNCH_BA
+    return segmi_launch_status();
+}
+
+int segmi_relu_fwd(const float* x, int ldx, float* y, int ldy, long rows, int C, segmi_stream_t stream) {
+    if (!x || !y || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if (!ld_ok(ldx, C) || !ld_ok(ldy, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(relu_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, rows, g.c4);
+    return segmi_launch_status();
+}
+int segmi_relu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, long rows, int C,
+                   segmi_stream_t stream) {
+    if (!dy || !y || !dx || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if (!ld_ok(lddy, C) || !ld_ok(ldy, C) || !ld_ok(lddx, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(relu_bwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, dy, lddy, y, ldy, dx, lddx, rows, g.c4);
+    return segmi_launch_status();
+}
+int segmi_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, long rows, int C,
+              segmi_stream_t stream) {
+    if (!a || !b || !out || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if (!ld_ok(lda, C) || !ld_ok(ldb, C) || !ld_ok(ldo, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(add_kernel, g.grid, g.block, 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, rows, g.c4);
+    return segmi_launch_status();
+}
+
+}  // extern "C"

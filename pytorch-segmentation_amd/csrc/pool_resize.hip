@@ -1,0 +1,323 @@
+// Max pooling, adaptive average pooling (PSP pyramid / ASPP image pool) and bilinear resize,
+// forward and backward, NHWC fp32.  All backward kernels are written in gather form (each input
+// element collects from the outputs that reference it): deterministic, no atomics.
+//
+// Replaces (reference call sites):
+//   aten::max_pool2d_with_indices(+bwd)  models/resnet.py:151, models/deeplabv3_plus.py:24, models/unet.py:27
+//   aten::adaptive_avg_pool2d(+bwd)      models/pspnet.py:26, models/deeplabv3_plus.py:274
+//   aten::upsample_bilinear2d(+bwd)      models/pspnet.py:35-36,86,91; models/deeplabv3_plus.py:291,328,361;
+//                                        models/unet.py:46-47
+#include "rowgeom.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ max pool
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C, int P, int Q,
+                                                          int k, int stride, int pad) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const long rows = (long)N * P * Q;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int q = (int)(r % Q);
+        const long t = r / Q;
+        const int p = (int)(t % P), n = (int)(t / P);
+        const int h0 = p * stride - pad, w0 = q * stride - pad;
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
+        bool first = true;
+        for (int a = 0; a < k; ++a) {
+            const int h = h0 + a;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int b = 0; b < k; ++b) {
+                const int w = w0 + b;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const float4 v = ld4(x + ((long)(n * H + h) * W + w) * ldx + c4 * 4);
+                const uint8_t tap = (uint8_t)(a * k + b);
+                // aten (cpu): take the first maximum; NaN wins
+                if (first || v.x > best.x || v.x != v.x) { best.x = v.x; bi.x = tap; }
+                if (first || v.y > best.y || v.y != v.y) { best.y = v.y; bi.y = tap; }
+                if (first || v.z > best.z || v.z != v.z) { best.z = v.z; bi.z = tap; }
+                if (first || v.w > best.w || v.w != v.w) { best.w = v.w; bi.w = tap; }
+                first = false;
+            }
+        }
+        st4(y + r * ldy + c4 * 4, best);
+        *reinterpret_cast<uchar4*>(idx + r * (long)(c4n * 4) + c4 * 4) = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int lddx, int N, int H, int W, int C, int P,
+                                                          int Q, int k, int stride, int pad) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const long rows = (long)N * H * W;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int w = (int)(r % W);
+        const long t = r / W;
+        const int h = (int)(t % H), n = (int)(t / H);
+        // outputs p with p*stride - pad <= h <= p*stride - pad + k - 1
+        int p_lo = h + pad - k + 1; p_lo = p_lo <= 0 ? 0 : (p_lo + stride - 1) / stride;
+        int p_hi = (h + pad) / stride; if (p_hi > P - 1) p_hi = P - 1;
+        int q_lo = w + pad - k + 1; q_lo = q_lo <= 0 ? 0 : (q_lo + stride - 1) / stride;
+        int q_hi = (w + pad) / stride; if (q_hi > Q - 1) q_hi = Q - 1;
+        float4 acc = zero4();
+        for (int p = p_lo; p <= p_hi; ++p) {
+            const int a = h + pad - p * stride;
+            for (int q = q_lo; q <= q_hi; ++q) {
+                const int b = w + pad - q * stride;
+                const uint8_t tap = (uint8_t)(a * k + b);
+                const long o = (long)(n * P + p) * Q + q;
+                const uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o * (long)(c4n * 4) + c4 * 4);
+                const float4 g = ld4(dy + o * lddy + c4 * 4);
+                if (bi.x == tap) acc.x += g.x;
+                if (bi.y == tap) acc.y += g.y;
+                if (bi.z == tap) acc.z += g.z;
+                if (bi.w == tap) acc.w += g.w;
+            }
+        }
+        st4(dx + r * lddx + c4 * 4, acc);
+    }
+}
+
+// ------------------------------------------------------------------------- adaptive average pool
+__device__ __forceinline__ int aap_start(int o, int in, int out) { return (int)(((long)o * in) / out); }
+__device__ __forceinline__ int aap_end(int o, int in, int out) { return (int)(((long)(o + 1) * in + out - 1) / out); }
+
+// one workgroup per (output bin, channel tile): the ry row-lanes stride over the window pixels
+__global__ __launch_bounds__(256) void aap_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
+                                                      int H, int W, int C, int OH, int OW) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool cok = c4 < c4n;
+    const int bin = blockIdx.x;
+    const int ow = bin % OW, t = bin / OW, oh = t % OH, n = t / OH;
+    const int h0 = aap_start(oh, H, OH), h1 = aap_end(oh, H, OH);
+    const int w0 = aap_start(ow, W, OW), w1 = aap_end(ow, W, OW);
+    const int ww = w1 - w0, cnt = (h1 - h0) * ww;
+    float4 acc = zero4();
+    if (cok)
+        for (int i = threadIdx.y; i < cnt; i += blockDim.y) {
+            const int h = h0 + i / ww, w = w0 + i % ww;
+            const float4 v = ld4(x + ((long)(n * H + h) * W + w) * ldx + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    __shared__ float4 sm[256];
+    const int tix = threadIdx.y * blockDim.x + threadIdx.x;
+    sm[tix] = acc;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm[tix] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        float4 a = sm[tix];
+        const float inv = 1.f / (float)cnt;
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        st4(y + (long)bin * ldy + c4 * 4, a);
+    }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void aap_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                      int N, int H, int W, int C, int OH, int OW) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const long rows = (long)N * H * W;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int w = (int)(r % W);
+        const long t = r / W;
+        const int h = (int)(t % H), n = (int)(t / H);
+        const int ohc = (int)(((long)h * OH) / H), owc = (int)(((long)w * OW) / W);
+        float4 acc = ACC ? ld4(dx + r * lddx + c4 * 4) : zero4();
+        const int ohe = min(OH - 1, (int)(((long)(h + 1) * OH + H - 1) / H));
+        const int owe = min(OW - 1, (int)(((long)(w + 1) * OW + W - 1) / W));
+        for (int oh = max(ohc - 1, 0); oh <= ohe; ++oh) {
+            const int h0 = aap_start(oh, H, OH), h1 = aap_end(oh, H, OH);
+            if (h < h0 || h >= h1) continue;
+            for (int ow = max(owc - 1, 0); ow <= owe; ++ow) {
+                const int w0 = aap_start(ow, W, OW), w1 = aap_end(ow, W, OW);
+                if (w < w0 || w >= w1) continue;
+                const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                const float4 g = ld4(dy + ((long)(n * OH + oh) * OW + ow) * lddy + c4 * 4);
+                acc.x += g.x * inv; acc.y += g.y * inv; acc.z += g.z * inv; acc.w += g.w * inv;
+            }
+        }
+        st4(dx + r * lddx + c4 * 4, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------ bilinear
+// Source coordinate exactly as aten's area_pixel_compute_source_index (fp32):
+//   align_corners: src = dst * (in-1)/(out-1)            (scale 0 when out == 1)
+//   otherwise    : src = max(0, fma(in/out, dst+0.5, -0.5))
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ float bl_scale(int in, int out, int ac) {
+    if (ac) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+__device__ __forceinline__ Lerp bl_src(int dst, float scale, int in, int ac) {
+    float s = ac ? scale * (float)dst : fmaxf(__fmaf_rn(scale, (float)dst + 0.5f, -0.5f), 0.f);
+    Lerp L;
+    L.i0 = min((int)s, in - 1);
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = s - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                           int N, int H, int W, int C, int OH, int OW, int ac) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
+    const long rows = (long)N * OH * OW;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int ow = (int)(r % OW);
+        const long t = r / OW;
+        const int oh = (int)(t % OH), n = (int)(t / OH);
+        const Lerp a = bl_src(oh, sh, H, ac), b = bl_src(ow, sw, W, ac);
+        const float* base = x + (long)n * H * W * ldx + c4 * 4;
+        const float4 v00 = ld4(base + ((long)a.i0 * W + b.i0) * ldx), v01 = ld4(base + ((long)a.i0 * W + b.i1) * ldx);
+        const float4 v10 = ld4(base + ((long)a.i1 * W + b.i0) * ldx), v11 = ld4(base + ((long)a.i1 * W + b.i1) * ldx);
+        float4 o;
+        o.x = a.l0 * (b.l0 * v00.x + b.l1 * v01.x) + a.l1 * (b.l0 * v10.x + b.l1 * v11.x);
+        o.y = a.l0 * (b.l0 * v00.y + b.l1 * v01.y) + a.l1 * (b.l0 * v10.y + b.l1 * v11.y);
+        o.z = a.l0 * (b.l0 * v00.z + b.l1 * v01.z) + a.l1 * (b.l0 * v10.z + b.l1 * v11.z);
+        o.w = a.l0 * (b.l0 * v00.w + b.l1 * v01.w) + a.l1 * (b.l0 * v10.w + b.l1 * v11.w);
+        st4(y + r * ldy + c4 * 4, o);
+    }
+}
+
+// candidate output range [lo, hi] whose source coordinate can touch input index i
+__device__ __forceinline__ void bl_range(int i, float scale, int in, int out, int ac, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    float a, b;
+    if (ac) { a = ((float)i - 1.f) / scale; b = ((float)i + 1.f) / scale; }
+    else    { a = ((float)i - 0.5f) / scale - 0.5f; b = ((float)i + 1.5f) / scale - 0.5f; }
+    lo = max(0, (int)floorf(a) - 1);
+    hi = min(out - 1, (int)ceilf(b) + 1);
+    if (i == 0) lo = 0;              // clamped sources (src < 0 -> 0)
+    if (i == in - 1) hi = out - 1;   // clamped i1
+}
+
+// one workgroup per (input pixel, channel tile); row-lanes stride over candidate outputs
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                           int lddx, int N, int H, int W, int C, int OH, int OW, int ac) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool cok = c4 < c4n;
+    const int pix = blockIdx.x;
+    const int w = pix % W, t = pix / W, h = t % H, n = t / H;
+    const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
+    int hlo, hhi, wlo, whi;
+    bl_range(h, sh, H, OH, ac, hlo, hhi);
+    bl_range(w, sw, W, OW, ac, wlo, whi);
+    const int nw = whi - wlo + 1, cnt = (hhi - hlo + 1) * nw;
+    float4 acc = zero4();
+    if (cok)
+        for (int i = threadIdx.y; i < cnt; i += blockDim.y) {
+            const int oh = hlo + i / nw, ow = wlo + i % nw;
+            const Lerp a = bl_src(oh, sh, H, ac), b = bl_src(ow, sw, W, ac);
+            float wh = 0.f, ww = 0.f;
+            if (a.i0 == h) wh += a.l0;
+            if (a.i1 == h) wh += a.l1;
+            if (b.i0 == w) ww += b.l0;
+            if (b.i1 == w) ww += b.l1;
+            const float wt = wh * ww;
+            if (wt != 0.f) {
+                const float4 g = ld4(dy + ((long)(n * OH + oh) * OW + ow) * lddy + c4 * 4);
+                acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
+            }
+        }
+    __shared__ float4 sm[256];
+    const int tix = threadIdx.y * blockDim.x + threadIdx.x;
+    sm[tix] = acc;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm[tix] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) st4(dx + (long)pix * lddx + c4 * 4, sm[tix]);
+}
+
+bool ldok(int ld, int C) { return ld >= ((C + 3) & ~3) && (ld & 3) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int segmi_maxpool_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, int P,
+                      int Q, int k, int stride, int pad, segmi_stream_t stream) {
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
+        return SEGMI_ERR_BADARG;
+    if (!ldok(ldx, C) || !ldok(ldy, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * P * Q, C, 2, SEGMI_MAX_GRID * 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, idx, N, H, W, C, P, Q, k, stride, pad);
+    return segmi_launch_status();
+}
+
+int segmi_maxpool_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int N, int H, int W, int C,
+                      int P, int Q, int k, int stride, int pad, segmi_stream_t stream) {
+    if (!dy || !dx || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || P <= 0 || Q <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
+        return SEGMI_ERR_BADARG;
+    if (!ldok(lddy, C) || !ldok(lddx, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID * 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, dy, lddy, idx, dx, lddx, N, H, W, C, P, Q, k, stride, pad);
+    return segmi_launch_status();
+}
+
+int segmi_adaptive_avgpool_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH, int OW,
+                               segmi_stream_t stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    if ((long)N * OH * OW > 0x7fffffffL) return SEGMI_ERR_BADARG;
+    if (!ldok(ldx, C) || !ldok(ldy, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom(1, C, 1, 1);
+    g.grid = dim3((unsigned)(N * OH * OW), g.grid.x);  // item on x (2^31 limit), channel tile on y
+    hipLaunchKernelGGL(aap_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, N, H, W, C, OH, OW);
+    return segmi_launch_status();
+}
+
+int segmi_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int OH,
+                               int OW, int accumulate, segmi_stream_t stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    if (!ldok(lddy, C) || !ldok(lddx, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID * 4);
+    if (accumulate) hipLaunchKernelGGL((aap_bwd_kernel<true>), g.grid, g.block, 0, (hipStream_t)stream, dy, lddy, dx, lddx, N, H, W, C, OH, OW);
+    else            hipLaunchKernelGGL((aap_bwd_kernel<false>), g.grid, g.block, 0, (hipStream_t)stream, dy, lddy, dx, lddx, N, H, W, C, OH, OW);
+    return segmi_launch_status();
+}
+
+int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH, int OW,
+                       int align_corners, segmi_stream_t stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    if (!ldok(ldx, C) || !ldok(ldy, C)) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * OH * OW, C, 2, SEGMI_MAX_GRID * 4);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, N, H, W, C, OH, OW, align_corners ? 1 : 0);
+    return segmi_launch_status();
+}
+
+int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                       int align_corners, segmi_stream_t stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    if (!ldok(lddy, C) || !ldok(lddx, C)) return SEGMI_ERR_ALIGN;
+    const long pix = (long)N * H * W;
+    if (pix > 0x7fffffffL) return SEGMI_ERR_BADARG;
+    RowGeom g = row_geom(1, C, 1, 1);
+    g.grid = dim3((unsigned)pix, g.grid.x);  // item on x (2^31 limit), channel tile on y
+    hipLaunchKernelGGL(bilinear_bwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, dy, lddy, dx, lddx, N, H, W, C, OH, OW, align_corners ? 1 : 0);
+    return segmi_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""nn.Module building blocks whose forward/backward run on libsegmi kernels.
+
+Each class subclasses the torch module of the same name, so `state_dict()` keys, constructor
+arguments and `isinstance(m, nn.BatchNorm2d)`-style checks of the reference
+(utils/helpers.py:12-22 `initialize_weights`, models/*.py `freeze_bn`,
+utils/sync_batchnorm/batchnorm.py:353-394 `convert_model`) keep working unchanged; only `forward`
+is replaced.  `Sequential` fuses Conv->BN->ReLU chains into the fused kernels while keeping the
+child indices (and therefore the checkpoint key names) of the reference's nn.Sequential containers.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (groups=1) on the implicit-GEMM MFMA kernels; the filter is held KRSC in memory
+    (torch channels_last) so no per-step re-layout is needed."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1:
+            raise ValueError("segmi.nn.Conv2d is dense (groups=1); use DepthwiseConv2d for groups=C")
+        if self.padding_mode != "zeros":
+            raise ValueError("segmi.nn.Conv2d supports zero padding only")
+        for name in ("stride", "padding", "dilation"):
+            v = getattr(self, name)
+            if v[0] != v[1]:
+                raise ValueError("segmi.nn.Conv2d needs symmetric %s, got %s" % (name, (v,)))
+        if self.kernel_size[0] > 1 or self.kernel_size[1] > 1:
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d with optional fused residual add and ReLU (one apply pass)."""
+
+    sync = None  # set by utils.sync_batchnorm.SynchronizedBatchNorm2d
+
+    def forward(self, x, residual=None, relu=False):
+        if self.momentum is None:
+            raise NotImplementedError("cumulative moving average (momentum=None) is not supported")
+        use_batch_stats = self.training or not self.track_running_stats
+        return ops.batch_norm_act(
+            x, self.weight, self.bias,
+            self.running_mean if self.track_running_stats else None,
+            self.running_var if self.track_running_stats else None,
+            self.num_batches_tracked if (self.track_running_stats and self.training) else None,
+            residual=residual, training=use_batch_stats, momentum=self.momentum, eps=self.eps, relu=relu,
+            sync=self.sync if use_batch_stats else None)
+
+
+class ReLU(nn.ReLU):
+    def forward(self, x):
+        return ops.relu(x)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        s = self.stride if isinstance(self.stride, int) else self.stride[0]
+        p = self.padding if isinstance(self.padding, int) else self.padding[0]
+        return ops.max_pool2d(x, k, s, p, self.ceil_mode)
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def forward(self, x):
+        return ops.adaptive_avg_pool2d(x, self.output_size)
+
+
+class Dropout2d(nn.Dropout2d):
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training, channelwise=True)
+
+
+class Dropout(nn.Dropout):
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training, channelwise=False)
+
+
+def run_fused(modules, x):
+    """Run a module chain, fusing BatchNorm2d -> ReLU pairs into one apply pass."""
+    mods = list(modules)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            x = m(x, relu=True)
+            i += 2
+            continue
+        x = m(x)
+        i += 1
+    return x
+
+
+class Sequential(nn.Sequential):
+    """nn.Sequential with the same child indices, executing fused BN+ReLU."""
+
+    def forward(self, x):
+        return run_fused(self, x)
+
+
+def interpolate(x, size, mode="bilinear", align_corners=None):
+    if mode != "bilinear":
+        raise NotImplementedError("only bilinear interpolation is on the hot path")
+    return ops.interpolate_bilinear(x, size, bool(align_corners))

@@ -1,0 +1,562 @@
+"""Functional ops + autograd glue over the libsegmi C ABI.
+
+Tensor convention ("NHWC-backed"): an activation is a logical NCHW fp32 CUDA tensor whose memory is
+NHWC with a pixel stride ld >= round_up(C, 4):  strides == (H*W*ld, 1, W*ld, ld).  Callers of the
+drop-in modules (trainer.py:56-66 of the reference) only look at `.size()`, so the convention is
+invisible to them; plain NCHW-contiguous inputs are converted once at the model boundary by our own
+transpose kernel.  Channels C..round_up(C,4)-1 of a buffer are always zero.
+
+PyTorch is used here for device memory (caching allocator), streams and autograd bookkeeping only:
+every arithmetic op below is a libsegmi kernel, and there is no CPU path — CPU tensors raise.
+"""
+import torch
+
+from ._lib import ConvDesc, SegmiError, check, lib
+
+__all__ = [
+    "conv2d", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
+    "cat", "dropout", "cross_entropy", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
+]
+
+
+def pad4(c):
+    return (c + 3) & ~3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise SegmiError("segmi.%s: tensor is on %s — the segmi hot path only runs on the MI355X "
+                         "(there is deliberately no CPU / eager fallback)" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise SegmiError("segmi.%s: expected float32, got %s" % (what, t.dtype))
+
+
+# --------------------------------------------------------------------------- workspace (per stream)
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer; kernels on one stream run in order, so one buffer per stream is safe."""
+    key = (device.index, _stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- layout helpers
+def empty_nhwc(N, C, H, W, device, ld=None):
+    ld = ld or pad4(C)
+    buf = torch.empty((N, H, W, ld), device=device, dtype=torch.float32)
+    t = buf.permute(0, 3, 1, 2)
+    return t if ld == C else t[:, :C]
+
+
+def ld_of(t):
+    """Pixel stride (elements) of an NHWC-backed tensor, or None if t does not follow the convention."""
+    if t.dim() != 4:
+        return None
+    N, C, H, W = t.shape
+    s = t.stride()
+    if W > 1:
+        ld = s[3]
+    elif H > 1:
+        ld = s[2]
+    elif N > 1:
+        ld = s[0]
+    else:
+        ld = pad4(C)
+    if ld < pad4(C) or (ld & 3):
+        return None
+    if C > 1 and s[1] != 1:
+        return None
+    if W > 1 and s[3] != ld:
+        return None
+    if H > 1 and s[2] != W * ld:
+        return None
+    if N > 1 and s[0] != H * W * ld:
+        return None
+    if (C & 3) and ld != pad4(C):
+        return None  # ragged channel count must own its zero padding
+    if t.data_ptr() & 15:
+        return None
+    return ld
+
+
+def is_nhwc(t):
+    return t.is_cuda and t.dtype == torch.float32 and ld_of(t) is not None
+
+
+def to_nhwc(t, what="to_nhwc"):
+    """Bring any 4-D fp32 CUDA tensor into the NHWC-backed convention (no-op when already there)."""
+    _need_cuda(t, what)
+    if ld_of(t) is not None:
+        return t
+    N, C, H, W = t.shape
+    out = empty_nhwc(N, C, H, W, t.device)
+    ld = pad4(C)
+    if t.is_contiguous():
+        check(lib.segmi_nchw_to_nhwc(t.data_ptr(), out.data_ptr(), N, C, H, W, ld, _stream()), "nchw_to_nhwc")
+    elif t.is_contiguous(memory_format=torch.channels_last):
+        check(lib.segmi_copy_rows(t.data_ptr(), C, out.data_ptr(), ld, N * H * W, C, ld, _stream()), "copy_rows")
+    else:
+        src = t.contiguous()  # arbitrary strided view: allocator-level gather by torch, then our transpose
+        check(lib.segmi_nchw_to_nhwc(src.data_ptr(), out.data_ptr(), N, C, H, W, ld, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw_contiguous(t):
+    """NHWC-backed -> plain contiguous NCHW (only for callers that insist on it)."""
+    t = to_nhwc(t)
+    N, C, H, W = t.shape
+    out = torch.empty((N, C, H, W), device=t.device, dtype=torch.float32)
+    check(lib.segmi_nhwc_to_nchw(t.data_ptr(), out.data_ptr(), N, C, H, W, ld_of(t), _stream()), "nhwc_to_nchw")
+    return out
+
+
+def _rows(t):
+    N, C, H, W = t.shape
+    return N * H * W
+
+
+# --------------------------------------------------------------------------- convolution
+def _filter_is_krsc(w):
+    K, C, R, S = w.shape
+    if R == 1 and S == 1:
+        return w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)
+    return w.is_contiguous(memory_format=torch.channels_last)
+
+
+def _filter_krsc(w, Ce):
+    """Filter as a flat [K,R,S,Ce] device buffer (Ce = channels padded to 4, zero filled).  Returns a
+    tensor that owns or aliases the memory."""
+    K, C, R, S = w.shape
+    if _filter_is_krsc(w):
+        if Ce == C and not (w.data_ptr() & 15):
+            return w
+        out = torch.empty(K * R * S * Ce, device=w.device, dtype=torch.float32)
+        check(lib.segmi_copy_rows(w.data_ptr(), C, out.data_ptr(), Ce, K * R * S, C, Ce, _stream()), "filter pad")
+        return out
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out = torch.empty(K * R * S * Ce, device=w.device, dtype=torch.float32)
+    check(lib.segmi_nchw_to_nhwc(w.data_ptr(), out.data_ptr(), K, C, R, S, Ce, _stream()), "filter kcrs->krsc")
+    return out
+
+
+def _filter_grad_like(dw_krsc, w, Ce):
+    """[K,R,S,Ce] wgrad buffer -> gradient tensor with weight's shape and memory layout."""
+    K, C, R, S = w.shape
+    if _filter_is_krsc(w):
+        if Ce != C:
+            crop = torch.empty(K * R * S * C, device=w.device, dtype=torch.float32)
+            check(lib.segmi_copy_rows(dw_krsc.data_ptr(), Ce, crop.data_ptr(), C, K * R * S, C, C, _stream()), "filter crop")
+            dw_krsc = crop
+        return dw_krsc.view(K, R, S, C).permute(0, 3, 1, 2)
+    out = torch.empty((K, C, R, S), device=w.device, dtype=torch.float32)
+    check(lib.segmi_nhwc_to_nchw(dw_krsc.data_ptr(), out.data_ptr(), K, C, R, S, Ce, _stream()), "filter krsc->kcrs")
+    return out
+
+
+def conv_out_size(H, k, stride, pad, dil):
+    return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        x = to_nhwc(x, "conv2d")
+        _need_cuda(weight, "conv2d")
+        N, C, H, W = x.shape
+        K, Cw, R, S = weight.shape
+        if Cw != C:
+            raise SegmiError("conv2d: input has %d channels, filter expects %d (groups != 1 goes through dwconv)" % (C, Cw))
+        Ce = pad4(C)
+        w = _filter_krsc(weight, Ce)
+        P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+        y = empty_nhwc(N, K, P, Q, x.device)
+        d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
+        check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   y.data_ptr(), 0, _stream()), "conv2d_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (N, C, H, W, K, R, S, P, Q, stride, pad, dil)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, C, H, W, K, R, S, P, Q, stride, pad, dil = ctx.geom
+        dy = to_nhwc(dy, "conv2d.backward")
+        Ce = pad4(C)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            Kp = pad4(K)
+            w = _filter_krsc(weight, Ce)
+            wt = torch.empty(Ce * R * S * Kp, device=x.device, dtype=torch.float32)
+            check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
+            dx = empty_nhwc(N, C, H, W, x.device)
+            d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
+            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
+            nws = lib.segmi_conv2d_wgrad_workspace(d)
+            ws = workspace(nws, x.device) if nws else None
+            dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
+            check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
+                                         ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
+            dw = _filter_grad_like(dwb, weight, Ce)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            rows = N * P * Q
+            nws = lib.segmi_colsum_workspace(rows, K)
+            ws = workspace(nws, x.device)
+            db = torch.empty(K, device=x.device, dtype=torch.float32)
+            check(lib.segmi_colsum(dy.data_ptr(), ld_of(dy), rows, K, db.data_ptr(), ws.data_ptr(), nws, st), "colsum")
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    """aten::conv2d replacement (groups == 1, symmetric stride/padding/dilation)."""
+    return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+# --------------------------------------------------------------------------- batch norm (+ReLU +residual)
+class _BatchNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, num_batches_tracked, training, momentum,
+                eps, relu, sync):
+        x = to_nhwc(x, "batch_norm")
+        N, C, H, W = x.shape
+        if C & 3:
+            raise SegmiError("batch_norm: channel count must be a multiple of 4 (got %d)" % C)
+        rows = N * H * W
+        dev, st = x.device, _stream()
+        if residual is not None:
+            residual = to_nhwc(residual, "batch_norm.residual")
+        coef = torch.empty(4 * C, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift
+        mean, invstd, scale, shift = (coef[i * C:(i + 1) * C] for i in range(4))
+        gp = gamma.data_ptr() if gamma is not None else None
+        bp = beta.data_ptr() if beta is not None else None
+        count = float(rows)
+        if training:
+            nws = lib.segmi_bn_stats_workspace(rows, C)
+            ws = workspace(nws, dev)
+            part = torch.empty(3 * C, device=dev, dtype=torch.float32)
+            check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st), "bn_stats")
+            nparts, clamp = 1, 0
+            if sync is not None:
+                part, nparts, count = sync.gather_stats(part, rows)
+                clamp = sync.clamp_mode
+            if count <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, clamp,
+                                        running_mean.data_ptr() if running_mean is not None else None,
+                                        running_var.data_ptr() if running_var is not None else None,
+                                        num_batches_tracked.data_ptr() if num_batches_tracked is not None else None,
+                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
+                  "bn_finalize")
+        else:
+            check(lib.segmi_bn_eval_coeffs(running_mean.data_ptr(), running_var.data_ptr(), gp, bp, eps, C,
+                                           mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
+                  "bn_eval_coeffs")
+        y = empty_nhwc(N, C, H, W, dev)
+        check(lib.segmi_bn_apply(x.data_ptr(), ld_of(x), residual.data_ptr() if residual is not None else None,
+                                 ld_of(residual) if residual is not None else 0, y.data_ptr(), ld_of(y), rows, C,
+                                 scale.data_ptr(), shift.data_ptr(), 1 if relu else 0, st), "bn_apply")
+        ctx.save_for_backward(x, y if relu else None, coef)
+        ctx.cfg = (training, relu, residual is not None, count, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, coef = ctx.saved_tensors
+        training, relu, has_res, count, sync = ctx.cfg
+        N, C, H, W = x.shape
+        rows = N * H * W
+        dev, st = x.device, _stream()
+        dy = to_nhwc(dy, "batch_norm.backward")
+        mean, invstd, scale = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C]
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        nws = lib.segmi_bn_bwd_reduce_workspace(rows, C)
+        ws = workspace(nws, dev)
+        yp, ldy = (y.data_ptr(), ld_of(y)) if relu else (None, 0)
+        check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
+                                      mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(),
+                                      ws.data_ptr(), nws, st), "bn_bwd_reduce")
+        dgamma = sums[C:2 * C] if ctx.needs_input_grad[1] else None
+        dbeta = sums[0:C] if ctx.needs_input_grad[2] else None
+        gsums = sums
+        if training and sync is not None:
+            gsums = sync.reduce_sums(sums)  # global sums for dx; local ones stay the parameter grads
+        dx = dres = None
+        want_dx = ctx.needs_input_grad[0]
+        want_res = has_res and ctx.needs_input_grad[3]
+        if want_dx or (want_res and relu):
+            dx = empty_nhwc(N, C, H, W, dev)
+            if want_res and relu:
+                dres = empty_nhwc(N, C, H, W, dev)
+            check(lib.segmi_bn_bwd_apply(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
+                                         mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), gsums.data_ptr(),
+                                         count, 1 if relu else 0, 1 if training else 0, dx.data_ptr(), ld_of(dx),
+                                         dres.data_ptr() if dres is not None else None,
+                                         ld_of(dres) if dres is not None else 0, st), "bn_bwd_apply")
+        if want_res and not relu:
+            dres = dy
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, residual=None, training=True,
+                   momentum=0.1, eps=1e-5, relu=False, sync=None):
+    """BN (batch or running statistics) -> (+ residual) -> (ReLU), one fused apply pass."""
+    return _BatchNormActFn.apply(x, gamma, beta, residual, running_mean, running_var, num_batches_tracked,
+                                 bool(training), float(momentum), float(eps), bool(relu), sync)
+
+
+# --------------------------------------------------------------------------- relu / add
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x, "relu")
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, H, W, x.device)
+        check(lib.segmi_relu_fwd(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), N * H * W, C, _stream()), "relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = to_nhwc(dy, "relu.backward")
+        N, C, H, W = y.shape
+        dx = empty_nhwc(N, C, H, W, y.device)
+        check(lib.segmi_relu_bwd(dy.data_ptr(), ld_of(dy), y.data_ptr(), ld_of(y), dx.data_ptr(), ld_of(dx), N * H * W, C,
+                                 _stream()), "relu_bwd")
+        return dx
+
+
+def relu(x):
+    return _ReluFn.apply(x)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a, "add"), to_nhwc(b, "add")
+        if a.shape != b.shape:
+            raise SegmiError("add: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        N, C, H, W = a.shape
+        o = empty_nhwc(N, C, H, W, a.device)
+        check(lib.segmi_add(a.data_ptr(), ld_of(a), b.data_ptr(), ld_of(b), o.data_ptr(), ld_of(o), N * H * W, C, _stream()), "add")
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+# --------------------------------------------------------------------------- pooling
+def pool_out_size(H, k, stride, pad, ceil_mode):
+    if ceil_mode:
+        o = -((H + 2 * pad - k) // -stride) + 1
+        if (o - 1) * stride >= H + pad:  # last window must start inside the input (or left padding)
+            o -= 1
+        return o
+    return (H + 2 * pad - k) // stride + 1
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, ceil_mode):
+        x = to_nhwc(x, "max_pool2d")
+        N, C, H, W = x.shape
+        P, Q = pool_out_size(H, k, stride, pad, ceil_mode), pool_out_size(W, k, stride, pad, ceil_mode)
+        y = empty_nhwc(N, C, P, Q, x.device)
+        idx = torch.empty((N * P * Q, pad4(C)), device=x.device, dtype=torch.uint8)
+        check(lib.segmi_maxpool_fwd(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), idx.data_ptr(), N, H, W, C, P, Q, k,
+                                    stride, pad, _stream()), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, C, H, W, P, Q, k, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W, P, Q, k, stride, pad = ctx.geom
+        dy = to_nhwc(dy, "max_pool2d.backward")
+        dx = empty_nhwc(N, C, H, W, dy.device)
+        check(lib.segmi_maxpool_bwd(dy.data_ptr(), ld_of(dy), idx.data_ptr(), dx.data_ptr(), ld_of(dx), N, H, W, C, P, Q, k,
+                                    stride, pad, _stream()), "maxpool_bwd")
+        return dx, None, None, None, None
+
+
+def max_pool2d(x, kernel_size, stride=None, padding=0, ceil_mode=False):
+    return _MaxPoolFn.apply(x, int(kernel_size), int(stride or kernel_size), int(padding), bool(ceil_mode))
+
+
+class _AdaptiveAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        x = to_nhwc(x, "adaptive_avg_pool2d")
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, OH, OW, x.device)
+        check(lib.segmi_adaptive_avgpool_fwd(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), N, H, W, C, OH, OW, _stream()),
+              "adaptive_avgpool_fwd")
+        ctx.geom = (N, C, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW = ctx.geom
+        dy = to_nhwc(dy, "adaptive_avg_pool2d.backward")
+        dx = empty_nhwc(N, C, H, W, dy.device)
+        check(lib.segmi_adaptive_avgpool_bwd(dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx), N, H, W, C, OH, OW, 0,
+                                             _stream()), "adaptive_avgpool_bwd")
+        return dx, None, None
+
+
+def adaptive_avg_pool2d(x, output_size):
+    if isinstance(output_size, int):
+        output_size = (output_size, output_size)
+    return _AdaptiveAvgPoolFn.apply(x, int(output_size[0]), int(output_size[1]))
+
+
+# --------------------------------------------------------------------------- bilinear resize
+class _BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW, align_corners):
+        x = to_nhwc(x, "interpolate")
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, OH, OW, x.device)
+        check(lib.segmi_bilinear_fwd(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), N, H, W, C, OH, OW,
+                                     1 if align_corners else 0, _stream()), "bilinear_fwd")
+        ctx.geom = (N, C, H, W, OH, OW, align_corners)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW, ac = ctx.geom
+        dy = to_nhwc(dy, "interpolate.backward")
+        dx = empty_nhwc(N, C, H, W, dy.device)
+        check(lib.segmi_bilinear_bwd(dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx), N, H, W, C, OH, OW,
+                                     1 if ac else 0, _stream()), "bilinear_bwd")
+        return dx, None, None, None
+
+
+def interpolate_bilinear(x, size, align_corners=False):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=align_corners)."""
+    return _BilinearFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+
+
+# --------------------------------------------------------------------------- concat / dropout
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [to_nhwc(x, "cat") for x in xs]
+        N, _, H, W = xs[0].shape
+        chans = [x.shape[1] for x in xs]
+        for x in xs:
+            if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
+                raise SegmiError("cat: spatial/batch mismatch")
+        Ct = sum(chans)
+        out = empty_nhwc(N, Ct, H, W, xs[0].device)
+        ldo, st, off = ld_of(out), _stream(), 0
+        for x, c in zip(xs, chans):
+            last = off + c == Ct
+            fill = (pad4(Ct) - off) if last else c   # zero the row padding after the last slice
+            check(lib.segmi_copy_rows(x.data_ptr(), ld_of(x), out.data_ptr() + 4 * off, ldo, N * H * W, c, fill, st), "cat")
+            off += c
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy, "cat.backward")
+        outs, off = [], 0
+        for c in ctx.chans:
+            outs.append(dy[:, off:off + c])   # zero-copy channel slices (ld = total)
+            off += c
+        return tuple(outs)
+
+
+def cat(tensors):
+    """torch.cat(tensors, dim=1)"""
+    return _CatFn.apply(*tensors)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, channelwise, seed):
+        x = to_nhwc(x, "dropout")
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, H, W, x.device)
+        check(lib.segmi_dropout(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), N, H * W, C, p, 1 if channelwise else 0, seed,
+                                _stream()), "dropout")
+        ctx.cfg = (p, channelwise, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, channelwise, seed = ctx.cfg
+        dy = to_nhwc(dy, "dropout.backward")
+        N, C, H, W = dy.shape
+        dx = empty_nhwc(N, C, H, W, dy.device)
+        check(lib.segmi_dropout(dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx), N, H * W, C, p, 1 if channelwise else 0,
+                                seed, _stream()), "dropout.backward")
+        return dx, None, None, None
+
+
+def dropout(x, p, training=True, channelwise=False):
+    """nn.Dropout (element mask) / nn.Dropout2d (per (n, c) mask).  The seed comes from torch's CPU
+    generator (reproducible under torch.manual_seed, no device sync); masks differ from aten's."""
+    if not training or p == 0.0:
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _DropoutFn.apply(x, float(p), bool(channelwise), seed)
+
+
+# --------------------------------------------------------------------------- cross entropy
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = to_nhwc(logits, "cross_entropy")
+        N, C, H, W = logits.shape
+        if target.dtype != torch.int64 or not target.is_cuda:
+            raise SegmiError("cross_entropy: target must be an int64 CUDA tensor")
+        if tuple(target.shape) != (N, H, W):
+            raise SegmiError("cross_entropy: target shape %s does not match logits %s" % (tuple(target.shape), tuple(logits.shape)))
+        target = target.contiguous()
+        rows, dev, st = N * H * W, logits.device, _stream()
+        lse = torch.empty(rows, device=dev, dtype=torch.float32)
+        out = torch.empty(2, device=dev, dtype=torch.float32)  # {loss, n_valid}
+        nws = lib.segmi_ce_workspace(rows)
+        ws = workspace(nws, dev)
+        check(lib.segmi_ce_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
+                               out.data_ptr(), ws.data_ptr(), nws, st), "ce_fwd")
+        ctx.save_for_backward(logits, target, lse, out)
+        ctx.ignore_index = ignore_index
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse, out = ctx.saved_tensors
+        N, C, H, W = logits.shape
+        g = g.contiguous().float()
+        dl = empty_nhwc(N, C, H, W, logits.device)
+        check(lib.segmi_ce_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C,
+                               ctx.ignore_index, out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "ce_bwd")
+        return dl, None, None
+
+
+def cross_entropy(logits, target, ignore_index=255):
+    """nn.CrossEntropyLoss(ignore_index=..., reduction='mean') on [N,C,H,W] logits / [N,H,W] int64 target."""
+    return _CrossEntropyFn.apply(logits, target, int(ignore_index))

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pytorch-segmentation_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libsegmi.so is built in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = os.path.join(PKG, "segmi", "libsegmi.so")
+    if not os.path.exists(lib):
+        sys.path.insert(0, PKG)
+        import build as segmi_build
+        segmi_build.build(verbose=False)
+    yield
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,266 @@
+"""Per-op parity of the HIP kernels (through the C ABI + autograd glue) against the plain PyTorch
+fp32 CPU operator the reference dispatches to.  Tolerances follow SURVEY.md §8(d):
+memory-bound ops rtol 1e-5 / atol 1e-6; conv |d| <= 1e-4 * max|ref|."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), "%s: max err %.3e (max ref %.3e)" % (what, err.max().item(), b.abs().max().item())
+
+
+def _close_rel_max(a, b, rel, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= rel * ref + 1e-30, "%s: max err %.3e vs %.3e * %.3e" % (what, err, rel, ref)
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad, dil, bias
+    (2, 64, 20, 24, 128, 3, 1, 1, 1, False),
+    (2, 32, 17, 19, 48, 3, 1, 2, 2, False),
+    (2, 128, 16, 16, 256, 1, 1, 0, 1, False),
+    (2, 64, 15, 15, 21, 1, 1, 0, 1, True),
+    (2, 3, 33, 33, 64, 3, 2, 1, 1, False),
+    (2, 64, 16, 16, 64, 3, 2, 1, 1, False),
+    (2, 36, 12, 12, 20, 3, 1, 4, 4, True),
+    (1, 256, 8, 8, 512, 3, 1, 1, 1, False),
+    (2, 3, 40, 40, 64, 7, 2, 3, 1, False),
+    (2, 64, 16, 16, 128, 1, 2, 0, 1, False),
+    (3, 512, 6, 6, 128, 3, 1, 6, 6, False),
+    (2, 304, 9, 9, 256, 3, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(cuda, case):
+    from segmi import ops
+    N, C, H, W, K, R, stride, pad, dil, bias = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    b = torch.randn(K, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    for wfmt in ("channels_last", "contiguous"):
+        xd = x.to(cuda).requires_grad_(True)
+        wd = w.to(cuda)
+        if wfmt == "channels_last":
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        wd.requires_grad_(True)
+        bd = b.to(cuda).requires_grad_(True) if bias else None
+        yd = ops.conv2d(xd, wd, bd, stride, pad, dil)
+        assert tuple(yd.shape) == tuple(yr.shape)
+        _close_rel_max(yd, yr, 1e-4, "conv fwd %s" % (case,))
+        yd.backward(gy.to(cuda))
+        _close_rel_max(xd.grad, xr.grad, 1e-4, "conv dgrad %s" % (case,))
+        _close_rel_max(wd.grad, wr.grad, 1e-4, "conv wgrad %s" % (case,))
+        assert wd.grad.stride() == wd.stride() or wd.grad.shape == wd.shape
+        if bias:
+            _close_rel_max(bd.grad, br.grad, 1e-4, "conv bias grad %s" % (case,))
+
+
+BN_CASES = [(2, 64, 9, 11), (4, 128, 7, 7), (8, 2048, 4, 4), (2, 16, 33, 35), (2, 728, 5, 5)]
+
+
+@pytest.mark.parametrize("shape", BN_CASES)
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_act(cuda, shape, relu, res, training):
+    from segmi import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    r = torch.randn(N, C, H, W, generator=g) if res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(N, C, H, W, generator=g)
+
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rm_r, rv_r, gr, br, training=training, momentum=0.1, eps=1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(gy)
+
+    xd, gd, bd = x.to(cuda).requires_grad_(True), gamma.to(cuda).requires_grad_(True), beta.to(cuda).requires_grad_(True)
+    rd = r.to(cuda).requires_grad_(True) if res else None
+    rm_d, rv_d = rm.to(cuda), rv.to(cuda)
+    nbt = torch.zeros((), dtype=torch.int64, device=cuda)
+    yd = ops.batch_norm_act(xd, gd, bd, rm_d, rv_d, nbt if training else None, residual=rd, training=training, relu=relu)
+    _close(yd, yr, 1e-5, 2e-6, "bn fwd")
+    yd.backward(gy.to(cuda))
+    _close(xd.grad, xr.grad, 1e-4, 2e-6, "bn dx")
+    _close(gd.grad, gr.grad, 1e-4, 1e-4, "bn dgamma")
+    _close(bd.grad, br.grad, 1e-4, 1e-4, "bn dbeta")
+    if res:
+        _close(rd.grad, rr.grad, 1e-6, 1e-7, "bn dres")
+    _close(rm_d, rm_r, 1e-5, 1e-6, "running_mean")
+    _close(rv_d, rv_r, 1e-5, 1e-6, "running_var")
+    if training:
+        assert int(nbt.item()) == 1
+
+
+def test_batch_norm_large_mean_is_stable(cuda):
+    """Welford/Chan statistics: a channel with |mean| >> std must not lose its variance."""
+    from segmi import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 8, 32, 32, generator=g) * 1e-2 + 100.0
+    yr = F.batch_norm(x, None, None, None, None, training=True)
+    yd = ops.batch_norm_act(x.to(cuda), None, None, None, None, training=True)
+    _close(yd, yr, 1e-3, 2e-3, "bn large mean")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 17, 19, 3, 2, 1, False), (2, 32, 16, 16, 2, 2, 0, True), (2, 16, 15, 17, 2, 2, 0, True),
+                                  (1, 128, 9, 9, 3, 2, 1, False)])
+def test_max_pool(cuda, case):
+    from segmi import ops
+    N, C, H, W, k, s, p, ceil = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p, ceil_mode=ceil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    yd = ops.max_pool2d(xd, k, s, p, ceil)
+    assert torch.equal(yd.cpu(), yr.detach())
+    yd.backward(gy.to(cuda))
+    _close(xd.grad, xr.grad, 1e-6, 1e-7, "maxpool bwd")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 1), (2, 64, 16, 16, 2), (2, 32, 16, 16, 3), (2, 32, 16, 16, 6), (2, 16, 13, 17, 6),
+                                  (1, 2048, 8, 8, 1), (2, 8, 5, 5, 6)])
+def test_adaptive_avg_pool(cuda, case):
+    from segmi import ops
+    N, C, H, W, o = case
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, o)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    yd = ops.adaptive_avg_pool2d(xd, o)
+    _close(yd, yr, 1e-5, 1e-6, "aap fwd")
+    yd.backward(gy.to(cuda))
+    _close(xd.grad, xr.grad, 1e-5, 1e-6, "aap bwd")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 1, 1, 16, 16, True), (2, 16, 2, 2, 16, 16, True), (2, 16, 3, 3, 16, 16, True),
+                                  (2, 16, 6, 6, 16, 16, True), (2, 21, 8, 8, 64, 64, False), (2, 19, 13, 13, 97, 97, False),
+                                  (2, 8, 9, 9, 33, 33, True), (1, 12, 33, 33, 129, 129, True), (2, 4, 10, 12, 7, 5, False),
+                                  (2, 4, 10, 12, 7, 5, True)])
+def test_bilinear(cuda, case):
+    from segmi import ops
+    N, C, H, W, OH, OW, ac = case
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=ac)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    yd = ops.interpolate_bilinear(xd, (OH, OW), ac)
+    _close(yd, yr, 1e-5, 2e-6, "bilinear fwd")
+    yd.backward(gy.to(cuda))
+    _close(xd.grad, xr.grad, 1e-4, 1e-5, "bilinear bwd")
+
+
+def test_cat_and_slices(cuda):
+    from segmi import ops
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, c, 5, 7, generator=g) for c in (8, 4, 12)]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    yr = torch.cat(xr, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = [x.to(cuda).requires_grad_(True) for x in xs]
+    yd = ops.cat(xd)
+    assert torch.equal(yd.cpu(), yr.detach())
+    yd.backward(gy.to(cuda))
+    for a, b in zip(xd, xr):
+        assert torch.equal(a.grad.cpu(), b.grad)
+    # ragged channel counts fall back to the scalar copy path
+    xs = [torch.randn(2, c, 3, 3, generator=g) for c in (5, 3)]
+    yd = ops.cat([x.to(cuda) for x in xs])
+    assert torch.equal(yd.cpu(), torch.cat(xs, 1))
+
+
+def test_relu_add(cuda):
+    from segmi import ops
+    g = torch.Generator().manual_seed(10)
+    a, b = torch.randn(2, 12, 5, 5, generator=g), torch.randn(2, 12, 5, 5, generator=g)
+    ad, bd = a.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    y = ops.relu(ops.add(ad, bd))
+    assert torch.equal(y.cpu(), F.relu(a + b))
+    gy = torch.randn(2, 12, 5, 5, generator=g)
+    y.backward(gy.to(cuda))
+    ref = gy * ((a + b) > 0)
+    assert torch.equal(ad.grad.cpu(), ref) and torch.equal(bd.grad.cpu(), ref)
+
+
+@pytest.mark.parametrize("channelwise", [True, False])
+def test_dropout_statistics_and_backward(cuda, channelwise):
+    from segmi import ops
+    torch.manual_seed(0)
+    x = torch.ones(8, 64, 16, 16, device=cuda, requires_grad=True)
+    p = 0.25
+    y = ops.dropout(x, p, True, channelwise)
+    yc = y.detach().cpu()
+    vals = torch.unique(yc)
+    assert set(vals.tolist()) <= {0.0, torch.tensor(1.0 / (1 - p), dtype=torch.float32).item()}
+    keep = (yc != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < (0.08 if channelwise else 0.01)
+    if channelwise:
+        per = yc.flatten(2)
+        assert bool((per.max(dim=2).values == per.min(dim=2).values).all())
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad.cpu(), yc)          # same mask and scale in backward
+    assert torch.equal(ops.dropout(x, p, False, channelwise), x)
+
+
+@pytest.mark.parametrize("case", [(2, 21, 16, 16), (1, 3, 2, 4), (2, 150, 9, 9), (3, 19, 7, 5), (2, 2, 8, 8)])
+def test_cross_entropy(cuda, case):
+    from segmi import ops
+    N, C, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g) * 3
+    t = torch.randint(0, C, (N, H, W), generator=g)
+    t[:, : max(1, H // 4), :] = 255
+    xr = x.clone().requires_grad_(True)
+    lr = F.cross_entropy(xr, t, ignore_index=255)
+    (lr * 0.4).backward()
+    xd = x.to(cuda).requires_grad_(True)
+    ld = ops.cross_entropy(xd, t.to(cuda), 255)
+    _close(ld, lr, 1e-5, 1e-6, "ce loss")
+    (ld * 0.4).backward()
+    _close(xd.grad, xr.grad, 1e-5, 1e-8, "ce grad")
+    assert float(xd.grad.cpu()[:, :, 0, :].abs().max()) == 0.0
+
+
+def test_layout_roundtrip_and_cpu_refusal(cuda):
+    from segmi import ops, SegmiError
+    x = torch.randn(2, 5, 7, 9)
+    xd = ops.to_nhwc(x.to(cuda))
+    assert ops.is_nhwc(xd) and xd.stride(3) == 8
+    assert torch.equal(xd.cpu(), x)
+    assert torch.equal(ops.to_nchw_contiguous(xd).cpu(), x)
+    with pytest.raises(SegmiError):
+        ops.conv2d(x, torch.randn(4, 5, 3, 3))
