@@ -1,0 +1,142 @@
+"""Generate tests/golden/*.pt by running the REAL reference (/root/reference) on torch CPU.
+
+    python oracle/gen_golden.py            (build container only; takes ~1 min)
+
+The fixtures pin the oracle restatements (tests/test_oracle_golden.py) and, through them, the HIP
+path.  Weights are not stored: they are re-created from the stored manifest by
+oracle.weights.synth_state_dict (same seed), inputs by oracle.weights.synth_batch.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import reference_harness  # noqa: E402
+from oracle.weights import manifest_of, synth_batch, synth_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _grad_digest(named_params):
+    out = {}
+    for k, p in named_params:
+        if p.grad is None:
+            continue
+        g = p.grad.detach().reshape(-1)
+        step = max(1, g.numel() // 64)
+        out[k] = {"norm": g.norm().item(), "absmax": g.abs().max().item(), "head": g[:8].clone(), "sample": g[::step][:64].clone()}
+    return out
+
+
+def gen_losses(losses):
+    cases = []
+    # known-answer example of SURVEY.md App. C
+    logits = (2 * torch.sin(0.37 * torch.arange(24.0))).reshape(1, 3, 2, 4)
+    target = torch.tensor([[[0, 1, 2, 255], [2, 2, 0, 1]]])
+    cases.append(("appendix_c", logits, target, 255))
+    g = torch.Generator().manual_seed(99)
+    for name, (N, C, H, W), ign in [("c21", (2, 21, 12, 10), 255), ("c5_absent", (2, 5, 6, 7), 255), ("c150", (1, 150, 8, 8), 255),
+                                    ("c2", (2, 2, 9, 9), 255), ("noignore", (2, 7, 5, 5), 255)]:
+        lg = torch.randn(N, C, H, W, generator=g) * 2
+        tg = torch.randint(0, C if name != "c5_absent" else C - 1, (N, H, W), generator=g)
+        if name != "noignore":
+            tg[:, 0, :] = ign
+        cases.append((name, lg, tg, ign))
+    out = {}
+    for name, lg, tg, ign in cases:
+        rec = {"logits": lg, "target": tg, "ignore_index": ign}
+        for lname in ("CrossEntropyLoss2d", "DiceLoss", "FocalLoss", "LovaszSoftmax"):
+            x = lg.clone().requires_grad_(True)
+            crit = getattr(losses, lname)(ignore_index=ign)
+            val = crit(x, tg.clone())
+            val.backward()
+            rec[lname] = {"loss": val.detach().clone(), "grad": x.grad.clone()}
+        out[name] = rec
+    torch.save(out, os.path.join(GOLD, "losses.pt"))
+    print("losses.pt:", list(out))
+
+
+def gen_pspnet(models, losses):
+    """Two regimes: (train) BN batch statistics as in BASELINE cfg2 — forward/loss/running stats are
+    well conditioned, parameter gradients are NOT (the reference's own fp32 vs fp64 runs differ by
+    percents at this size), so only digests are kept for a coarse check;
+    (frozen) the reference's freeze_bn=True configuration — gradients are well conditioned and pinned tightly."""
+    torch.manual_seed(0)
+    C, N, H, W = 5, 4, 104, 104
+    crit = losses.CrossEntropyLoss2d(ignore_index=255)
+    x, t = synth_batch(N, 3, H, W, C)
+    rec = {"num_classes": C, "input_shape": (N, 3, H, W)}
+    for regime in ("train", "frozen"):
+        model = models.PSPNet(C, backbone="resnet50", pretrained=False)
+        man = manifest_of(model.state_dict())
+        model.load_state_dict(synth_state_dict(man, seed=0))
+        model.train()
+        if regime == "frozen":
+            model.freeze_bn()
+        for m in model.modules():  # parity runs neutralise dropout
+            if isinstance(m, torch.nn.Dropout2d):
+                m.eval()
+        out, aux = model(x)
+        loss = crit(out, t) + 0.4 * crit(aux, t)
+        loss.backward()
+        sd_after = model.state_dict()
+        rec["manifest"] = man
+        rec[regime] = {
+            # full-resolution main head only for the train regime (argmax audit); the rest at pixel stride 2
+            "out": out.detach().clone() if regime == "train" else out.detach()[:, :, ::2, ::2].clone(),
+            "aux": aux.detach()[:, :, ::2, ::2].clone(), "loss": loss.detach().clone(),
+            "grads": _grad_digest(model.named_parameters()),
+            "running": {k: sd_after[k].clone() for k in ("initial.0.1.running_mean", "initial.0.1.running_var",
+                                                         "layer4.2.bn3.running_mean", "layer4.2.bn3.running_var",
+                                                         "master_branch.0.stages.0.2.running_var",
+                                                         "master_branch.0.bottleneck.1.running_mean",
+                                                         "initial.1.num_batches_tracked")},
+        }
+        print("pspnet_r50.pt[%s]: loss %.6f, logit max %.3f" % (regime, loss.item(), out.abs().max().item()))
+    model.eval()
+    with torch.no_grad():
+        rec["eval_out"] = model(x)[:, :, ::2, ::2].clone()
+    torch.save(rec, os.path.join(GOLD, "pspnet_r50.pt"))
+
+
+def gen_misc():
+    sys.path.insert(0, reference_harness.REFERENCE)
+    from utils.metrics import eval_metrics
+    from utils.sync_batchnorm import SynchronizedBatchNorm2d
+    logits = (2 * torch.sin(0.37 * torch.arange(24.0))).reshape(1, 3, 2, 4)
+    target = torch.tensor([[[0, 1, 2, 255], [2, 2, 0, 1]]])
+    correct, labeled, inter, union = eval_metrics(logits, target, 3)
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(2, 6, 9, 9, generator=g)
+    tg = torch.randint(0, 6, (2, 9, 9), generator=g)
+    tg[:, 0] = 255
+    m2 = eval_metrics(lg, tg, 6)
+    bn = SynchronizedBatchNorm2d(2)
+    mean, inv_std = bn._compute_mean_std(torch.tensor([10.0, -4.0]), torch.tensor([30.0, 4.000001]), 8)
+    rec = {
+        "metrics_appendix_c": {"logits": logits, "target": target, "correct": float(correct), "labeled": float(labeled),
+                               "inter": torch.as_tensor(inter), "union": torch.as_tensor(union)},
+        "metrics_rand": {"logits": lg, "target": tg, "correct": float(m2[0]), "labeled": float(m2[1]),
+                         "inter": torch.as_tensor(m2[2]), "union": torch.as_tensor(m2[3])},
+        "syncbn_mean_std": {"sum": torch.tensor([10.0, -4.0]), "ssum": torch.tensor([30.0, 4.000001]), "n": 8,
+                            "mean": mean.clone(), "inv_std": inv_std.clone(),
+                            "running_mean": bn.running_mean.clone(), "running_var": bn.running_var.clone()},
+    }
+    torch.save(rec, os.path.join(GOLD, "misc.pt"))
+    print("misc.pt ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    models, losses = reference_harness.load()
+    which = sys.argv[1:] or ["losses", "pspnet", "misc"]
+    if "losses" in which:
+        gen_losses(losses)
+    if "pspnet" in which:
+        gen_pspnet(models, losses)
+    if "misc" in which:
+        gen_misc()

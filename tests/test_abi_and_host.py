@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports exactly what include/segmi.h
+declares; host-side planning/query functions behave; the drop-in modules keep the reference's
+plugin surface (class names, constructor kwargs, state_dict keys) and refuse to run on CPU."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "segmi.h")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(segmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from segmi import LIB_PATH
+    from segmi._lib import SIGNATURES
+    names = _header_functions()
+    assert len(names) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (segmi_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(SIGNATURES), (sorted(set(names) ^ set(SIGNATURES)))
+
+
+def test_library_is_gfx950_only_and_has_no_rocm_runpath():
+    from segmi import LIB_PATH
+    dyn = subprocess.run(["readelf", "-d", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "libamdhip64.so.7" in dyn
+    assert "RUNPATH" not in dyn and "RPATH" not in dyn   # must bind to the runtime torch already loaded
+    blob = open(LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_80"):
+        assert other not in blob
+
+
+def test_status_strings_and_queries():
+    from segmi import lib
+    from segmi._lib import ConvDesc
+    assert lib.segmi_abi_version() == 1
+    assert lib.segmi_strerror(0) == b"ok"
+    assert b"workspace" in lib.segmi_strerror(-3)
+    # bad descriptor -> argument error before any launch (no GPU needed)
+    d = ConvDesc(1, 8, 8, 4, 8, 3, 3, 7, 8, 1, 1, 1, 4, 8)  # P inconsistent with H/pad/dil
+    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None) == -1
+    d = ConvDesc(1, 8, 8, 6, 8, 3, 3, 8, 8, 1, 1, 1, 6, 8)  # C % 4 != 0
+    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None) == -2
+    # split-K planning: a 64->64 3x3 on a 256x256 map at batch 8 must split its 524288-pixel reduction
+    d = ConvDesc(8, 256, 256, 64, 64, 3, 3, 256, 256, 1, 1, 1, 64, 64)
+    ws = lib.segmi_conv2d_wgrad_workspace(d)
+    assert ws % (64 * 9 * 64 * 4) == 0 and ws // (64 * 9 * 64 * 4) >= 32
+    # the 4096->512 3x3 PSP bottleneck already has >1000 tiles: no split, no workspace
+    d = ConvDesc(8, 64, 64, 4096, 512, 3, 3, 64, 64, 1, 1, 1, 4096, 512)
+    assert lib.segmi_conv2d_wgrad_workspace(d) == 0
+    assert lib.segmi_bn_stats_workspace(8 * 64 * 64, 2048) >= 3 * 2048 * 4
+    assert lib.segmi_ce_workspace(1 << 21) > 0
+
+
+def test_pool_output_sizes_match_torch():
+    from segmi.ops import conv_out_size, pool_out_size
+    import torch.nn.functional as F
+    for H in (15, 16, 17, 33, 256):
+        for k, s, p, ceil in ((3, 2, 1, False), (2, 2, 0, True), (2, 2, 0, False), (3, 2, 0, True)):
+            ref = F.max_pool2d(torch.zeros(1, 1, H, H), k, s, p, ceil_mode=ceil).shape[-1]
+            assert pool_out_size(H, k, s, p, ceil) == ref, (H, k, s, p, ceil)
+    assert conv_out_size(512, 3, 2, 1, 1) == 256 and conv_out_size(64, 3, 1, 4, 4) == 64
+
+
+def test_pspnet_plugin_surface_matches_reference_manifest():
+    import models
+    gold = torch.load(os.path.join(GOLD, "pspnet_r50.pt"), weights_only=False)
+    m = models.PSPNet(gold["num_classes"], backbone="resnet50", pretrained=False)
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == [(k, tuple(s)) for k, s in gold["manifest"]]
+    assert sum(p.numel() for p in m.get_backbone_params()) + sum(p.numel() for p in m.get_decoder_params()) == \
+        sum(p.numel() for p in m.parameters())
+    m.freeze_bn()
+    assert all(not b.training for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    assert "Nbr of trainable parameters" in str(m)
+    m2 = models.PSPNet(3, backbone="resnet50", pretrained=False, freeze_backbone=True, use_aux=False)
+    assert all(not p.requires_grad for p in m2.layer1.parameters()) and all(p.requires_grad for p in m2.master_branch.parameters())
+    with pytest.raises(FileNotFoundError):
+        models.PSPNet(3, backbone="resnet50", pretrained=True)
+
+
+def test_product_path_refuses_cpu_tensors():
+    import models
+    from segmi import SegmiError
+    from utils.losses import CrossEntropyLoss2d
+    m = models.PSPNet(3, backbone="resnet50", pretrained=False)
+    with pytest.raises(SegmiError):
+        m(torch.randn(2, 3, 64, 64))
+    with pytest.raises(SegmiError):
+        CrossEntropyLoss2d()(torch.randn(1, 3, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int64))
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pytorch-segmentation_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
