@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py — training images/sec of the MI355X-native segmentation hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch resident in HBM: zero_grad -> PSPNet-R50
+forward (train mode: BN batch statistics, dropout active, aux head) -> CrossEntropy(main) + 0.4*CE(aux)
+-> backward -> gradient all-reduce (N>1, RCCL, overlapped with backward) -> SGD(momentum, weight decay)
+step — the reference's inner loop trainer.py:55-71.  Workload at every N: BASELINE.json configs[1]
+(PSPNet-ResNet50, 8 x 3x512x512, 21 classes) PER GPU, i.e. weak scaling; fp32 end to end (the
+reference's dtype; convolutions on v_mfma_f32_32x32x2_f32).
+
+Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
+  roofline     : the conv implicit-GEMM kernel family (MFMA-bound) measured with HIP events per launch
+                 in an extra instrumented step; `kernel` is the variant with the largest total time,
+                 `avg_us` its mean launch duration (compare with profiles/*kernel_stats*), `achieved`
+                 = algorithmic FLOPs / measured time over ALL conv launches of the step.
+  cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on
+                 this host's cores on a bounded sample (batch 2 of the same 512x512 workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-segmentation_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+
+# name -> (arch, kwargs, num_classes, per-GPU batch, H, W, train FLOPs/image (conv only))
+CONFIGS = {
+    "cfg2": ("PSPNet", dict(backbone="resnet50", pretrained=False), 21, 8, 512, 512, 1_221_159_026_688),
+    "cfg4": ("PSPNet", dict(backbone="resnet50", pretrained=False), 19, 4, 769, 769, 2_802_443_088_000),
+}
+
+
+def build_model(name, device):
+    import models
+    arch, kw, classes, *_ = CONFIGS[name]
+    torch.manual_seed(0)
+    return getattr(models, arch)(classes, **kw).to(device).train()
+
+
+def synth_batch(name, device, rank):
+    _, _, classes, n, h, w, _ = CONFIGS[name]
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(n, 3, h, w, generator=g)
+    t = torch.randint(0, classes, (n, h, w), generator=g)
+    t[:, : h // 20, :] = 255
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(name, seconds_cap=40.0):
+    """Oracle leg: same model family / loss / optimizer on torch-CPU, bounded sample."""
+    from oracle import losses_ref, pspnet_ref
+    import models
+    arch, kw, classes, n, h, w, _ = CONFIGS[name]
+    nb = 2
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone().contiguous() for k, v in getattr(models, arch)(classes, **kw).state_dict().items()}
+    ref = pspnet_ref.clone_state(sd)
+    params = [v for v in ref.values() if v.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(nb, 3, h, w, generator=g)
+    t = torch.randint(0, classes, (nb, h, w), generator=g)
+    t[:, : h // 20, :] = 255
+    cores = torch.get_num_threads()
+    times = []
+    t_begin = time.perf_counter()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out, aux = pspnet_ref.pspnet_forward(ref, x, training=True, backbone=kw["backbone"])
+        loss = losses_ref.cross_entropy(out, t) + 0.4 * losses_ref.cross_entropy(aux, t)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > seconds_cap:
+            break
+    best = min(times)
+    return {"value": round(nb / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d train step(s) of batch %d x 3x%dx%d (same model/loss/SGD as the GPU leg), best step %.2f s"
+                      % (len(times), nb, h, w, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
+    ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from segmi.distributed import DistributedModel
+    from segmi.profile import KernelTimer
+    from utils.losses import CrossEntropyLoss2d
+
+    arch, kw, classes, nb, h, w, flops_img = CONFIGS[args.config]
+    model = build_model(args.config, device)
+    if args.sync_bn and world > 1:
+        from utils.sync_batchnorm import convert_model
+        model = convert_model(model)
+    dm = DistributedModel(model) if world > 1 else None
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    crit = CrossEntropyLoss2d(ignore_index=255)
+    x, t = synth_batch(args.config, device, rank)
+
+    def step():
+        if dm is not None:
+            dm.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out, aux = model(x)
+        loss = crit(out, t) + 0.4 * crit(aux, t)
+        loss.backward()
+        if dm is not None:
+            dm.finish_gradients()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+    ms = 1e3 * dt / args.steps
+    value = world * nb * args.steps / dt
+
+    roof = None
+    if not args.no_roofline:       # every rank runs the instrumented step (it contains collectives)
+        with KernelTimer() as kt:
+            step()
+        summ = kt.summary()
+        tot_ms = sum(r["total_ms"] for r in summ.values())
+        tot_fl = sum(r["flops"] for r in summ.values())
+        top_name, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "scope": "all conv implicit-GEMM launches of one step (fwd+dgrad+wgrad), HIP events per launch",
+                "conv_launches": sum(r["launches"] for r in summ.values()), "conv_ms_per_step": round(tot_ms, 2),
+                "conv_flops_per_step": tot_fl,
+                "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
+                "kernel_achieved": round(top["flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
+                "step_frac": round(value / world * flops_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
+                                 "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(args.config)
+
+    if rank == 0:
+        line = {
+            "metric": "training images/sec @512x512 (PSPNet-R50)" if args.config == "cfg2" else "training images/sec (%s)" % args.config,
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s-%s %dx3x%dx%d per GPU, %d classes, CE + 0.4*aux CE, SGD(momentum 0.9, wd 1e-4), "
+                                   "BN batch stats%s, dropout on" % (args.config, arch, kw["backbone"], nb, h, w, classes,
+                                                                      " (SyncBN)" if args.sync_bn and world > 1 else ""),
+                       "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

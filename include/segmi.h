@@ -71,6 +71,9 @@ int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w
 size_t segmi_conv2d_wgrad_workspace(const segmi_conv_desc* d);
 int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
                        size_t workspace_bytes, segmi_stream_t stream);
+/* Name of the kernel variant the dispatcher picks for this problem (op: 0 fwd, 1 dgrad, 2 wgrad),
+ * as it appears in a rocprofv3 kernel trace; used by bench.py to attribute measured time. */
+int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
 int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, int S, int C, int Kpad,
                               segmi_stream_t stream);
 /* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */

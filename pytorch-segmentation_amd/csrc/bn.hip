@@ -81,21 +81,44 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// merge nparts packed partials (stride 3*Cp each) into out[3*Cp]; one thread per channel
-__global__ void bn_stats_merge_kernel(const float* __restrict__ part, int nparts, int Cp, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cp) return;
+// merge nparts packed partials (stride 3*Cp each) into out[3*Cp].  Block = (16 channels, 16 part lanes):
+// each lane folds parts y, y+16, ... serially (<= 32 steps at the 512-part cap), then a Chan tree over
+// the 16 lanes in LDS — the serial one-thread-per-channel form cost 160 us per BN layer.
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int nparts, int Cp,
+                                                             float* __restrict__ out) {
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    const bool cok = c < Cp;
     float n = 0.f, m = 0.f, q = 0.f;
-    for (int i = 0; i < nparts; ++i) {
-        const float* p = part + (long)i * 3 * Cp;
-        const float nb = p[c];
-        if (nb > 0.f) {
-            const float nn = n + nb;
-            chan1(n, m, q, nb, p[Cp + c], p[2 * Cp + c], nn);
-            n = nn;
+    if (cok) {
+#pragma unroll 4
+        for (int i = threadIdx.y; i < nparts; i += 16) {
+            const float* p = part + (long)i * 3 * Cp;
+            const float nb = p[c];
+            if (nb > 0.f) {
+                const float nn = n + nb;
+                chan1(n, m, q, nb, p[Cp + c], p[2 * Cp + c], nn);
+                n = nn;
+            }
         }
     }
-    out[c] = n; out[Cp + c] = m; out[2 * Cp + c] = q;
+    __shared__ float sn[16][17], sm[16][17], sq[16][17];
+    sn[threadIdx.y][threadIdx.x] = n; sm[threadIdx.y][threadIdx.x] = m; sq[threadIdx.y][threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 8; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            float na = sn[threadIdx.y][threadIdx.x], ma = sm[threadIdx.y][threadIdx.x], qa = sq[threadIdx.y][threadIdx.x];
+            const float nb = sn[threadIdx.y + s][threadIdx.x];
+            if (nb > 0.f) {
+                const float nn = na + nb;
+                chan1(na, ma, qa, nb, sm[threadIdx.y + s][threadIdx.x], sq[threadIdx.y + s][threadIdx.x], nn);
+                sn[threadIdx.y][threadIdx.x] = nn; sm[threadIdx.y][threadIdx.x] = ma; sq[threadIdx.y][threadIdx.x] = qa;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        out[c] = sn[0][threadIdx.x]; out[Cp + c] = sm[0][threadIdx.x]; out[2 * Cp + c] = sq[0][threadIdx.x];
+    }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int Cp, const float* gamma,
@@ -205,12 +228,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_p part[p][i]; block = (32 elements, 8 part lanes), LDS tree over the lanes
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 32 + threadIdx.x;
     float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += part[(long)p * n + i];
-    out[i] = a;
+    if (i < n)
+#pragma unroll 4
+        for (int p = threadIdx.y; p < nparts; p += 8) a += part[(long)p * n + i];
+    __shared__ float sm[8][33];
+    sm[threadIdx.y][threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+        out[i] = t;
+    }
 }
 
 template <bool RELU, bool TRAIN, bool DRES>
@@ -313,7 +346,7 @@ int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, voi
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
-    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, parts, C, partial);
+    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial);
     return segmi_launch_status();
 }
 
@@ -373,7 +406,7 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     g.grid.y = parts;
     if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
     else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)workspace, parts, 2 * C, sums);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
 

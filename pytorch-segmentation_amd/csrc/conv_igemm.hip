@@ -18,6 +18,7 @@
 // zero-filled), double-buffered, one barrier per K-chunk.  LDS rows are padded by 4 floats so the
 // ds_read_b128 fragment reads are bank-conflict free (MI355X_MICROARCH.md, LDS table).
 #include "segmi_common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -530,6 +531,20 @@ int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy
         rc = segmi_launch_status();
     }
     return rc;
+}
+
+int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len) {
+    if (!desc_ok(d) || !buf || len == 0 || op < 0 || op > 2) return SEGMI_ERR_BADARG;
+    if (op == 2) {
+        WgradPlan pl = plan_wgrad(d);
+        snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
+        return SEGMI_OK;
+    }
+    const int Cs = op == 0 ? d->C : ((d->K + 3) & ~3), Cd = op == 0 ? d->K : d->C;
+    const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
+    const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    snprintf(buf, len, "conv_gather_kernel<128, %d, %d, %s, %d>", bn, bk, bn == 32 ? "4, 1" : "2, 2", op);
+    return SEGMI_OK;
 }
 
 int segmi_filter_krsc_to_crsk(const float* w, float* wt, int K, int R, int S, int C, int Kpad, segmi_stream_t stream) {

@@ -9,9 +9,12 @@ transpose kernel.  Channels C..round_up(C,4)-1 of a buffer are always zero.
 PyTorch is used here for device memory (caching allocator), streams and autograd bookkeeping only:
 every arithmetic op below is a libsegmi kernel, and there is no CPU path — CPU tensors raise.
 """
+import ctypes
+
 import torch
 
 from ._lib import ConvDesc, SegmiError, check, lib
+from .profile import span
 
 __all__ = [
     "conv2d", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
@@ -167,6 +170,22 @@ def conv_out_size(H, k, stride, pad, dil):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+def conv_variant(d, op):
+    """Kernel variant name for (desc, op in {0 fwd, 1 dgrad, 2 wgrad}) as a rocprofv3 trace shows it."""
+    buf = ctypes.create_string_buffer(128)
+    check(lib.segmi_conv2d_variant(d, op, buf, 128), "conv2d_variant")
+    return buf.value.decode()
+
+
+def _geom(d):
+    return "N%d %dx%d C%d K%d %dx%d s%d d%d" % (d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, d.dil)
+
+
+def _conv_flops(d, C):
+    """Algorithmic FLOPs of one conv pass (true channel count C, not the 4-padded d.C)."""
+    return 2 * d.N * d.P * d.Q * d.K * d.R * d.S * C
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -181,8 +200,9 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, K, P, Q, x.device)
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
-        check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                   y.data_ptr(), 0, _stream()), "conv2d_fwd")
+        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       y.data_ptr(), 0, _stream()), "conv2d_fwd")
         ctx.save_for_backward(x, weight)
         ctx.geom = (N, C, H, W, K, R, S, P, Q, stride, pad, dil)
         ctx.has_bias = bias is not None
@@ -203,14 +223,16 @@ class _Conv2dFn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
             dx = empty_nhwc(N, C, H, W, x.device)
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
-            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "conv2d_dgrad")
+            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, x.device) if nws else None
             dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
-            check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
-                                         ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
+                                             ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
             dw = _filter_grad_like(dwb, weight, Ce)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             rows = N * P * Q

@@ -1,0 +1,181 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange steps (segmi.distributed) are correct by
+construction — bucketed gradient averaging equals the gradient of the global-batch loss, and the
+SyncBN statistic exchange merges to the statistics of the concatenated batch (the reference's
+semantics: nn.DataParallel computes the loss on the gathered global batch, base/base_trainer.py:33-38;
+utils/sync_batchnorm/batchnorm.py:105-145)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "pytorch-segmentation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.a.weight.data = self.a.weight.data.contiguous(memory_format=torch.channels_last)  # permuted-dense param
+        self.b = torch.nn.Linear(8, 5)
+        self.unused = torch.nn.Linear(4, 4)      # never produces a gradient: finish() must still reduce its bucket
+        self.s = torch.nn.Parameter(torch.ones(()))
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)).mean((2, 3))) * self.s
+
+
+def _grad_worker(rank, world):
+    from segmi.distributed import DistributedModel
+    torch.manual_seed(100 + rank)          # different init per rank: the wrapper must broadcast rank 0's
+    net = _Net()
+    dm = DistributedModel(net, bucket_bytes=600)   # tiny buckets -> several collectives
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(4 * world, 3, 6, 6, generator=g)
+    Y = torch.randn(4 * world, 5, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    out = {}
+    for it, zero in enumerate(("reducer", "set_to_none")):
+        if zero == "reducer":
+            dm.zero_grad()
+        else:
+            torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)
+            dm.reducer.zero_grad()
+            for p in net.parameters():
+                p.grad = None               # the hook must re-attach bucket views
+        loss = ((dm(xs) - ys) ** 2).mean()
+        loss.backward()
+        dm.finish_gradients()
+        out[zero] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        assert all(p.grad.data_ptr() == dm.reducer._where[id(p)][1].data_ptr() for p in dm.reducer.params)
+    # reference: one process, global batch
+    torch.manual_seed(100)
+    ref = _Net()
+    ((ref(X) - Y) ** 2).mean().backward()
+    refg = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    sd_equal = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    return {"nb": len(dm.reducer.buckets), "sd_equal": sd_equal,
+            "err": {z: max((out[z][k] - refg[k]).abs().max().item() for k in refg) for z in out},
+            "unused_zero": all(float(out[z]["unused.weight"].abs().max()) == 0.0 for z in out)}
+
+
+def test_bucketed_gradient_allreduce_equals_global_batch_gradient():
+    res = _spawn(_grad_worker)
+    for r in res:
+        assert r["nb"] >= 3
+        assert r["sd_equal"]
+        assert r["unused_zero"]
+        for z, e in r["err"].items():
+            assert e < 1e-6, (z, e)
+
+
+def _welford_partial(x):
+    """[3*C] packed partial exactly as segmi_bn_stats emits it: count (replicated), mean, M2 per channel."""
+    C = x.shape[1]
+    flat = x.permute(1, 0, 2, 3).reshape(C, -1).double()
+    n = flat.shape[1]
+    mean = flat.mean(1)
+    m2 = ((flat - mean[:, None]) ** 2).sum(1)
+    return torch.cat([torch.full((C,), float(n), dtype=torch.float64), mean, m2]).float()
+
+
+def _chan_merge(parts, nparts, C):
+    """Host restatement of segmi_bn_finalize's merge (Chan et al.)."""
+    p = parts.view(nparts, 3, C).double()
+    n, mean, m2 = p[0, 0].clone(), p[0, 1].clone(), p[0, 2].clone()
+    for i in range(1, nparts):
+        nb, mb, m2b = p[i, 0], p[i, 1], p[i, 2]
+        tot = n + nb
+        delta = mb - mean
+        mean = mean + delta * nb / tot
+        m2 = m2 + m2b + delta * delta * n * nb / tot
+        n = tot
+    return n, mean, m2
+
+
+def _syncbn_worker(rank, world):
+    from segmi.distributed import SyncBNContext
+    g = torch.Generator().manual_seed(9)
+    rows = (3, 5)                                   # ragged shards: ranks hold different batch sizes
+    X = torch.randn(sum(rows), 6, 4, 4, generator=g) * 3 + 1
+    off = sum(rows[:rank])
+    x = X[off:off + rows[rank]]
+    ctx = SyncBNContext()
+    parts, nparts, count = ctx.gather_stats(_welford_partial(x), x.shape[0] * 16)
+    count2 = ctx.global_count(x.shape[0] * 16)       # cached second time
+    n, mean, m2 = _chan_merge(parts, nparts, 6)
+    ref_mean = X.double().mean((0, 2, 3))
+    ref_var = X.double().var((0, 2, 3), unbiased=False)
+    sums = torch.arange(12.0) * (rank + 1)
+    gs = ctx.reduce_sums(sums)
+    return {"nparts": nparts, "count": count, "count2": count2, "n": float(n[0]),
+            "mean_err": (mean - ref_mean).abs().max().item(), "var_err": (m2 / n - ref_var).abs().max().item(),
+            "sums_ok": torch.equal(gs, torch.arange(12.0) * 3), "local_untouched": torch.equal(sums, torch.arange(12.0) * (rank + 1))}
+
+
+def test_syncbn_statistic_exchange_matches_global_batch():
+    for r in _spawn(_syncbn_worker):
+        assert r["nparts"] == 2 and r["count"] == r["count2"] == r["n"] == 8 * 16
+        assert r["mean_err"] < 1e-6 and r["var_err"] < 1e-5
+        assert r["sums_ok"] and r["local_untouched"]
+
+
+def test_single_process_paths_need_no_process_group():
+    from segmi.distributed import GradAllReducer, SyncBNContext
+    lin = torch.nn.Linear(3, 2)
+    red = GradAllReducer(lin.parameters())
+    red.zero_grad()
+    lin(torch.ones(4, 3)).sum().backward()
+    red.finish()
+    assert torch.allclose(lin.weight.grad, torch.full((2, 3), 4.0))
+    ctx = SyncBNContext()
+    p = torch.ones(6)
+    assert ctx.gather_stats(p, 10) == (p, 1, 10.0) and ctx.reduce_sums(p) is p
+
+
+def test_syncbn_plugin_surface():
+    """convert_model / DataParallelWithCallback keep the reference's names and share parameters."""
+    import models
+    from segmi import nn as snn
+    from utils.sync_batchnorm import DataParallelWithCallback, SynchronizedBatchNorm2d, convert_model, patch_replication_callback
+    m = models.PSPNet(3, backbone="resnet50", pretrained=False)
+    keys = list(m.state_dict().keys())
+    w_before = m.layer1[0].bn1.weight
+    m2 = convert_model(m)
+    bns = [b for b in m2.modules() if isinstance(b, torch.nn.BatchNorm2d)]
+    assert bns and all(isinstance(b, SynchronizedBatchNorm2d) and isinstance(b, snn.BatchNorm2d) for b in bns)
+    assert list(m2.state_dict().keys()) == keys and m2.layer1[0].bn1.weight is w_before
+    dp = DataParallelWithCallback(m2, device_ids=[0])
+    assert dp.module is m2 and patch_replication_callback(dp) is dp
+    assert all(p.grad is not None for p in m2.parameters())   # bucket views attached
