@@ -208,6 +208,193 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the gather kernel (the fast path): operand tiles go global -> LDS directly with
+// `buffer_load_dwordx4 ... offen lds` (no VGPR staging, no ds_write pass, no per-load branches):
+//   * a wave-instruction deposits 64 lanes x 16 B = 1 KiB lane-linearly, i.e. 8 tile rows of BK = 32
+//     floats (128 B) each, so LDS rows are UNPADDED; bank conflicts of the ds_read_b128 fragment reads
+//     are avoided by an XOR swizzle of the 16-byte k-group, applied on the SOURCE address of the DMA and
+//     again on the read (slot = kgroup ^ ((row >> 1) & 7): 16 consecutive rows hit 16 distinct 4-bank groups);
+//   * out-of-image taps, rows past M / Cd and channels past Cs are given a byte offset beyond the buffer
+//     descriptor's range: the hardware then writes ZEROS to LDS (tools/probes/lds_dma_oob.hip verifies
+//     both properties on gfx950).  Padding and dilation stay pure index math, with no divergence.
+// Requires both operands to be smaller than 4 GiB (32-bit buffer offsets); larger tensors take the
+// register-staged kernel above.
+// The DMA is issued from inline asm on purpose: hipcc does not count asm memory operations, so it does
+// not put an `s_waitcnt vmcnt(0)` between the DMA of stage t+1 and the ds_reads of stage t (with the
+// builtin it does, serialising load latency and MFMA work).  We count them ourselves: one
+// `s_waitcnt vmcnt(0)` + barrier at the end of each stage.  M0 (LDS destination base) is written in
+// the same statement that consumes it.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0, no swizzle
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);                              // num_records (bytes)
+    r.w = 0x00020000;                                                              // raw buffer, 32-bit data format
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(lds_void*)p; }
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voffset, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;      // wave-instructions per wave per tile (8 rows each, 4 waves)
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile shape");
+
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int STAGE = (BM + BN) * BK;               // floats per pipeline stage
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    const unsigned ntiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned t = xcd_swizzle(blockIdx.x, ntiles);
+    const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const i32x4 src_rsrc = make_rsrc(p.src, src_bytes);
+    const i32x4 wgt_rsrc = make_rsrc(p.wgt, wgt_bytes);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)wave * (8 * BK * 4);
+
+    // DMA role of this lane: row (wave*8 + lane/8) of every 32-row group, 16-byte slot lane%8
+    const int rl = wave * 8 + (lane >> 3);
+    const int kg = (lane & 7) ^ ((rl >> 1) & 7);        // k-group this lane fetches (source-side swizzle)
+
+    int a_pix[A_IT], a_bh[A_IT], a_bw[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + i * 32 + rl;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int hw = p.Hd * p.Wd;
+        const int n = mm / hw, rem = mm - n * hw;
+        const int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+        a_pix[i] = n * p.Hs * p.Ws;
+        if (MODE == MODE_FPROP) { a_bh[i] = hd * p.stride - p.pad; a_bw[i] = wd * p.stride - p.pad; }
+        else                    { a_bh[i] = hd + p.pad;            a_bw[i] = wd + p.pad; }
+        a_ok[i] = ok;
+    }
+    const int RS = p.R * p.S;
+    unsigned b_off[B_IT];                                // element offset of the filter row, OOB if k >= Cd
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int k = n0 + i * 32 + rl;
+        b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)(RS * p.Cs) : OOB;
+    }
+
+    auto issue = [&](int r, int s, int c0, int buf) {
+        const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BM * BK * 4;   // LDS byte addresses (wave's 8-row slice)
+        const int c = c0 + kg * 4;
+        const bool cok = c < p.Cs;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int hs, ws;
+            bool ok = a_ok[i] && cok;
+            if (MODE == MODE_FPROP) {
+                hs = a_bh[i] + r * p.dil; ws = a_bw[i] + s * p.dil;
+            } else {
+                const int th = a_bh[i] - r * p.dil, tw = a_bw[i] - s * p.dil;
+                if (p.stride == 1) { hs = th; ws = tw; }
+                else {
+                    ok = ok && th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0);
+                    hs = th / p.stride; ws = tw / p.stride;
+                }
+            }
+            ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+            const unsigned off = ((unsigned)(a_pix[i] + hs * p.Ws + ws) * (unsigned)p.lds + (unsigned)c) * 4u;
+            dma16(src_rsrc, ok ? off : OOB, As + i * (32 * BK * 4));
+        }
+        const unsigned tapc = (unsigned)((r * p.S + s) * p.Cs + c);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const bool ok = cok && b_off[i] != OOB;
+            dma16(wgt_rsrc, ok ? (b_off[i] + tapc) * 4u : OOB, Bs + i * (32 * BK * 4));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunk = (p.Cs + BK - 1) / BK;
+    const int T = nchunk * RS;
+    int r = 0, s = 0, c0 = 0;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
+    auto advance = [&]() {
+        if (++s == p.S) { s = 0; if (++r == p.R) { r = 0; c0 += BK; } }
+    };
+
+    issue(r, s, c0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    const int lrow32 = lane & 31, lhalf = lane >> 5;
+    const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
+    for (int it = 0; it < T; ++it) {
+        if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
+        const float* Ab = smem + buf * STAGE;
+        const float* Bb = Ab + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ld4(Ab + (wm0 + i * 32 + lrow32) * BK + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = ld4(Bb + (wn0 + j * 32 + lrow32) * BK + slot);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
+        __syncthreads();                                     // ... for every wave, and this stage is free again
+        buf ^= 1;
+    }
+
+    // ---- epilogue (same C/D mapping as the register-staged kernel)
+    const int cd4 = min((p.Cd + 3) & ~3, p.ldd);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn0 + j * 32 + lrow32;
+        const bool kreal = k < p.Cd, kok = k < cd4;
+        const float bv = (kreal && p.bias) ? p.bias[k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                if (kok && m < p.M) {
+                    float* o = p.dst + (long)m * p.ldd + k;
+                    float v = acc[i][j][e] + bv;
+                    if (p.accumulate) v += *o;
+                    *o = kreal ? v : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct WgradParams {
     const float* x;   // [N,H,W,C] ldx
     const float* dy;  // [N,P,Q,K] ldy
@@ -256,6 +443,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int PQ = p.P * p.Q;
 
     float4 ra[A_IT], rb[B_IT];
+    // Pixel coordinates of each B row this thread loads, advanced incrementally chunk by chunk (the
+    // m -> (n, p, q) divisions are paid once here, not per chunk).
+    int b_n[B_IT], b_p[B_IT], b_q[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int m = mbeg + b_row + i * B_RPP;
+        const int mm = m < p.M ? m : 0;
+        b_n[i] = mm / PQ;
+        const int rem = mm - b_n[i] * PQ;
+        b_p[i] = rem / p.Q;
+        b_q[i] = rem - b_p[i] * p.Q;
+    }
+    const int tap_h = -p.pad + r * p.dil, tap_w = -p.pad + s * p.dil;
     auto gload = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -264,14 +464,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            int m = mb + b_row + i * B_RPP;
-            bool ok = b_cok && m < mend;
-            int mm = ok ? m : 0;
-            int n = mm / PQ, rem = mm - n * PQ;
-            int pp = rem / p.Q, qq = rem - pp * p.Q;
-            int hs = pp * p.stride - p.pad + r * p.dil, ws = qq * p.stride - p.pad + s * p.dil;
-            ok = ok && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
-            rb[i] = ok ? ld4(p.x + ((long)(n * p.H + hs) * p.W + ws) * p.ldx + c0 + b_col) : zero4();
+            const int m = mb + b_row + i * B_RPP;
+            const int hs = b_p[i] * p.stride + tap_h, ws = b_q[i] * p.stride + tap_w;
+            const bool ok = b_cok && m < mend && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+            rb[i] = ok ? ld4(p.x + ((long)(b_n[i] * p.H + hs) * p.W + ws) * p.ldx + c0 + b_col) : zero4();
+            // advance this row's pixel by one chunk (BKP pixels)
+            b_q[i] += BKP;
+            while (b_q[i] >= p.Q) {
+                b_q[i] -= p.Q;
+                if (++b_p[i] == p.P) { b_p[i] = 0; ++b_n[i]; }
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -313,6 +515,150 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    float* out = p.out + (long)split * p.split_stride;
+    const int RS = p.R * p.S;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wn0 + j * 32 + lrow32;
+        const bool cok = c < p.C;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                if (cok && k < p.K) out[((long)k * RS + tap) * p.C + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+// LDS-DMA variant of the weight-gradient kernel.  Tile rows are pixels (the GEMM reduction axis) and
+// run along channels, so a row of BM (BN) floats is BM/4 lanes x 16 B of one DMA wave-instruction and the
+// unpadded [BKP][BM] layout is already conflict-free for the per-lane ds_read_b32 operand reads
+// (lanes read consecutive channels of one pixel).  Out-of-image taps / rows past the split's pixel range /
+// channels past K (C) get an out-of-range offset and arrive as zeros.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int BKP = 32, WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LPR = BM / 4, B_LPR = BN / 4;               // lanes per tile row
+    constexpr int A_RPI = 64 / A_LPR, B_RPI = 64 / B_LPR;       // tile rows per wave-instruction
+    constexpr int A_IT = BKP / A_RPI / 4, B_IT = BKP / B_RPI / 4;  // wave-instructions per wave per stage
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr int STAGE = BKP * (BM + BN);
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile passes");
+
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const int lrow32 = lane & 31, lhalf = lane >> 5;
+
+    // tile = (c-tile, k-tile, tap) with the tap fastest, and each XCD owning a contiguous range of tile ids:
+    // an XCD's L2 then holds only ITS channel slices of x (read once per tap from L2, not from HBM) plus dy.
+    const int RSn = p.R * p.S;
+    int tidx = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tap = tidx % RSn; tidx /= RSn;
+    const int tk = tidx % p.tiles_k; tidx /= p.tiles_k;
+    const int tc = tidx;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int k0 = tk * BM, c0 = tc * BN;
+    const int split = blockIdx.y;
+    const int mbeg = split * p.chunks_per_split * BKP;
+    const int mend = min(p.M, mbeg + p.chunks_per_split * BKP);
+    const int PQ = p.P * p.Q;
+
+    const i32x4 dy_rsrc = make_rsrc(p.dy, dy_bytes);
+    const i32x4 x_rsrc = make_rsrc(p.x, x_bytes);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+
+    // DMA roles: A (dy) row = (i*4 + wave)*A_RPI + lane/A_LPR, channel group lane%A_LPR; same for B (x)
+    const int a_rl = lane / A_LPR, a_col = (lane % A_LPR) * 4;
+    const int b_rl = lane / B_LPR, b_col = (lane % B_LPR) * 4;
+    const bool a_cok = (k0 + a_col) < ((p.K + 3) & ~3);          // dy rows own zero-filled channel padding up to 4
+    const bool b_cok = (c0 + b_col) < p.C;
+    int b_n[B_IT], b_p[B_IT], b_q[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int m = mbeg + (i * 4 + wave) * B_RPI + b_rl;
+        const int mm = m < p.M ? m : 0;
+        b_n[i] = mm / PQ;
+        const int rem = mm - b_n[i] * PQ;
+        b_p[i] = rem / p.Q;
+        b_q[i] = rem - b_p[i] * p.Q;
+    }
+    const int tap_h = -p.pad + r * p.dil, tap_w = -p.pad + s * p.dil;
+
+    auto issue = [&](int mb, int buf) {
+        const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BKP * BM * 4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int row0 = (i * 4 + wave) * A_RPI;
+            const int m = mb + row0 + a_rl;
+            const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)(k0 + a_col)) * 4u;
+            dma16(dy_rsrc, (a_cok && m < mend) ? off : OOB, As + row0 * (BM * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row0 = (i * 4 + wave) * B_RPI;
+            const int m = mb + row0 + b_rl;
+            const int hs = b_p[i] * p.stride + tap_h, ws = b_q[i] * p.stride + tap_w;
+            const bool ok = b_cok && m < mend && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+            const unsigned off = ((unsigned)((b_n[i] * p.H + hs) * p.W + ws) * (unsigned)p.ldx + (unsigned)(c0 + b_col)) * 4u;
+            dma16(x_rsrc, ok ? off : OOB, Bs + row0 * (BN * 4));
+            b_q[i] += BKP;
+            while (b_q[i] >= p.Q) {
+                b_q[i] -= p.Q;
+                if (++b_p[i] == p.P) { b_p[i] = 0; ++b_n[i]; }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (mbeg < mend) {
+        issue(mbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int mb = mbeg; mb < mend; mb += BKP) {
+            if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
+            const float* Ab = smem + buf * STAGE;
+            const float* Bb = Ab + BKP * BM;
+            // operand registers are double-buffered by hand: the ds_reads of step kk+2 are in flight while the
+            // MFMAs of step kk issue (without it the wave waits out the LDS latency every 4 MFMAs: 115 vs 130 TF/s)
+            float a[3][TM], b[3][TN];
+            auto fetch = [&](int kk, int slot) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[slot][i] = Ab[(kk * 2 + lhalf) * BM + wm0 + i * 32 + lrow32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[slot][j] = Bb[(kk * 2 + lhalf) * BN + wn0 + j * 32 + lrow32];
+            };
+            fetch(0, 0);
+            fetch(1, 1);
+#pragma unroll
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                if (kk + 2 < BKP / 2) fetch(kk + 2, (kk + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % 3][i], b[kk % 3][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;
         }
@@ -412,8 +758,39 @@ int conv_bk() {
     return g_bk;
 }
 
+template <int BM, int BN, int WM, int WN, int MODE>
+int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
+    p.tiles_m = segmi_cdiv(p.M, BM);
+    p.tiles_n = segmi_cdiv(p.Cd, BN);
+    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    auto kern = conv_dma_kernel<BM, BN, WM, WN, MODE>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    return segmi_launch_status();
+}
+
+int g_dma = -1;  // SEGMI_CONV_DMA=0 forces the register-staged kernels (A/B testing)
+bool conv_dma() {
+    if (g_dma < 0) {
+        const char* e = getenv("SEGMI_CONV_DMA");
+        g_dma = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_dma == 1;
+}
+// bytes spanned by an operand if it fits 32-bit buffer offsets (with room for the OOB marker), else 0
+unsigned span32(long elems) {
+    const long b = elems * (long)sizeof(float);
+    return (b > 0 && b < 0xFFFFFF00L) ? (unsigned)b : 0u;
+}
+
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
+    const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
+    const unsigned wb = span32((long)p.Cd * p.R * p.S * p.Cs);
+    if (conv_dma() && sb && wb) {
+        if (p.Cd > 64) return launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
+        if (p.Cd > 32) return launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
+        return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, st);
+    }
     const bool bk32 = conv_bk() == 32 && p.Cs >= 32;
     if (p.Cd > 64) return bk32 ? launch_gather<128, 128, 32, 2, 2, MODE>(p, st) : launch_gather<128, 128, 16, 2, 2, MODE>(p, st);
     if (p.Cd > 32) return bk32 ? launch_gather<128, 64, 32, 2, 2, MODE>(p, st) : launch_gather<128, 64, 16, 2, 2, MODE>(p, st);
@@ -432,7 +809,7 @@ bool desc_ok(const segmi_conv_desc* d) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct WgradPlan { int bm, bn, tiles_k, tiles_c, nsplit, chunks_per_split; };
-constexpr int WG_BKP = 16;
+constexpr int WG_BKP = 32;
 WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     WgradPlan pl;
     pl.bm = d->K > 64 ? 128 : 64;
@@ -442,21 +819,40 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     const long tiles = (long)pl.tiles_k * pl.tiles_c * d->R * d->S;
     const long M = (long)d->N * d->P * d->Q;
     const long chunks = (M + WG_BKP - 1) / WG_BKP;
-    long want = (4L * SEGMI_NUM_CU + tiles - 1) / tiles;        // ~4 workgroups per CU
-    long max_split = chunks / 16 > 0 ? chunks / 16 : 1;          // >= 256 pixels per split
-    long ns = want < max_split ? want : max_split;
-    if (ns < 1) ns = 1;
-    if (ns > 65535) ns = 65535;
+    // Split the pixel reduction so that the grid fills whole "rounds" of resident workgroups: two
+    // 256-thread workgroups (64 KB LDS each) live on a CU, i.e. 512 slots.  1152 tiles unsplit are 2.25
+    // rounds (75 % efficient: measured 100 vs 127 TF/s for the PSP bottleneck); x4 gives exactly 9.
+    const long slots = 2L * SEGMI_NUM_CU;
+    long max_split = chunks / 8 > 0 ? chunks / 8 : 1;            // >= 256 pixels per split
+    if (max_split > 512) max_split = 512;
+    long ns = 1;
+    double best = -1.0;
+    for (long c = 1; c <= max_split; ++c) {
+        const long wg = tiles * c;
+        if (wg < slots && c < max_split) continue;               // fill the chip first
+        const long rounds = (wg + slots - 1) / slots;
+        const double eff = (double)wg / (double)(rounds * slots);
+        if (eff > best + 1e-9) { best = eff; ns = c; }
+        if (eff >= 0.92 || rounds >= 12) break;                  // good enough: keep the split (and its traffic) small
+    }
     pl.chunks_per_split = (int)((chunks + ns - 1) / ns);
     pl.nsplit = (int)((chunks + pl.chunks_per_split - 1) / pl.chunks_per_split);
     return pl;
+}
+
+bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
+    *xb = span32((long)p.N * p.H * p.W * p.ldx);
+    *dyb = span32((long)p.N * p.P * p.Q * p.ldy);
+    return conv_dma() && *xb && *dyb;
 }
 
 template <int BM, int BN>
 int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
     dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * p.R * p.S), (unsigned)pl.nsplit);
-    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
+    unsigned xb, dyb;
+    if (wgrad_dma(p, &xb, &dyb)) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN>), grid, dim3(256), lds, st, p, xb, dyb);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();
 }
 
@@ -537,12 +933,19 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (!desc_ok(d) || !buf || len == 0 || op < 0 || op > 2) return SEGMI_ERR_BADARG;
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
-        snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
+        const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d> splitk=%d", pl.bm, pl.bn, pl.nsplit);
+        else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
     const int Cs = op == 0 ? d->C : ((d->K + 3) & ~3), Cd = op == 0 ? d->K : d->C;
-    const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
+    if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
+        snprintf(buf, len, "conv_dma_kernel<128, %d, %s, %d>", bn, bn == 32 ? "4, 1" : "2, 2", op);
+        return SEGMI_OK;
+    }
+    const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
     snprintf(buf, len, "conv_gather_kernel<128, %d, %d, %s, %d>", bn, bk, bn == 32 ? "4, 1" : "2, 2", op);
     return SEGMI_OK;
 }

@@ -56,8 +56,12 @@ def test_status_strings_and_queries():
     d = ConvDesc(8, 256, 256, 64, 64, 3, 3, 256, 256, 1, 1, 1, 64, 64)
     ws = lib.segmi_conv2d_wgrad_workspace(d)
     assert ws % (64 * 9 * 64 * 4) == 0 and ws // (64 * 9 * 64 * 4) >= 32
-    # the 4096->512 3x3 PSP bottleneck already has >1000 tiles: no split, no workspace
+    # the 4096->512 3x3 PSP bottleneck has 1152 tiles = 2.25 rounds of the 512 resident workgroups:
+    # (75 % efficient); the planner takes the smallest split that is >= 92 % efficient: x3 = 6.75 -> 7 rounds
     d = ConvDesc(8, 64, 64, 4096, 512, 3, 3, 64, 64, 1, 1, 1, 4096, 512)
+    assert lib.segmi_conv2d_wgrad_workspace(d) == 3 * 512 * 9 * 4096 * 4
+    # a 1x1 2048->512 on an 8-pixel map cannot be split at all
+    d = ConvDesc(8, 1, 1, 2048, 512, 1, 1, 1, 1, 1, 0, 1, 2048, 512)
     assert lib.segmi_conv2d_wgrad_workspace(d) == 0
     assert lib.segmi_bn_stats_workspace(8 * 64 * 64, 2048) >= 3 * 2048 * 4
     assert lib.segmi_ce_workspace(1 << 21) > 0
