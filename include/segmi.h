@@ -81,6 +81,25 @@ size_t segmi_colsum_workspace(long rows, int C);
 int segmi_colsum(const float* dy, int ld, long rows, int C, float* out, void* workspace, size_t workspace_bytes,
                  segmi_stream_t stream);
 
+/* ------------------------------------------------------------------ depthwise convolution (K2)
+ * nn.Conv2d(C, C, 3, groups=C) of Xception's SeparableConv2d (models/deeplabv3_plus.py:80).  Uses
+ * segmi_conv_desc with K == C; the filter is [R,S,C] (tap-major, channels contiguous), R*S <= 9.
+ * HBM-bound streaming kernels (0.75 % of Xception's MACs): deliberately not a GEMM. */
+int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, segmi_stream_t stream);
+int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream);
+size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d);
+int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
+                         size_t workspace_bytes, segmi_stream_t stream);
+
+/* ------------------------------------------------------------------ 2x2 pixel shuffles (K3)
+ * nn.ConvTranspose2d(Cin, K, kernel_size=2, stride=2) (models/unet.py:37) == 1x1 convolution with 4K
+ * outputs (column k*4 + r*2 + s, weight W[c,k,r,s]) followed by depth_to_space (+ bias[k]); its backward
+ * begins with space_to_depth of dy.  src/dst NHWC; H, W are the LOW-resolution sizes; K % 4 == 0. */
+int segmi_depth_to_space2(const float* src, int ld_src, float* dst, int ld_dst, const float* bias, int N, int H, int W,
+                          int K, segmi_stream_t stream);
+int segmi_space_to_depth2(const float* src, int ld_src, float* dst, int ld_dst, int N, int H, int W, int K,
+                          segmi_stream_t stream);
+
 /* ------------------------------------------------------------------ batch norm (K4/K5/K6)
  * Replaces aten::native_batch_norm(+_backward), relu_/threshold_backward and the residual add_:
  * every nn.BatchNorm2d call site (61 in PSPNet-R50), F.batch_norm fallback

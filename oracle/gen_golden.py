@@ -102,6 +102,33 @@ def gen_pspnet(models, losses):
     torch.save(rec, os.path.join(GOLD, "pspnet_r50.pt"))
 
 
+def gen_unet(models, losses):
+    """cfg1 regime (UNet, 2 classes, CE) at two sizes: 64x64 (clean halving) and 50x70 (ceil-mode pooling and the
+    bilinear re-alignment of models/unet.py:43-47 both active).  Full outputs + gradient digests, BN batch stats."""
+    crit = losses.CrossEntropyLoss2d(ignore_index=255)
+    rec = {}
+    for name, (N, H, W), C in (("s64", (2, 64, 64), 2), ("s50x70", (2, 50, 70), 3)):
+        torch.manual_seed(0)
+        model = models.UNet(C)
+        man = manifest_of(model.state_dict())
+        model.load_state_dict(synth_state_dict(man, seed=1))
+        model.train()
+        x, t = synth_batch(N, 3, H, W, C, seed=4321)
+        out = model(x)
+        loss = crit(out, t)
+        loss.backward()
+        sd_after = model.state_dict()
+        rec[name] = {"manifest": man, "num_classes": C, "input_shape": (N, 3, H, W), "out": out.detach().clone(),
+                     "loss": loss.detach().clone(), "grads": _grad_digest(model.named_parameters()),
+                     "running": {k: sd_after[k].clone() for k in ("start_conv.1.running_mean", "middle_conv.4.running_var",
+                                                                  "up4.up_conv.4.running_mean")}}
+        model.eval()
+        with torch.no_grad():
+            rec[name]["eval_out"] = model(x).clone()
+        print("unet.pt[%s]: loss %.6f" % (name, loss.item()))
+    torch.save(rec, os.path.join(GOLD, "unet.pt"))
+
+
 def gen_misc():
     sys.path.insert(0, reference_harness.REFERENCE)
     from utils.metrics import eval_metrics
@@ -133,10 +160,12 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     models, losses = reference_harness.load()
-    which = sys.argv[1:] or ["losses", "pspnet", "misc"]
+    which = sys.argv[1:] or ["losses", "pspnet", "unet", "misc"]
     if "losses" in which:
         gen_losses(losses)
     if "pspnet" in which:
         gen_pspnet(models, losses)
+    if "unet" in which:
+        gen_unet(models, losses)
     if "misc" in which:
         gen_misc()

@@ -1,0 +1,276 @@
+// Depthwise 3x3 convolution (Xception SeparableConv2d) and the 2x2 pixel shuffles that turn
+// nn.ConvTranspose2d(kernel=2, stride=2) into a 1x1 convolution on the MFMA path.
+//
+//   depthwise : models/deeplabv3_plus.py:80 (`groups=in_channels`), reached from Block :89-132 and the exit-flow
+//               separable convs :160-165 — 63 launches per forward for Xception, 0.75 % of the MACs: pure HBM
+//               streaming (one read of x per output, 9 taps from L1/L2), so it is NOT reshaped into a GEMM.
+//   shuffles  : models/unet.py:37 `nn.ConvTranspose2d(in, in//2, kernel_size=2, stride=2)`:
+//               y[n, 2h+r, 2w+s, k] = b[k] + sum_c x[n,h,w,c] * W[c,k,r,s]  ==  a 1x1 conv with 4K outputs
+//               (column k*4 + r*2 + s) followed by depth_to_space; its backward starts with space_to_depth.
+//
+// All kernels: NHWC fp32, a thread owns one float4 channel group and walks pixels (rowgeom.h).
+#include "rowgeom.h"
+
+namespace {
+
+struct DwGeom {
+    int N, H, W, C, P, Q, R, S, stride, pad, dil;
+};
+
+// y[n,p,q,c] = sum_{r,s} x[n, p*stride - pad + r*dil, q*stride - pad + s*dil, c] * w[r,s,c]
+template <int MAXT>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         float* __restrict__ y, int ldy, DwGeom g) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= g.C) return;
+    const int T = g.R * g.S;
+    float4 wt[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) wt[t] = t < T ? ld4(w + (long)t * g.C + c4 * 4) : zero4();
+    const long rows = (long)g.N * g.P * g.Q;
+    for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
+        const int q = (int)(row % g.Q);
+        const long t1 = row / g.Q;
+        const int pp = (int)(t1 % g.P), n = (int)(t1 / g.P);
+        float4 acc = zero4();
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < T) {
+                const int r = t / g.S, s = t - r * g.S;
+                const int h = pp * g.stride - g.pad + r * g.dil, ww = q * g.stride - g.pad + s * g.dil;
+                if ((unsigned)h < (unsigned)g.H && (unsigned)ww < (unsigned)g.W) {
+                    const float4 v = ld4(x + ((long)(n * g.H + h) * g.W + ww) * ldx + c4 * 4);
+                    acc.x = fmaf(v.x, wt[t].x, acc.x); acc.y = fmaf(v.y, wt[t].y, acc.y);
+                    acc.z = fmaf(v.z, wt[t].z, acc.z); acc.w = fmaf(v.w, wt[t].w, acc.w);
+                }
+            }
+        }
+        st4(y + row * ldy + c4 * 4, acc);
+    }
+}
+
+// dx[n,h,w,c] = sum_{r,s} dy[n, (h + pad - r*dil)/stride, (w + pad - s*dil)/stride, c] * w[r,s,c]   (where divisible)
+template <int MAXT>
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int lddx, DwGeom g) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= g.C) return;
+    const int T = g.R * g.S;
+    float4 wt[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) wt[t] = t < T ? ld4(w + (long)t * g.C + c4 * 4) : zero4();
+    const long rows = (long)g.N * g.H * g.W;
+    for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
+        const int ww = (int)(row % g.W);
+        const long t1 = row / g.W;
+        const int h = (int)(t1 % g.H), n = (int)(t1 / g.H);
+        float4 acc = zero4();
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < T) {
+                const int r = t / g.S, s = t - r * g.S;
+                const int th = h + g.pad - r * g.dil, tw = ww + g.pad - s * g.dil;
+                if (th >= 0 && tw >= 0 && th % g.stride == 0 && tw % g.stride == 0) {
+                    const int pp = th / g.stride, q = tw / g.stride;
+                    if (pp < g.P && q < g.Q) {
+                        const float4 v = ld4(dy + ((long)(n * g.P + pp) * g.Q + q) * lddy + c4 * 4);
+                        acc.x = fmaf(v.x, wt[t].x, acc.x); acc.y = fmaf(v.y, wt[t].y, acc.y);
+                        acc.z = fmaf(v.z, wt[t].z, acc.z); acc.w = fmaf(v.w, wt[t].w, acc.w);
+                    }
+                }
+            }
+        }
+        st4(dx + row * lddx + c4 * 4, acc);
+    }
+}
+
+// part[blockIdx.y][t][C] = sum over this block's pixel range of dy[pix,c] * x[tap t of pix, c]
+template <int MAXT>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                           float* __restrict__ part, DwGeom g) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 * 4 < g.C;
+    const int T = g.R * g.S;
+    float4 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = zero4();
+    const long rows = (long)g.N * g.P * g.Q;
+    if (cok)
+        for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
+            const int q = (int)(row % g.Q);
+            const long t1 = row / g.Q;
+            const int pp = (int)(t1 % g.P), n = (int)(t1 / g.P);
+            const float4 gy = ld4(dy + row * lddy + c4 * 4);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < T) {
+                    const int r = t / g.S, s = t - r * g.S;
+                    const int h = pp * g.stride - g.pad + r * g.dil, ww = q * g.stride - g.pad + s * g.dil;
+                    if ((unsigned)h < (unsigned)g.H && (unsigned)ww < (unsigned)g.W) {
+                        const float4 v = ld4(x + ((long)(n * g.H + h) * g.W + ww) * ldx + c4 * 4);
+                        acc[t].x = fmaf(v.x, gy.x, acc[t].x); acc[t].y = fmaf(v.y, gy.y, acc[t].y);
+                        acc[t].z = fmaf(v.z, gy.z, acc[t].z); acc[t].w = fmaf(v.w, gy.w, acc[t].w);
+                    }
+                }
+            }
+        }
+    __shared__ float4 sm[256];
+    const int tix = threadIdx.y * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {   // T is uniform: the barriers below are reached by every thread
+            sm[tix] = acc[t];
+            __syncthreads();
+            for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+                if ((int)threadIdx.y < s) {
+                    float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    sm[tix] = a;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.y == 0 && cok) st4(part + ((long)blockIdx.y * T + t) * g.C + c4 * 4, sm[tix]);
+            __syncthreads();
+        }
+    }
+}
+
+// out[i] = sum_p part[p][i]; block = (32 elements, 8 part lanes)
+__global__ __launch_bounds__(256) void dw_sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    float a = 0.f;
+    if (i < n)
+        for (int p = threadIdx.y; p < nparts; p += 8) a += part[(long)p * n + i];
+    __shared__ float sm[8][33];
+    sm[threadIdx.y][threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+        out[i] = t;
+    }
+}
+
+// src[pix, k*4 + rs] -> dst[(2h + r, 2w + s), k] (+ bias[k]);  a thread moves a 4x4 (channel x position) block
+__global__ __launch_bounds__(256) void depth_to_space2_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                              const float* __restrict__ bias, int N, int H, int W, int K) {
+    const int k4 = blockIdx.x * blockDim.x + threadIdx.x;   // channels k4*4 .. +3
+    if (k4 * 4 >= K) return;
+    const float4 bv = bias ? ld4(bias + k4 * 4) : zero4();
+    const long rows = (long)N * H * W;
+    for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
+        const int w = (int)(row % W);
+        const long t1 = row / W;
+        const int h = (int)(t1 % H), n = (int)(t1 / H);
+        const float* sp = src + row * lds + k4 * 16;
+        const float4 c0 = ld4(sp), c1 = ld4(sp + 4), c2 = ld4(sp + 8), c3 = ld4(sp + 12);   // channel k+j: (rs = 0..3)
+        float* o = dst + ((long)(n * 2 * H + 2 * h) * (2 * W) + 2 * w) * ldd + k4 * 4;
+        const long down = (long)2 * W * ldd;
+        st4(o, make_float4(c0.x + bv.x, c1.x + bv.y, c2.x + bv.z, c3.x + bv.w));                 // r=0, s=0
+        st4(o + ldd, make_float4(c0.y + bv.x, c1.y + bv.y, c2.y + bv.z, c3.y + bv.w));           // r=0, s=1
+        st4(o + down, make_float4(c0.z + bv.x, c1.z + bv.y, c2.z + bv.z, c3.z + bv.w));          // r=1, s=0
+        st4(o + down + ldd, make_float4(c0.w + bv.x, c1.w + bv.y, c2.w + bv.z, c3.w + bv.w));    // r=1, s=1
+    }
+}
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                              int N, int H, int W, int K) {
+    const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k4 * 4 >= K) return;
+    const long rows = (long)N * H * W;   // H, W = the LOW-resolution size; src is [N, 2H, 2W, K]
+    for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
+        const int w = (int)(row % W);
+        const long t1 = row / W;
+        const int h = (int)(t1 % H), n = (int)(t1 / H);
+        const float* i0 = src + ((long)(n * 2 * H + 2 * h) * (2 * W) + 2 * w) * lds + k4 * 4;
+        const long down = (long)2 * W * lds;
+        const float4 p00 = ld4(i0), p01 = ld4(i0 + lds), p10 = ld4(i0 + down), p11 = ld4(i0 + down + lds);
+        float* o = dst + row * ldd + k4 * 16;
+        st4(o, make_float4(p00.x, p01.x, p10.x, p11.x));
+        st4(o + 4, make_float4(p00.y, p01.y, p10.y, p11.y));
+        st4(o + 8, make_float4(p00.z, p01.z, p10.z, p11.z));
+        st4(o + 12, make_float4(p00.w, p01.w, p10.w, p11.w));
+    }
+}
+
+bool dw_ok(const segmi_conv_desc* d) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->R <= 0 || d->S <= 0) return false;
+    if (d->K != d->C || d->R * d->S > 9 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return false;
+    if (d->P != (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1) return false;
+    if (d->Q != (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1) return false;
+    return d->P > 0 && d->Q > 0;
+}
+DwGeom dw_geom(const segmi_conv_desc* d) {
+    DwGeom g;
+    g.N = d->N; g.H = d->H; g.W = d->W; g.C = d->C; g.P = d->P; g.Q = d->Q; g.R = d->R; g.S = d->S;
+    g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+    return g;
+}
+int dw_parts(long rows) {
+    long p = (rows + 255) / 256;
+    if (p < 1) p = 1;
+    if (p > 256) p = 256;
+    return (int)p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, segmi_stream_t stream) {
+    if (!dw_ok(d) || !x || !w_rsc || !y) return SEGMI_ERR_BADARG;
+    if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
+    const long rows = (long)d->N * d->P * d->Q;
+    RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL((dwconv_fwd_kernel<9>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, dw_geom(d));
+    return segmi_launch_status();
+}
+
+int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream) {
+    if (!dw_ok(d) || !dy || !w_rsc || !dx) return SEGMI_ERR_BADARG;
+    if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
+    const long rows = (long)d->N * d->H * d->W;
+    RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL((dwconv_dgrad_kernel<9>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, dw_geom(d));
+    return segmi_launch_status();
+}
+
+size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d) {
+    if (!dw_ok(d)) return 0;
+    return (size_t)dw_parts((long)d->N * d->P * d->Q) * d->R * d->S * d->C * sizeof(float);
+}
+
+int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
+                         size_t workspace_bytes, segmi_stream_t stream) {
+    if (!dw_ok(d) || !x || !dy || !dw_rsc) return SEGMI_ERR_BADARG;
+    if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_dwconv2d_wgrad_workspace(d)) return SEGMI_ERR_WORKSPACE;
+    const long rows = (long)d->N * d->P * d->Q;
+    const int parts = dw_parts(rows);
+    RowGeom g = row_geom(rows, d->C, 1, 1);
+    g.grid.y = parts;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<9>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, dw_geom(d));
+    const int n = d->R * d->S * d->C;
+    hipLaunchKernelGGL(dw_sum_parts_kernel, dim3(segmi_cdiv(n, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, n, dw_rsc);
+    return segmi_launch_status();
+}
+
+int segmi_depth_to_space2(const float* src, int ld_src, float* dst, int ld_dst, const float* bias, int N, int H, int W, int K,
+                          segmi_stream_t stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || K <= 0) return SEGMI_ERR_BADARG;
+    if ((K & 3) || (ld_src & 3) || (ld_dst & 3) || ld_src < 4 * K || ld_dst < K) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * H * W, K, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(depth_to_space2_kernel, g.grid, g.block, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, bias, N, H, W, K);
+    return segmi_launch_status();
+}
+
+int segmi_space_to_depth2(const float* src, int ld_src, float* dst, int ld_dst, int N, int H, int W, int K, segmi_stream_t stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || K <= 0) return SEGMI_ERR_BADARG;
+    if ((K & 3) || (ld_src & 3) || (ld_dst & 3) || ld_src < K || ld_dst < 4 * K) return SEGMI_ERR_ALIGN;
+    RowGeom g = row_geom((long)N * H * W, K, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(space_to_depth2_kernel, g.grid, g.block, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, N, H, W, K);
+    return segmi_launch_status();
+}
+
+}  // extern "C"

@@ -1,1 +1,2 @@
 from .pspnet import PSPNet  # noqa: F401
+from .unet import UNet  # noqa: F401

@@ -36,6 +36,12 @@ SIGNATURES = {
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_conv2d_variant": (i32, [PD, i32, C.c_char_p, sz]),
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "segmi_dwconv2d_fwd": (i32, [PD, vp, vp, vp, vp]),
+    "segmi_dwconv2d_dgrad": (i32, [PD, vp, vp, vp, vp]),
+    "segmi_dwconv2d_wgrad_workspace": (sz, [PD]),
+    "segmi_dwconv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
+    "segmi_depth_to_space2": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "segmi_space_to_depth2": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "segmi_colsum_workspace": (sz, [i64, i32]),
     "segmi_colsum": (i32, [vp, i32, i64, i32, vp, vp, sz, vp]),
     "segmi_bn_stats_workspace": (sz, [i64, i32]),

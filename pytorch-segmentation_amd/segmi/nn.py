@@ -14,24 +14,41 @@ from . import ops
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d (groups=1) on the implicit-GEMM MFMA kernels; the filter is held KRSC in memory
-    (torch channels_last) so no per-step re-layout is needed."""
+    """nn.Conv2d on libsegmi: dense (groups=1) -> implicit-GEMM MFMA kernels with the filter held KRSC
+    in memory (torch channels_last, no per-step re-layout); depthwise (groups == in == out channels, no
+    bias) -> the streaming depthwise kernels."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if self.groups != 1:
-            raise ValueError("segmi.nn.Conv2d is dense (groups=1); use DepthwiseConv2d for groups=C")
+        self.depthwise = self.groups != 1
+        if self.depthwise and not (self.groups == self.in_channels == self.out_channels and self.bias is None):
+            raise ValueError("segmi.nn.Conv2d supports groups=1 or bias-free depthwise (groups == in == out channels)")
         if self.padding_mode != "zeros":
             raise ValueError("segmi.nn.Conv2d supports zero padding only")
         for name in ("stride", "padding", "dilation"):
             v = getattr(self, name)
             if v[0] != v[1]:
                 raise ValueError("segmi.nn.Conv2d needs symmetric %s, got %s" % (name, (v,)))
-        if self.kernel_size[0] > 1 or self.kernel_size[1] > 1:
+        if not self.depthwise and (self.kernel_size[0] > 1 or self.kernel_size[1] > 1):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x):
+        if self.depthwise:
+            return ops.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(kernel_size=2, stride=2) — the U-Net up-convolution (models/unet.py:37)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0) or self.output_padding != (0, 0) \
+                or self.groups != 1 or self.dilation != (1, 1):
+            raise ValueError("segmi.nn.ConvTranspose2d implements kernel_size=2, stride=2, padding=0 only")
+
+    def forward(self, x, output_size=None):
+        return ops.conv_transpose2x2(x, self.weight, self.bias)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -17,7 +17,7 @@ from ._lib import ConvDesc, SegmiError, check, lib
 from .profile import span
 
 __all__ = [
-    "conv2d", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
+    "conv2d", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
     "cat", "dropout", "cross_entropy", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
@@ -246,6 +246,129 @@ class _Conv2dFn(torch.autograd.Function):
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """aten::conv2d replacement (groups == 1, symmetric stride/padding/dilation)."""
     return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+# --------------------------------------------------------------------------- depthwise convolution
+class _DepthwiseConv2dFn(torch.autograd.Function):
+    """nn.Conv2d(C, C, k, groups=C, bias=False): filter [C,1,R,S] is re-laid [R,S,C] per call (C*R*S floats)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil):
+        x = to_nhwc(x, "depthwise_conv2d")
+        _need_cuda(weight, "depthwise_conv2d")
+        N, C, H, W = x.shape
+        Cw, one, R, S = weight.shape
+        if Cw != C or one != 1:
+            raise SegmiError("depthwise_conv2d: filter %s does not match %d input channels" % (tuple(weight.shape), C))
+        if C & 3:
+            raise SegmiError("depthwise_conv2d: channel count must be a multiple of 4 (got %d)" % C)
+        st = _stream()
+        wrsc = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
+        check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), wrsc.data_ptr(), 1, C, R * S, 1, C, st), "dw filter crs->rsc")
+        P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+        y = empty_nhwc(N, C, P, Q, x.device)
+        d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
+        check(lib.segmi_dwconv2d_fwd(d, x.data_ptr(), wrsc.data_ptr(), y.data_ptr(), st), "dwconv2d_fwd")
+        ctx.save_for_backward(x, wrsc)
+        ctx.geom = (N, C, H, W, R, S, P, Q, stride, pad, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wrsc = ctx.saved_tensors
+        N, C, H, W, R, S, P, Q, stride, pad, dil = ctx.geom
+        dy = to_nhwc(dy, "depthwise_conv2d.backward")
+        st = _stream()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(N, C, H, W, x.device)
+            d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
+            check(lib.segmi_dwconv2d_dgrad(d, dy.data_ptr(), wrsc.data_ptr(), dx.data_ptr(), st), "dwconv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
+            nws = lib.segmi_dwconv2d_wgrad_workspace(d)
+            ws = workspace(nws, x.device)
+            dwr = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
+            check(lib.segmi_dwconv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, st), "dwconv2d_wgrad")
+            dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
+            check(lib.segmi_nhwc_to_nchw(dwr.data_ptr(), dw.data_ptr(), 1, C, R * S, 1, C, st), "dw filter rsc->crs")
+        return dx, dw, None, None, None
+
+
+def depthwise_conv2d(x, weight, stride=1, padding=0, dilation=1):
+    return _DepthwiseConv2dFn.apply(x, weight, int(stride), int(padding), int(dilation))
+
+
+# --------------------------------------------------------------------------- transposed convolution 2x2 / stride 2
+class _ConvTranspose2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, K, kernel_size=2, stride=2): a 1x1 convolution with 4K outputs on the MFMA
+    path (column k*4 + r*2 + s) followed by depth_to_space (+bias); backward = space_to_depth + 1x1 dgrad/wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = to_nhwc(x, "conv_transpose2x2")
+        _need_cuda(weight, "conv_transpose2x2")
+        N, C, H, W = x.shape
+        Cw, K, R, S = weight.shape
+        if Cw != C or R != 2 or S != 2:
+            raise SegmiError("conv_transpose2x2: expected weight [%d, K, 2, 2], got %s" % (C, tuple(weight.shape)))
+        if (C & 3) or (K & 3):
+            raise SegmiError("conv_transpose2x2: channel counts must be multiples of 4 (got %d -> %d)" % (C, K))
+        st = _stream()
+        K4 = 4 * K
+        w2 = torch.empty(K4 * C, device=x.device, dtype=torch.float32)          # [(k,r,s), c]
+        check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), w2.data_ptr(), 1, C, K4, 1, C, st), "convT filter")
+        t = empty_nhwc(N, K4, H, W, x.device)
+        d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(t))
+        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w2.data_ptr(), None, t.data_ptr(), 0, st), "convT conv2d_fwd")
+        y = empty_nhwc(N, K, 2 * H, 2 * W, x.device)
+        check(lib.segmi_depth_to_space2(t.data_ptr(), ld_of(t), y.data_ptr(), ld_of(y), bias.data_ptr() if bias is not None else None,
+                                        N, H, W, K, st), "depth_to_space2")
+        ctx.save_for_backward(x, w2)
+        ctx.geom = (N, C, H, W, K)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        N, C, H, W, K = ctx.geom
+        K4 = 4 * K
+        dy = to_nhwc(dy, "conv_transpose2x2.backward")
+        st, dev = _stream(), x.device
+        g = empty_nhwc(N, K4, H, W, dev)
+        check(lib.segmi_space_to_depth2(dy.data_ptr(), ld_of(dy), g.data_ptr(), ld_of(g), N, H, W, K, st), "space_to_depth2")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(C * K4, device=dev, dtype=torch.float32)
+            check(lib.segmi_filter_krsc_to_crsk(w2.data_ptr(), wt.data_ptr(), K4, 1, 1, C, K4, st), "krsc_to_crsk")
+            dx = empty_nhwc(N, C, H, W, dev)
+            d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(dx), ld_of(g))
+            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_dgrad(d, g.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "convT conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(g))
+            nws = lib.segmi_conv2d_wgrad_workspace(d)
+            ws = workspace(nws, dev) if nws else None
+            dw2 = torch.empty(K4 * C, device=dev, dtype=torch.float32)
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), g.data_ptr(), dw2.data_ptr(),
+                                             ws.data_ptr() if ws is not None else None, nws, st), "convT conv2d_wgrad")
+            dw = torch.empty((C, K, 2, 2), device=dev, dtype=torch.float32)
+            check(lib.segmi_nhwc_to_nchw(dw2.data_ptr(), dw.data_ptr(), 1, C, K4, 1, C, st), "convT filter grad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            rows = N * 4 * H * W
+            nws = lib.segmi_colsum_workspace(rows, K)
+            ws = workspace(nws, dev)
+            db = torch.empty(K, device=dev, dtype=torch.float32)
+            check(lib.segmi_colsum(dy.data_ptr(), ld_of(dy), rows, K, db.data_ptr(), ws.data_ptr(), nws, st), "colsum")
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, weight, bias=None):
+    """F.conv_transpose2d(x, weight, bias, stride=2) for 2x2 kernels (the U-Net up-convolution)."""
+    return _ConvTranspose2x2Fn.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------- batch norm (+ReLU +residual)

@@ -264,3 +264,45 @@ def test_layout_roundtrip_and_cpu_refusal(cuda):
     assert torch.equal(ops.to_nchw_contiguous(xd).cpu(), x)
     with pytest.raises(SegmiError):
         ops.conv2d(x, torch.randn(4, 5, 3, 3))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 5, 7, 4), (3, 64, 16, 16, 32), (1, 128, 9, 4, 64)])
+def test_conv_transpose2x2(cuda, case):
+    """nn.ConvTranspose2d(k=2, s=2) (models/unet.py:37) = 1x1 MFMA conv + depth_to_space."""
+    from segmi import ops
+    N, C, H, W, K = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, K, 2, 2, generator=g) * 0.2
+    b = torch.randn(K, generator=g)
+    gy = torch.randn(N, K, 2 * H, 2 * W, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    yd = ops.conv_transpose2x2(xd, wd, bd)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(gy.to(cuda))
+    for a, r, what in ((yd, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw"), (bd.grad, br.grad, "db")):
+        assert (a.detach().cpu() - r.detach()).abs().max().item() <= 1e-4 * r.detach().abs().max().item() + 1e-6, what
+
+
+@pytest.mark.parametrize("case", [(2, 8, 9, 11, 3, 1, 1, 1), (2, 64, 16, 16, 3, 2, 1, 1), (1, 128, 13, 13, 3, 1, 2, 2),
+                                  (2, 32, 10, 12, 3, 1, 4, 4), (2, 728, 8, 8, 3, 1, 1, 1), (1, 16, 7, 7, 3, 2, 2, 2)])
+def test_depthwise_conv(cuda, case):
+    """nn.Conv2d(C, C, 3, groups=C) of Xception's SeparableConv2d (models/deeplabv3_plus.py:80), stride/dilation variants."""
+    from segmi import ops
+    N, C, H, W, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad, dil, groups=C)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, wd = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    yd = ops.depthwise_conv2d(xd, wd, stride, pad, dil)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(gy.to(cuda))
+    for a, r, what in ((yd, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
+        assert (a.detach().cpu() - r.detach()).abs().max().item() <= 1e-5 * r.detach().abs().max().item() + 1e-6, what

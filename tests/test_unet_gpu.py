@@ -1,0 +1,79 @@
+"""GPU: the drop-in U-Net (cfg1: 2 classes, CrossEntropy) against golden outputs of the REAL reference and
+against the torch-CPU oracle, incl. the ragged 50x70 case (ceil-mode pooling + bilinear re-alignment)."""
+import os
+
+import pytest
+import torch
+
+from oracle import losses_ref, pspnet_ref, unet_ref
+from oracle.weights import synth_batch, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _margin_audit(dev_logits, ref_logits):
+    d = (dev_logits - ref_logits).abs().max().item()
+    top2 = ref_logits.topk(2, dim=1).values
+    mism = dev_logits.argmax(1) != ref_logits.argmax(1)
+    return d, int(mism.sum()), int((mism & ((top2[:, 0] - top2[:, 1]) > 2 * d)).sum())
+
+
+@pytest.mark.parametrize("case", ["s64", "s50x70"])
+def test_unet_step_matches_reference_golden(cuda, case):
+    import models
+    from utils.losses import CrossEntropyLoss2d
+    rec = torch.load(os.path.join(GOLD, "unet.pt"), weights_only=False)[case]
+    C = rec["num_classes"]
+    m = models.UNet(C)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in rec["manifest"]]
+    m.load_state_dict(synth_state_dict(rec["manifest"], seed=1))
+    m.to(cuda).train()
+    N, _, H, W = rec["input_shape"]
+    x, t = synth_batch(N, 3, H, W, C, seed=4321)
+    out = m(x.to(cuda))
+    loss = CrossEntropyLoss2d(ignore_index=255)(out, t.to(cuda))
+    loss.backward()
+    d, n_mis, bad = _margin_audit(out.detach().cpu(), rec["out"])
+    assert d <= 1e-3 * rec["out"].abs().max().item() and bad == 0, (d, n_mis, bad)
+    assert abs(loss.item() - rec["loss"].item()) < 1e-4
+    named = dict(m.named_parameters())
+    for k, dg in rec["grads"].items():      # batch-statistics gradients: coarse
+        g = named[k].grad.detach().cpu().reshape(-1)
+        assert abs(g.norm().item() - dg["norm"]) <= 0.1 * dg["norm"] + 1e-7, (k, g.norm().item(), dg["norm"])
+    sd_after = m.state_dict()
+    for k, v in rec["running"].items():
+        assert torch.allclose(sd_after[k].cpu().float(), v.float(), rtol=1e-4, atol=1e-5), k
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(cuda))
+    assert (ev.cpu() - rec["eval_out"]).abs().max().item() <= 1e-3 * rec["eval_out"].abs().max().item()
+
+
+def test_unet_frozen_bn_all_gradients_match_oracle(cuda):
+    """cfg1 shape (2x3x256x256, 2 classes), freeze_bn: every parameter gradient against the oracle."""
+    import models
+    from utils.losses import CrossEntropyLoss2d
+    rec = torch.load(os.path.join(GOLD, "unet.pt"), weights_only=False)["s64"]
+    C = 2
+    sd = synth_state_dict(rec["manifest"], seed=2)
+    m = models.UNet(C, freeze_bn=True)
+    m.load_state_dict(sd)
+    m.to(cuda).train()
+    m.freeze_bn()
+    x, t = synth_batch(2, 3, 256, 256, C, seed=99)
+    out = m(x.to(cuda))
+    loss = CrossEntropyLoss2d(ignore_index=255)(out, t.to(cuda))
+    loss.backward()
+    ref = pspnet_ref.clone_state(sd)
+    ro = unet_ref.unet_forward(ref, x, training=True, bn_training=False)
+    rl = losses_ref.cross_entropy(ro, t)
+    rl.backward()
+    d, n_mis, bad = _margin_audit(out.detach().cpu(), ro.detach())
+    assert d <= 1e-3 * ro.abs().max().item() and bad == 0, (d, n_mis, bad)
+    assert abs(loss.item() - rl.item()) < 1e-4
+    for k, p in m.named_parameters():
+        g, r = p.grad.detach().cpu().double(), ref[k].grad.double()
+        l2 = (g - r).norm().item() / (r.norm().item() + 1e-30)
+        mx = (g - r).abs().max().item() / (r.abs().max().item() + 1e-30)
+        assert l2 <= 1e-3 and mx <= 5e-3, (k, l2, mx)
