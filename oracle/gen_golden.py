@@ -129,6 +129,45 @@ def gen_unet(models, losses):
     torch.save(rec, os.path.join(GOLD, "unet.pt"))
 
 
+def gen_deeplab(models, losses):
+    """DeepLabV3+ train steps run by the REAL reference class (its torchvision dependency replaced by oracle/tv_resnet.py):
+    aligned Xception at output_stride 16 (cfg5 family; `block2.relu.inplace=False` is the numerically neutral workaround for
+    the reference's in-place-ReLU autograd error under torch >= 1.5) and ResNet-50 at output_stride 8 and 16
+    (cfg3 family: same code path as ResNet-101, 1/2 the layers)."""
+    crit = losses.CrossEntropyLoss2d(ignore_index=255)
+    rec = {}
+    cases = (("xception_os16", dict(backbone="xception", output_stride=16), (2, 96, 96), 7),
+             ("resnet50_os8", dict(backbone="resnet50", output_stride=8), (2, 72, 88), 5),
+             ("resnet50_os16", dict(backbone="resnet50", output_stride=16), (2, 97, 97), 19))
+    for name, kw, (N, H, W), C in cases:
+        torch.manual_seed(0)
+        model = models.DeepLab(C, pretrained=False, **kw)
+        if kw["backbone"] == "xception":
+            model.backbone.block2.relu.inplace = False
+        man = manifest_of(model.state_dict())
+        model.load_state_dict(synth_state_dict(man, seed=2))
+        x, t = synth_batch(N, 3, H, W, C, seed=555)
+        r = {"manifest": man, "num_classes": C, "input_shape": (N, 3, H, W), "kwargs": kw}
+        for regime in ("train", "frozen"):
+            model.zero_grad()
+            model.train()
+            if regime == "frozen":
+                model.freeze_bn()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+            out = model(x)
+            loss = crit(out, t)
+            loss.backward()
+            r[regime] = {"out": out.detach().clone(), "loss": loss.detach().clone(), "grads": _grad_digest(model.named_parameters())}
+            print("deeplab.pt[%s/%s]: loss %.6f, |logit| max %.3f" % (name, regime, loss.item(), out.abs().max().item()))
+        model.eval()
+        with torch.no_grad():
+            r["eval_out"] = model(x).clone()
+        rec[name] = r
+    torch.save(rec, os.path.join(GOLD, "deeplab.pt"))
+
+
 def gen_misc():
     sys.path.insert(0, reference_harness.REFERENCE)
     from utils.metrics import eval_metrics
@@ -160,12 +199,14 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     models, losses = reference_harness.load()
-    which = sys.argv[1:] or ["losses", "pspnet", "unet", "misc"]
+    which = sys.argv[1:] or ["losses", "pspnet", "unet", "deeplab", "misc"]
     if "losses" in which:
         gen_losses(losses)
     if "pspnet" in which:
         gen_pspnet(models, losses)
     if "unet" in which:
         gen_unet(models, losses)
+    if "deeplab" in which:
+        gen_deeplab(models, losses)
     if "misc" in which:
         gen_misc()

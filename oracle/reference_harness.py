@@ -47,7 +47,8 @@ def load():
     sk = _stub("skimage")
     sk.filters = _stub("skimage.filters", gaussian=None)
     tv = _stub("torchvision")
-    tv.models = _stub("torchvision.models")
+    from oracle import tv_resnet     # restated torchvision ResNet-v1.5 factories (un-vendored third-party dependency)
+    tv.models = _stub("torchvision.models", **{n: getattr(tv_resnet, n) for n in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152")})
     tv.utils = _stub("torchvision.utils", make_grid=None)
     tv.transforms = _stub("torchvision.transforms", ToTensor=_Nop, Normalize=_Nop, Compose=_Nop, Resize=_Nop, ToPILImage=_Nop)
     torch.utils.tensorboard = _stub("torch.utils.tensorboard", SummaryWriter=_Nop)

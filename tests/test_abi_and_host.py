@@ -112,3 +112,27 @@ def test_product_path_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_unet_and_deeplab_plugin_surface_matches_reference_manifests():
+    """state_dict keys/shapes of the drop-ins equal those of the REAL reference models (manifests stored by gen_golden.py)."""
+    import models
+    un = torch.load(os.path.join(GOLD, "unet.pt"), weights_only=False)["s64"]
+    m = models.UNet(un["num_classes"])
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in un["manifest"]]
+    assert list(m.get_backbone_params()) == [] and len(list(m.get_decoder_params())) == len(list(m.parameters()))
+    dl = torch.load(os.path.join(GOLD, "deeplab.pt"), weights_only=False)
+    for case, rec in dl.items():
+        m = models.DeepLab(rec["num_classes"], pretrained=False, **rec["kwargs"])
+        mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        assert mine == [(k, tuple(s)) for k, s in rec["manifest"]], case
+        nb = sum(p.numel() for p in m.get_backbone_params()) + sum(p.numel() for p in m.get_decoder_params())
+        assert nb == sum(p.numel() for p in m.parameters())
+    m = models.DeepLab(3, backbone="resnet50", pretrained=False, freeze_backbone=True, freeze_bn=True)   # NameError in the reference
+    assert all(not p.requires_grad for p in m.backbone.parameters()) and all(p.requires_grad for p in m.decoder.parameters())
+    # re-striding by module name (models/deeplabv3_plus.py:33-53)
+    m16 = models.DeepLab(3, backbone="resnet50", pretrained=False, output_stride=16)
+    assert m16.backbone.layer3[0].conv2.stride == (2, 2) and m16.backbone.layer4[0].conv2.stride == (1, 1)
+    assert m16.backbone.layer4[2].conv2.dilation == (2, 2) and m16.backbone.layer4[0].downsample[0].stride == (1, 1)
+    with pytest.raises(FileNotFoundError):
+        models.DeepLab(3, backbone="xception", pretrained=True)
