@@ -183,6 +183,24 @@ int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float
                  long ignore_index, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
                  segmi_stream_t stream);
 
+/* DiceLoss (utils/losses.py:33-50): softmax, one-hot, whole-batch 1 - (2*sum(p*y)+s)/(sum(p)+sum(y)+s).
+ * Reproduces the reference's in-place rewrite of ignored pixels to target.min() (target is mutated when
+ * ignore_index is not in range(target.min(), target.max()) and an ignored pixel exists); stats[4] =
+ * {tmin, tmax, n_ignored, remapped} are computed on the device.  loss_out[4] = {loss, sum p*y, denominator, -}. */
+size_t segmi_dice_workspace(long rows);
+int segmi_dice_fwd(const float* logits, int ld, int64_t* target, long rows, int C, long ignore_index, float smooth,
+                   int64_t* stats, float* lse, float* loss_out, void* workspace, size_t workspace_bytes,
+                   segmi_stream_t stream);
+int segmi_dice_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
+                   const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream);
+/* FocalLoss (utils/losses.py:52-65, alpha=None): mean over ALL pixels of (1-exp(-ce))^gamma * ce with
+ * ce = 0 at ignored pixels.  Workspace: segmi_ce_workspace(rows).  loss_out[2] = {loss, rows}. */
+int segmi_focal_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float gamma,
+                    float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
+                    long ignore_index, float gamma, const float* grad_out, float* dlogits, int lddl,
+                    segmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

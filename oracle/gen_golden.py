@@ -48,12 +48,25 @@ def gen_losses(losses):
     out = {}
     for name, lg, tg, ign in cases:
         rec = {"logits": lg, "target": tg, "ignore_index": ign}
-        for lname in ("CrossEntropyLoss2d", "DiceLoss", "FocalLoss", "LovaszSoftmax"):
+        for lname in ("CrossEntropyLoss2d", "DiceLoss", "FocalLoss", "LovaszSoftmax", "CE_DiceLoss"):
             x = lg.clone().requires_grad_(True)
             crit = getattr(losses, lname)(ignore_index=ign)
-            val = crit(x, tg.clone())
-            val.backward()
-            rec[lname] = {"loss": val.detach().clone(), "grad": x.grad.clone()}
+            tgt = tg.clone()
+            val = crit(x, tgt)
+            r = {"loss": val.detach().clone(), "target_after": tgt.clone()}   # DiceLoss rewrites ignored pixels in place
+            try:
+                val.backward()
+                r["grad"] = x.grad.clone()
+            except RuntimeError as e:
+                # CE_DiceLoss: the in-place target rewrite invalidates the tensor saved for CE's backward (reference bug,
+                # SURVEY.md App. E) -> the gradient of the same expression is taken with a protected copy of the target
+                assert lname == "CE_DiceLoss", (lname, e)
+                x = lg.clone().requires_grad_(True)
+                val2 = crit.cross_entropy(x, tg.clone()) + crit.dice(x, tg.clone())
+                val2.backward()
+                r["grad"] = x.grad.clone()
+                r["reference_backward_raises"] = True
+            rec[lname] = r
         out[name] = rec
     torch.save(out, os.path.join(GOLD, "losses.pt"))
     print("losses.pt:", list(out))

@@ -112,6 +112,206 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DiceLoss  utils/losses.py:33-50.  The reference first rewrites ignored pixels IN PLACE to target.min()
+// (when ignore_index is not inside range(target.min(), target.max()) and at least one pixel is ignored),
+// one-hot encodes, and reduces over the WHOLE batch:  1 - (2*sum(p*y) + s) / (sum(p) + sum(y) + s).
+// stats = {tmin, tmax, n_ignored, remap flag} are produced on the device (no host sync); the fwd kernel
+// performs the same in-place rewrite of `target` so that callers observe the reference's side effect.
+__global__ __launch_bounds__(256) void target_stats_partial_kernel(const int64_t* __restrict__ target, long rows, long ignore,
+                                                                   long long* __restrict__ part) {
+    long long mn = 0x7fffffffffffffffLL, mx = -0x7fffffffffffffffLL - 1, cnt = 0;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const long long t = target[r];
+        mn = t < mn ? t : mn; mx = t > mx ? t : mx; cnt += (t == ignore);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64), c = __shfl_xor(cnt, o, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += c;
+    }
+    __shared__ long long sm[12];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sm[wave] = mn; sm[4 + wave] = mx; sm[8 + wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = sm[w] < mn ? sm[w] : mn; mx = sm[4 + w] > mx ? sm[4 + w] : mx; }
+        part[3 * blockIdx.x] = mn < sm[0] ? mn : sm[0];
+        part[3 * blockIdx.x + 1] = mx > sm[4] ? mx : sm[4];
+        part[3 * blockIdx.x + 2] = sm[8] + sm[9] + sm[10] + sm[11];
+    }
+}
+__global__ void target_stats_final_kernel(const long long* __restrict__ part, int nparts, long ignore, int64_t* __restrict__ stats) {
+    long long mn = 0x7fffffffffffffffLL, mx = -0x7fffffffffffffffLL - 1, cnt = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        mn = part[3 * i] < mn ? part[3 * i] : mn; mx = part[3 * i + 1] > mx ? part[3 * i + 1] : mx; cnt += part[3 * i + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64), c = __shfl_xor(cnt, o, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += c;
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = mn; stats[1] = mx; stats[2] = cnt;
+        const bool in_range = ignore >= mn && ignore < mx;          // `ignore_index in range(target.min(), target.max())`
+        stats[3] = (!in_range && cnt > 0) ? 1 : 0;
+    }
+}
+
+// part[block] = {sum p_t, sum_c p_c, sum onehot}
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__ logits, int ld, int64_t* __restrict__ target, long rows,
+                                                       int C, long ignore, const int64_t* __restrict__ stats,
+                                                       float* __restrict__ lse_out, double* __restrict__ part) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const bool remap = stats[3] != 0;
+    const long tmin = stats[0];
+    const int c4n = (C + 3) >> 2;
+    float si = 0.f, sp = 0.f, st = 0.f;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        long t = target[r];
+        if (remap && t == ignore) {
+            t = tmin;
+            if (g == 0) target[r] = tmin;     // the reference's in-place rewrite (utils/losses.py:40-42)
+        }
+        const bool valid = t >= 0 && t < C;
+        float xt;
+        const float* row = logits + r * ld;
+        const float lse = pixel_lse(row, C, g, valid ? t : -1, xt);
+        float ps = 0.f;
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            ps += expf(v.x - lse);
+            if (c + 1 < C) ps += expf(v.y - lse);
+            if (c + 2 < C) ps += expf(v.z - lse);
+            if (c + 3 < C) ps += expf(v.w - lse);
+        }
+        ps = grp_sum(ps);
+        if (g == 0) {
+            lse_out[r] = lse;
+            sp += ps;
+            if (valid) { si += expf(xt - lse); st += 1.f; }
+        }
+    }
+    si = wave_sum(si); sp = wave_sum(sp); st = wave_sum(st);
+    __shared__ float sm[12];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sm[wave] = si; sm[4 + wave] = sp; sm[8 + wave] = st; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x] = (double)sm[0] + sm[1] + sm[2] + sm[3];
+        part[3 * blockIdx.x + 1] = (double)sm[4] + sm[5] + sm[6] + sm[7];
+        part[3 * blockIdx.x + 2] = (double)sm[8] + sm[9] + sm[10] + sm[11];
+    }
+}
+__global__ void dice_finalize_kernel(const double* __restrict__ part, int nparts, float smooth, float* __restrict__ out) {
+    double i = 0.0, p = 0.0, t = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 64) { i += part[3 * k]; p += part[3 * k + 1]; t += part[3 * k + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { i += __shfl_xor(i, o, 64); p += __shfl_xor(p, o, 64); t += __shfl_xor(t, o, 64); }
+    if (threadIdx.x == 0) {
+        const double den = p + t + smooth;
+        out[0] = (float)(1.0 - (2.0 * i + smooth) / den);
+        out[1] = (float)i; out[2] = (float)den; out[3] = 0.f;
+    }
+}
+// dz_c = g * (-2/den) * p_t * (delta_ct - p_c); the sum(p) term of the quotient rule vanishes (sum_c p_c == 1)
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                       const float* __restrict__ lse, long rows, int C,
+                                                       const float* __restrict__ loss_out, const float* __restrict__ grad_out,
+                                                       float* __restrict__ dl, int lddl) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const int c4n = (C + 3) >> 2;
+    const float A = -2.f * grad_out[0] / loss_out[2];
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const long t = target[r];
+        const bool valid = t >= 0 && t < C;
+        const float l = lse[r];
+        const float* row = logits + r * ld;
+        const float pt = valid ? expf(row[t] - l) : 0.f;
+        const float k = A * pt;
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            float4 d;
+            d.x = k * ((t == c ? 1.f : 0.f) - expf(v.x - l));
+            d.y = c + 1 < C ? k * ((t == c + 1 ? 1.f : 0.f) - expf(v.y - l)) : 0.f;
+            d.z = c + 2 < C ? k * ((t == c + 2 ? 1.f : 0.f) - expf(v.z - l)) : 0.f;
+            d.w = c + 3 < C ? k * ((t == c + 3 ? 1.f : 0.f) - expf(v.w - l)) : 0.f;
+            st4(dl + r * lddl + q * 4, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FocalLoss  utils/losses.py:52-65 (alpha=None): ce = per-pixel cross entropy (0 at ignored pixels),
+// loss = mean over ALL pixels of (1 - exp(-ce))^gamma * ce.
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                        long rows, int C, long ignore, float gamma, float* __restrict__ lse_out,
+                                                        double* __restrict__ part) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    float lsum = 0.f;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const long t = target[r];
+        const bool valid = t != ignore && t >= 0 && t < C;
+        float xt;
+        const float lse = pixel_lse(logits + r * ld, C, g, valid ? t : -1, xt);
+        if (g == 0) {
+            lse_out[r] = lse;
+            if (valid) {
+                const float ce = lse - xt;
+                lsum += powf(1.f - expf(-ce), gamma) * ce;
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    __shared__ float sm[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sm[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = (double)sm[0] + sm[1] + sm[2] + sm[3]; part[2 * blockIdx.x + 1] = 0.0; }
+}
+__global__ void focal_finalize_kernel(const double* __restrict__ part, int nparts, double rows, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[2 * i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) { out[0] = (float)(s / rows); out[1] = (float)rows; }
+}
+// d loss / d z_c = g/rows * [ gamma (1-pt)^(gamma-1) pt ce + (1-pt)^gamma ] * (p_c - delta_ct)
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                        const float* __restrict__ lse, long rows, int C, long ignore, float gamma,
+                                                        const float* __restrict__ grad_out, float* __restrict__ dl, int lddl) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const int c4n = (C + 3) >> 2;
+    const float gs = grad_out[0] / (float)rows;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const long t = target[r];
+        const bool valid = t != ignore && t >= 0 && t < C;
+        const float l = lse[r];
+        const float* row = logits + r * ld;
+        float k = 0.f;
+        if (valid) {
+            const float ce = l - row[t];
+            const float pt = expf(-ce), om = 1.f - pt;
+            const float dce = (gamma == 0.f ? 0.f : gamma * powf(om, gamma - 1.f) * pt * ce) + powf(om, gamma);
+            k = gs * dce;
+        }
+        for (int q = g; q < c4n; q += LPP) {
+            float4 d = zero4();
+            if (valid) {
+                const float4 v = ld4(row + q * 4);
+                const int c = q * 4;
+                d.x = k * (expf(v.x - l) - (t == c ? 1.f : 0.f));
+                d.y = c + 1 < C ? k * (expf(v.y - l) - (t == c + 1 ? 1.f : 0.f)) : 0.f;
+                d.z = c + 2 < C ? k * (expf(v.z - l) - (t == c + 2 ? 1.f : 0.f)) : 0.f;
+                d.w = c + 3 < C ? k * (expf(v.w - l) - (t == c + 3 ? 1.f : 0.f)) : 0.f;
+            }
+            st4(dl + r * lddl + q * 4, d);
+        }
+    }
+}
+
 int ce_blocks(long rows) {
     long b = (rows + 31) / 32;
     if (b < 1) b = 1;
@@ -144,6 +344,55 @@ int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float
     if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
                        ignore_index, loss_out, grad_out, dlogits, lddl);
+    return segmi_launch_status();
+}
+
+/* workspace: 3 doubles per block (dice partials) + 3 int64 per block (target statistics) */
+size_t segmi_dice_workspace(long rows) { return (size_t)ce_blocks(rows) * 3 * (sizeof(double) + sizeof(long long)); }
+
+int segmi_dice_fwd(const float* logits, int ld, int64_t* target, long rows, int C, long ignore_index, float smooth,
+                   int64_t* stats, float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits || !target || !stats || !lse || !loss_out || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_dice_workspace(rows)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_blocks(rows);
+    double* dpart = (double*)workspace;
+    long long* ipart = (long long*)(dpart + 3 * (size_t)nb);
+    hipLaunchKernelGGL(target_stats_partial_kernel, dim3(nb), dim3(256), 0, st, (const int64_t*)target, rows, ignore_index, ipart);
+    hipLaunchKernelGGL(target_stats_final_kernel, dim3(1), dim3(64), 0, st, (const long long*)ipart, nb, ignore_index, stats);
+    hipLaunchKernelGGL(dice_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, (const int64_t*)stats, lse, dpart);
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)dpart, nb, smooth, loss_out);
+    return segmi_launch_status();
+}
+
+int segmi_dice_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C, const float* loss_out,
+                   const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
+    if (!logits || !target || !lse || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
+                       loss_out, grad_out, dlogits, lddl);
+    return segmi_launch_status();
+}
+
+int segmi_focal_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float gamma,
+                    float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits || !target || !lse || !loss_out || rows <= 0 || C <= 0 || !(gamma >= 0.f)) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_ce_workspace(rows)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_blocks(rows);
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, gamma, lse, (double*)workspace);
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, (double)rows, loss_out);
+    return segmi_launch_status();
+}
+
+int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C, long ignore_index,
+                    float gamma, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
+    if (!logits || !target || !lse || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
+                       ignore_index, gamma, grad_out, dlogits, lddl);
     return segmi_launch_status();
 }
 

@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
+    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
 
@@ -705,3 +705,80 @@ class _CrossEntropyFn(torch.autograd.Function):
 def cross_entropy(logits, target, ignore_index=255):
     """nn.CrossEntropyLoss(ignore_index=..., reduction='mean') on [N,C,H,W] logits / [N,H,W] int64 target."""
     return _CrossEntropyFn.apply(logits, target, int(ignore_index))
+
+
+def _loss_inputs(logits, target, what):
+    logits = to_nhwc(logits, what)
+    N, C, H, W = logits.shape
+    if target.dtype != torch.int64 or not target.is_cuda:
+        raise SegmiError("%s: target must be an int64 CUDA tensor" % what)
+    if tuple(target.shape) != (N, H, W):
+        raise SegmiError("%s: target shape %s does not match logits %s" % (what, tuple(target.shape), tuple(logits.shape)))
+    return logits, N * H * W, C
+
+
+class _DiceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, smooth):
+        logits, rows, C = _loss_inputs(logits, target, "dice_loss")
+        if not target.is_contiguous():
+            raise SegmiError("dice_loss: target must be contiguous (it is rewritten in place like the reference does)")
+        dev, st = logits.device, _stream()
+        lse = torch.empty(rows, device=dev, dtype=torch.float32)
+        out = torch.empty(4, device=dev, dtype=torch.float32)
+        stats = torch.empty(4, device=dev, dtype=torch.int64)
+        nws = lib.segmi_dice_workspace(rows)
+        ws = workspace(nws, dev)
+        check(lib.segmi_dice_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, smooth,
+                                 stats.data_ptr(), lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "dice_fwd")
+        ctx.save_for_backward(logits, lse, out)
+        ctx.target = target     # int64, no autograd involvement; kept by reference (its rewritten content is what backward needs)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, out = ctx.saved_tensors
+        N, C, H, W = logits.shape
+        g = g.contiguous().float()
+        dl = empty_nhwc(N, C, H, W, logits.device)
+        check(lib.segmi_dice_bwd(logits.data_ptr(), ld_of(logits), ctx.target.data_ptr(), lse.data_ptr(), N * H * W, C,
+                                 out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "dice_bwd")
+        return dl, None, None, None
+
+
+def dice_loss(logits, target, ignore_index=255, smooth=1.0):
+    """DiceLoss.forward of the reference (utils/losses.py:39-50), including its in-place rewrite of ignored target pixels."""
+    return _DiceFn.apply(logits, target, int(ignore_index), float(smooth))
+
+
+class _FocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, gamma):
+        logits, rows, C = _loss_inputs(logits, target, "focal_loss")
+        target = target.contiguous()
+        dev, st = logits.device, _stream()
+        lse = torch.empty(rows, device=dev, dtype=torch.float32)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        nws = lib.segmi_ce_workspace(rows)
+        ws = workspace(nws, dev)
+        check(lib.segmi_focal_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, gamma, lse.data_ptr(),
+                                  out.data_ptr(), ws.data_ptr(), nws, st), "focal_fwd")
+        ctx.save_for_backward(logits, target, lse)
+        ctx.cfg = (ignore_index, gamma)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        ignore_index, gamma = ctx.cfg
+        N, C, H, W = logits.shape
+        g = g.contiguous().float()
+        dl = empty_nhwc(N, C, H, W, logits.device)
+        check(lib.segmi_focal_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C, ignore_index,
+                                  gamma, g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "focal_bwd")
+        return dl, None, None, None
+
+
+def focal_loss(logits, target, ignore_index=255, gamma=2.0):
+    """FocalLoss.forward of the reference (utils/losses.py:59-65), alpha=None, size_average=True."""
+    return _FocalFn.apply(logits, target, int(ignore_index), float(gamma))

@@ -1,6 +1,8 @@
 """Per-op parity of the HIP kernels (through the C ABI + autograd glue) against the plain PyTorch
 fp32 CPU operator the reference dispatches to.  Tolerances follow SURVEY.md §8(d):
 memory-bound ops rtol 1e-5 / atol 1e-6; conv |d| <= 1e-4 * max|ref|."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -306,3 +308,25 @@ def test_depthwise_conv(cuda, case):
     yd.backward(gy.to(cuda))
     for a, r, what in ((yd, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
         assert (a.detach().cpu() - r.detach()).abs().max().item() <= 1e-5 * r.detach().abs().max().item() + 1e-6, what
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("lname", ["DiceLoss", "FocalLoss", "CE_DiceLoss", "CrossEntropyLoss2d"])
+def test_losses_match_reference_golden(cuda, lname):
+    """Loss value, gradient and (Dice) the in-place target rewrite against vectors produced by the REAL reference
+    (utils/losses.py) in oracle/gen_golden.py, incl. the SURVEY App. C example, 150 classes, absent classes, no ignore."""
+    import utils.losses as L
+    gold = torch.load(os.path.join(GOLD, "losses.pt"), weights_only=False)
+    for case, rec in gold.items():
+        if lname not in rec:
+            continue
+        x = rec["logits"].to(cuda).requires_grad_(True)
+        t = rec["target"].clone().to(cuda)
+        val = getattr(L, lname)(ignore_index=rec["ignore_index"])(x, t)
+        val.backward()
+        ref = rec[lname]
+        assert torch.allclose(val.cpu(), ref["loss"], rtol=1e-5, atol=1e-6), (lname, case, val.item(), ref["loss"].item())
+        assert torch.allclose(x.grad.cpu(), ref["grad"], rtol=1e-4, atol=1e-7), (lname, case, (x.grad.cpu() - ref["grad"]).abs().max())
+        assert torch.equal(t.cpu(), ref["target_after"]), (lname, case)     # Dice rewrites ignored pixels in place, CE/Focal do not
