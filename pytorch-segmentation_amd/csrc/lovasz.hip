@@ -1,0 +1,346 @@
+// Lovasz-Softmax loss (classes='present', per_image=False), forward and backward.
+// Replaces utils/losses.py:79-89 -> utils/lovasz_losses.py:153-218 (flatten_probas, lovasz_softmax_flat) and
+// lovasz_grad :19-31 of the reference, which run softmax + C x (torch.sort over all valid pixels, 2 cumsums, dot)
+// and whose backward scatters through C `probas[:, c]` selects (O(C^2 * P) traffic on the reference).
+//
+// MI355X formulation — all HBM-bound streaming, no host synchronisation:
+//   1. lovasz_prepare   per pixel: log-sum-exp; histogram of labels (class presence, |fg_c|), number of valid pixels
+//   2. lovasz_emit      one 64-bit key per (class, pixel):  class << 33 | invalid << 32 | ~bits(|fg - p_c|)
+//                       value = pixel index | fg << 31.  Ascending key order == classes ascending, errors DESCENDING,
+//                       ignored pixels last inside their class.
+//   3. ONE device-wide radix sort of C*P pairs over 33 + log2(C) bits (rocPRIM radix_sort_pairs, double buffered) — the
+//      per-class sorts of the reference become a single bandwidth-bound pass set (8 B + 4 B per element per pass).
+//   4. lovasz_chunk_count / lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index
+//      at every rank in the same float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels),
+//      first difference, dot with the sorted errors, and scatter of d loss / d p into G[pixel, class].
+//   5. lovasz_finalize  loss = mean over present classes.
+//   backward: dz_c = g * p_c * (G_c - sum_j G_j p_j) / n_present   (softmax Jacobian; G = 0 for absent classes / ignored pixels)
+//
+// Ties: elements of one class with bit-equal errors may be ranked in any order (torch.sort is unstable too); the loss value
+// does not depend on that order, the per-pixel gradients inside a tie group do.
+#include "segmi_common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+constexpr int CHUNK = 2048;   // ranks per scan block (256 threads x 8)
+
+__global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                             long rows, int C, long ignore, float* __restrict__ lse,
+                                                             unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */) {
+    extern __shared__ unsigned hist[];   // C + 1
+    for (int i = threadIdx.x; i <= C; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const float* row = logits + r * ld;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        lse[r] = m + logf(s);
+        const long t = target[r];
+        if (t != ignore) {
+            atomicAdd(&hist[C], 1u);
+            if (t >= 0 && t < C) atomicAdd(&hist[(int)t], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= C; i += 256)
+        if (hist[i]) atomicAdd(&counts[i], hist[i]);
+}
+
+// thread per pixel, loop over classes: writes are coalesced along pixels for each class
+__global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                          const float* __restrict__ lse, long rows, int C, long ignore,
+                                                          unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const long t = target[r];
+    const bool valid = t != ignore;
+    const float l = lse[r];
+    const float* row = logits + r * ld;
+    for (int c = 0; c < C; ++c) {
+        const float p = expf(row[c] - l);
+        const bool fg = valid && t == c;
+        const float e = fabsf((fg ? 1.f : 0.f) - p);
+        const unsigned long long key = ((unsigned long long)c << 33) | ((unsigned long long)(valid ? 0 : 1) << 32) |
+                                       (unsigned long long)(~__float_as_uint(e));
+        keys[(long)c * rows + r] = key;
+        vals[(long)c * rows + r] = (unsigned)r | (fg ? 0x80000000u : 0u);
+    }
+}
+
+// chunk_fg[c][k] = number of fg elements among ranks [k*CHUNK, (k+1)*CHUNK) (ranks < n_valid only)
+__global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned* __restrict__ vals, long rows, int nchunks,
+                                                                 const unsigned* __restrict__ counts, int C,
+                                                                 unsigned* __restrict__ chunk_fg) {
+    const int c = blockIdx.y, k = blockIdx.x;
+    if (counts[c] == 0) return;                          // absent class: skipped by classes='present'
+    const long nv = counts[C];
+    const unsigned* v = vals + (long)c * rows;
+    unsigned n = 0;
+    for (int j = threadIdx.x; j < CHUNK; j += 256) {
+        const long i = (long)k * CHUNK + j;
+        if (i < nv) n += v[i] >> 31;
+    }
+    n = (unsigned)wave_sum((float)n);                    // < 2048: exact in fp32
+    __shared__ unsigned sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_fg[(long)c * nchunks + k] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// exclusive scan of chunk_fg[c][:] in place (one block per class)
+__global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_fg, int nchunks, const unsigned* __restrict__ counts) {
+    const int c = blockIdx.x;
+    if (counts[c] == 0) return;
+    unsigned* a = chunk_fg + (long)c * nchunks;
+    __shared__ unsigned sm[256];
+    unsigned carry = 0;
+    for (int base = 0; base < nchunks; base += 256) {
+        const int i = base + threadIdx.x;
+        const unsigned x = i < nchunks ? a[i] : 0u;
+        sm[threadIdx.x] = x;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned y = threadIdx.x >= o ? sm[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sm[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if (i < nchunks) a[i] = carry + sm[threadIdx.x] - x;
+        carry += sm[255];
+        __syncthreads();
+    }
+}
+
+// Jaccard gradient at every rank, dot product with the sorted errors, scatter of d loss_c / d p into G
+__global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                              long rows, int nchunks, const unsigned* __restrict__ counts, int C,
+                                                              const unsigned* __restrict__ chunk_fg, float* __restrict__ G, int ldg,
+                                                              double* __restrict__ part) {
+    const int c = blockIdx.y, k = blockIdx.x;
+    if (counts[c] == 0) return;
+    const long nv = counts[C];
+    const float gts = (float)counts[c];
+    const unsigned long long* kk = keys + (long)c * rows;
+    const unsigned* v = vals + (long)c * rows;
+    // each thread owns 8 consecutive ranks
+    const long i0 = (long)k * CHUNK + threadIdx.x * 8;
+    unsigned vv[8];
+    unsigned local = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        vv[j] = (i0 + j < nv) ? v[i0 + j] : 0u;
+        local += vv[j] >> 31;
+    }
+    // block exclusive scan of `local`
+    __shared__ unsigned sm[256];
+    sm[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned y = threadIdx.x >= o ? sm[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sm[threadIdx.x] += y;
+        __syncthreads();
+    }
+    unsigned cum = chunk_fg[(long)c * nchunks + k] + sm[threadIdx.x] - local;   // fg count strictly before rank i0
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long i = i0 + j;
+        if (i < nv) {
+            const unsigned fg = vv[j] >> 31;
+            const unsigned pix = vv[j] & 0x7fffffffu;
+            const unsigned long long key = kk[i];
+            const bool invalid = (key >> 32) & 1ull;       // an ignored pixel inside the valid range only through an e == 0 tie
+            const float e = invalid ? 0.f : __uint_as_float(~(unsigned)(key & 0xffffffffull));
+            // lovasz_grad (utils/lovasz_losses.py:19-31) in the same fp32 arithmetic
+            const float cum_prev = (float)cum, cum_now = (float)(cum + fg);
+            const float inter = gts - cum_now, uni = gts + ((float)(i + 1) - cum_now);
+            const float jac = 1.f - inter / uni;
+            float grad = jac;
+            if (i > 0) {
+                const float inter_p = gts - cum_prev, uni_p = gts + ((float)i - cum_prev);
+                grad = jac - (1.f - inter_p / uni_p);
+            }
+            dot += e * grad;
+            // d|fg - p| / dp = -sign(fg - p);  e == 0 -> 0 (torch's abs backward uses sign)
+            const float sgn = invalid || e == 0.f ? 0.f : (fg ? -1.f : 1.f);
+            G[(long)pix * ldg + c] = sgn * grad;
+            cum += fg;
+        }
+    }
+    dot = wave_sum(dot);
+    __shared__ float sd[4];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)c * nchunks + k] = (double)sd[0] + sd[1] + sd[2] + sd[3];
+}
+
+// loss_out = {mean over present classes of loss_c, n_present}
+__global__ __launch_bounds__(256) void lovasz_finalize_kernel(const double* __restrict__ part, int nchunks, const unsigned* __restrict__ counts,
+                                                              int C, long rows, float* __restrict__ loss_out) {
+    __shared__ double sm[256];
+    __shared__ int np[256];
+    double total = 0.0;
+    int present = 0;
+    const long nv = counts[C];
+    const int used = (int)((nv + CHUNK - 1) / CHUNK);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (counts[c] == 0) continue;
+        double s = 0.0;
+        for (int k = 0; k < used; ++k) s += part[(long)c * nchunks + k];
+        total += s;
+        ++present;
+    }
+    sm[threadIdx.x] = total; np[threadIdx.x] = present;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sm[threadIdx.x] += sm[threadIdx.x + o]; np[threadIdx.x] += np[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = np[0] > 0 ? (float)(sm[0] / np[0]) : 0.f;
+        loss_out[1] = (float)np[0];
+    }
+}
+
+constexpr int LPP = 8;
+__device__ __forceinline__ float grp_sum8(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+// dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j)
+__global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ lse,
+                                                         const float* __restrict__ G, int ldg, long rows, int C,
+                                                         const float* __restrict__ loss_out, const float* __restrict__ grad_out,
+                                                         float* __restrict__ dl, int lddl) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const int c4n = (C + 3) >> 2;
+    const float np = loss_out[1];
+    const float gs = np > 0.f ? grad_out[0] / np : 0.f;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const float l = lse[r];
+        const float* row = logits + r * ld;
+        const float* gr = G + r * ldg;
+        float s = 0.f;
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4), w = ld4(gr + q * 4);
+            const int c = q * 4;
+            s += w.x * expf(v.x - l);
+            if (c + 1 < C) s += w.y * expf(v.y - l);
+            if (c + 2 < C) s += w.z * expf(v.z - l);
+            if (c + 3 < C) s += w.w * expf(v.w - l);
+        }
+        s = grp_sum8(s);
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4), w = ld4(gr + q * 4);
+            const int c = q * 4;
+            float4 d;
+            d.x = gs * expf(v.x - l) * (w.x - s);
+            d.y = c + 1 < C ? gs * expf(v.y - l) * (w.y - s) : 0.f;
+            d.z = c + 2 < C ? gs * expf(v.z - l) * (w.z - s) : 0.f;
+            d.w = c + 3 < C ? gs * expf(v.w - l) * (w.w - s) : 0.f;
+            st4(dl + r * lddl + q * 4, d);
+        }
+    }
+}
+
+struct LovaszLayout {
+    size_t keys_a, keys_b, vals_a, vals_b, chunk_fg, counts, part, temp, total;
+    int nchunks, end_bit;
+    size_t temp_bytes;
+};
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool lovasz_layout(long rows, int C, LovaszLayout* L) {
+    if (rows <= 0 || C <= 0 || rows >= (1L << 31) || rows >= (1L << 24)) return false;   // fp32-exact cumsums like the reference
+    const size_t n = (size_t)rows * C;
+    L->nchunks = (int)((rows + CHUNK - 1) / CHUNK);
+    int cb = 1;
+    while ((1 << cb) < C) ++cb;
+    L->end_bit = 33 + cb;
+    size_t off = 0;
+    L->keys_a = off; off += align256(n * 8);
+    L->keys_b = off; off += align256(n * 8);
+    L->vals_a = off; off += align256(n * 4);
+    L->vals_b = off; off += align256(n * 4);
+    L->chunk_fg = off; off += align256((size_t)C * L->nchunks * 4);
+    L->counts = off; off += align256((size_t)(C + 1) * 4);
+    L->part = off; off += align256((size_t)C * L->nchunks * 8);
+    // rocPRIM temporary storage (histograms / lookback state): a host-side size query, nothing is launched
+    size_t tb = 0;
+    rocprim::double_buffer<unsigned long long> dk(nullptr, nullptr);
+    rocprim::double_buffer<unsigned> dv(nullptr, nullptr);
+    if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0u, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
+    L->temp_bytes = tb;
+    L->temp = off; off += align256(tb);
+    L->total = off;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t segmi_lovasz_workspace(long rows, int C) {
+    LovaszLayout L;
+    return lovasz_layout(rows, C, &L) ? L.total : 0;
+}
+
+int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
+                     float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits || !target || !lse || !G || !loss_out || C <= 0) return SEGMI_ERR_BADARG;
+    LovaszLayout L;
+    if (!lovasz_layout(rows, C, &L)) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    unsigned long long* ka = (unsigned long long*)(ws + L.keys_a);
+    unsigned long long* kb = (unsigned long long*)(ws + L.keys_b);
+    unsigned* va = (unsigned*)(ws + L.vals_a);
+    unsigned* vb = (unsigned*)(ws + L.vals_b);
+    unsigned* chunk_fg = (unsigned*)(ws + L.chunk_fg);
+    unsigned* counts = (unsigned*)(ws + L.counts);
+    double* part = (double*)(ws + L.part);
+
+    hipMemsetAsync(counts, 0, (size_t)(C + 1) * 4, st);
+    hipMemsetAsync(G, 0, (size_t)rows * ldg * sizeof(float), st);
+    long pb = (rows + 255) / 256;
+    if (pb > SEGMI_MAX_GRID) pb = SEGMI_MAX_GRID;
+    hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(C + 1) * 4, st, logits, ld, target, rows, C,
+                       ignore_index, lse, counts);
+    hipLaunchKernelGGL(lovasz_emit_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ld, target, (const float*)lse,
+                       rows, C, ignore_index, ka, va);
+    rocprim::double_buffer<unsigned long long> dk(ka, kb);
+    rocprim::double_buffer<unsigned> dv(va, vb);
+    size_t tb = L.temp_bytes;
+    if (rocprim::radix_sort_pairs(ws + L.temp, tb, dk, dv, (size_t)rows * C, 0u, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
+    const unsigned long long* ks = dk.current();
+    const unsigned* vs = dv.current();
+    dim3 grid((unsigned)L.nchunks, (unsigned)C);
+    hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, vs, rows, L.nchunks, (const unsigned*)counts, C, chunk_fg);
+    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
+    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid, dim3(256), 0, st, ks, vs, rows, L.nchunks, (const unsigned*)counts, C,
+                       (const unsigned*)chunk_fg, G, ldg, part);
+    hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
+    return segmi_launch_status();
+}
+
+int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float* G, int ldg, long rows, int C,
+                     const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
+    if (!logits || !lse || !G || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    long b = (rows + 31) / 32;
+    if (b > SEGMI_MAX_GRID) b = SEGMI_MAX_GRID;
+    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, logits, ld, lse, G, ldg, rows, C, loss_out,
+                       grad_out, dlogits, lddl);
+    return segmi_launch_status();
+}
+
+}  // extern "C"

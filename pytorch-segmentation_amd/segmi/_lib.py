@@ -70,6 +70,9 @@ SIGNATURES = {
     "segmi_dice_bwd": (i32, [vp, i32, vp, vp, i64, i32, vp, vp, vp, i32, vp]),
     "segmi_focal_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, sz, vp]),
     "segmi_focal_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, f32, vp, vp, i32, vp]),
+    "segmi_lovasz_workspace": (sz, [i64, i32]),
+    "segmi_lovasz_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_lovasz_bwd": (i32, [vp, i32, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),
 }
 
 

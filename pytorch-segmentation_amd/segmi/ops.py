@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
+    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
 
@@ -782,3 +782,39 @@ class _FocalFn(torch.autograd.Function):
 def focal_loss(logits, target, ignore_index=255, gamma=2.0):
     """FocalLoss.forward of the reference (utils/losses.py:59-65), alpha=None, size_average=True."""
     return _FocalFn.apply(logits, target, int(ignore_index), float(gamma))
+
+
+class _LovaszFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits, rows, C = _loss_inputs(logits, target, "lovasz_softmax")
+        target = target.contiguous()
+        N, _, H, W = logits.shape
+        dev, st = logits.device, _stream()
+        nws = lib.segmi_lovasz_workspace(rows, C)
+        if nws == 0:
+            raise SegmiError("lovasz_softmax: unsupported size (needs 0 < pixels < 2^24, got %d)" % rows)
+        ws = workspace(nws + 256, dev)
+        wp = (ws.data_ptr() + 255) & ~255
+        lse = torch.empty(rows, device=dev, dtype=torch.float32)
+        G = empty_nhwc(N, C, H, W, dev)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        check(lib.segmi_lovasz_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
+                                   G.data_ptr(), ld_of(G), out.data_ptr(), wp, nws, st), "lovasz_fwd")
+        ctx.save_for_backward(logits, lse, G, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, G, out = ctx.saved_tensors
+        N, C, H, W = logits.shape
+        g = g.contiguous().float()
+        dl = empty_nhwc(N, C, H, W, logits.device)
+        check(lib.segmi_lovasz_bwd(logits.data_ptr(), ld_of(logits), lse.data_ptr(), G.data_ptr(), ld_of(G), N * H * W, C,
+                                   out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "lovasz_bwd")
+        return dl, None, None
+
+
+def lovasz_softmax(logits, target, ignore_index=255):
+    """LovaszSoftmax.forward of the reference (softmax + lovasz_softmax(classes='present', per_image=False, ignore=...))."""
+    return _LovaszFn.apply(logits, target, int(ignore_index))

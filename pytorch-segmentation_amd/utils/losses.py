@@ -70,3 +70,19 @@ class CE_DiceLoss(nn.Module):
     def forward(self, output, target):
         ce = self.cross_entropy(output, target.clone())     # CE keeps its own copy of the un-rewritten target for backward
         return ce + self.dice(output, target)
+
+
+class LovaszSoftmax(nn.Module):
+    """Reference utils/losses.py:79-89: softmax + Lovasz-Softmax over the whole batch, classes present in the labels.
+    (`classes` is stored in an attribute the reference never reads — utils/losses.py:82 — so 'present' is what runs.)"""
+
+    def __init__(self, classes="present", per_image=False, ignore_index=255):
+        super().__init__()
+        if per_image:
+            raise NotImplementedError("per_image=True is never passed through by the reference's LovaszSoftmax.forward")
+        self.smooth = classes
+        self.per_image = per_image
+        self.ignore_index = ignore_index
+
+    def forward(self, output, target):
+        return ops.lovasz_softmax(output, target, self.ignore_index)

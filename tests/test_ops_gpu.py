@@ -313,7 +313,7 @@ def test_depthwise_conv(cuda, case):
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("lname", ["DiceLoss", "FocalLoss", "CE_DiceLoss", "CrossEntropyLoss2d"])
+@pytest.mark.parametrize("lname", ["DiceLoss", "FocalLoss", "CE_DiceLoss", "CrossEntropyLoss2d", "LovaszSoftmax"])
 def test_losses_match_reference_golden(cuda, lname):
     """Loss value, gradient and (Dice) the in-place target rewrite against vectors produced by the REAL reference
     (utils/losses.py) in oracle/gen_golden.py, incl. the SURVEY App. C example, 150 classes, absent classes, no ignore."""
@@ -330,3 +330,26 @@ def test_losses_match_reference_golden(cuda, lname):
         assert torch.allclose(val.cpu(), ref["loss"], rtol=1e-5, atol=1e-6), (lname, case, val.item(), ref["loss"].item())
         assert torch.allclose(x.grad.cpu(), ref["grad"], rtol=1e-4, atol=1e-7), (lname, case, (x.grad.cpu() - ref["grad"]).abs().max())
         assert torch.equal(t.cpu(), ref["target_after"]), (lname, case)     # Dice rewrites ignored pixels in place, CE/Focal do not
+
+
+@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255)])
+def test_lovasz_softmax_vs_oracle(cuda, case):
+    """Multi-chunk sizes (ranks span several 2048-element scan blocks), 150 classes with ignore=-1 (ADE20K style), absent
+    classes; block-constant masks so that errors are well separated (per-pixel gradients inside bit-equal tie groups are
+    arbitrary in the reference too: torch.sort is unstable)."""
+    import utils.losses as L
+    from oracle import losses_ref
+    N, C, H, W, ign = case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, C, H, W, generator=g) * 2
+    t = torch.randint(0, max(2, C - 1), (N, (H + 7) // 8, (W + 7) // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :H, :W].contiguous()
+    t[:, :2, :] = ign
+    xr = x.clone().requires_grad_(True)
+    lr = losses_ref.lovasz_softmax(xr, t, ign)
+    (lr * 0.7).backward()
+    xd = x.to(cuda).requires_grad_(True)
+    ld = L.LovaszSoftmax(ignore_index=ign)(xd, t.to(cuda))
+    (ld * 0.7).backward()
+    assert abs(ld.item() - lr.item()) <= 1e-5 * abs(lr.item()) + 1e-6, (ld.item(), lr.item())
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-8), (xd.grad.cpu() - xr.grad).abs().max()
+    assert float(xd.grad.cpu()[:, :, :2, :].abs().max()) == 0.0     # ignored pixels get no gradient
