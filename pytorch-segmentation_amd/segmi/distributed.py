@@ -203,7 +203,12 @@ class DistributedModel(torch.nn.Module):
         self.module = module
         if _is_dist() and dist.get_world_size(process_group) > 1:
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=0, group=process_group)
+                d = t.data
+                if not d.is_contiguous():
+                    # permuted-dense parameters (channels_last filters): broadcast the underlying memory run —
+                    # collectives on non-contiguous tensors may act on a temporary copy
+                    d = torch.as_strided(d, (d.numel(),), (1,), d.storage_offset())
+                dist.broadcast(d, src=0, group=process_group)
         self.reducer = GradAllReducer(module.parameters(), process_group, bucket_bytes)
 
     def forward(self, *a, **k):
