@@ -35,26 +35,31 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 
-# name -> (arch, kwargs, num_classes, per-GPU batch, H, W, train FLOPs/image (conv only))
+# name -> (arch, kwargs, num_classes, per-GPU batch, H, W, train FLOPs/image (conv only), loss, ignore_index)
+# cfg2 is the bench line (BASELINE.json configs[1]); the others are the remaining BASELINE configs, runnable with --config
+# for profiling (they are parity-test cases, not bench lines).
 CONFIGS = {
-    "cfg2": ("PSPNet", dict(backbone="resnet50", pretrained=False), 21, 8, 512, 512, 1_221_159_026_688),
-    "cfg4": ("PSPNet", dict(backbone="resnet50", pretrained=False), 19, 4, 769, 769, 2_802_443_088_000),
+    "cfg1": ("UNet", dict(), 2, 2, 256, 256, 295_937_507_328, "CrossEntropyLoss2d", 255),
+    "cfg2": ("PSPNet", dict(backbone="resnet50", pretrained=False), 21, 8, 512, 512, 1_221_159_026_688, "CrossEntropyLoss2d", 255),
+    "cfg3": ("DeepLab", dict(backbone="resnet101", pretrained=False, output_stride=16), 19, 16, 513, 513, 556_871_061_120, "CrossEntropyLoss2d", 255),
+    "cfg4": ("PSPNet", dict(backbone="resnet50", pretrained=False), 19, 4, 769, 769, 2_802_443_088_000, "CrossEntropyLoss2d", 255),
+    "cfg5": ("DeepLab", dict(backbone="xception", pretrained=False, output_stride=16), 150, 8, 512, 512, 499_565_445_120, "LovaszSoftmax", -1),
 }
 
 
 def build_model(name, device):
     import models
-    arch, kw, classes, *_ = CONFIGS[name]
+    arch, kw, classes = CONFIGS[name][:3]
     torch.manual_seed(0)
     return getattr(models, arch)(classes, **kw).to(device).train()
 
 
 def synth_batch(name, device, rank):
-    _, _, classes, n, h, w, _ = CONFIGS[name]
+    _, _, classes, n, h, w, _, _, ign = CONFIGS[name]
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(n, 3, h, w, generator=g)
     t = torch.randint(0, classes, (n, h, w), generator=g)
-    t[:, : h // 20, :] = 255
+    t[:, : h // 20, :] = ign
     return x.to(device), t.to(device)
 
 
@@ -62,7 +67,9 @@ def cpu_baseline(name, seconds_cap=40.0):
     """Oracle leg: same model family / loss / optimizer on torch-CPU, bounded sample."""
     from oracle import losses_ref, pspnet_ref
     import models
-    arch, kw, classes, n, h, w, _ = CONFIGS[name]
+    arch, kw, classes, n, h, w = CONFIGS[name][:6]
+    if arch != "PSPNet":
+        return None      # the oracle leg is wired for the bench line (cfg2 family) only
     nb = 2
     torch.manual_seed(0)
     sd = {k: v.detach().clone().contiguous() for k, v in getattr(models, arch)(classes, **kw).state_dict().items()}
@@ -120,25 +127,29 @@ def main():
 
     from segmi.distributed import DistributedModel
     from segmi.profile import KernelTimer
-    from utils.losses import CrossEntropyLoss2d
+    import utils.losses as losses_mod
 
-    arch, kw, classes, nb, h, w, flops_img = CONFIGS[args.config]
+    arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)
     if args.sync_bn and world > 1:
         from utils.sync_batchnorm import convert_model
         model = convert_model(model)
     dm = DistributedModel(model) if world > 1 else None
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
-    crit = CrossEntropyLoss2d(ignore_index=255)
+    crit = getattr(losses_mod, loss_name)(ignore_index=ign)
     x, t = synth_batch(args.config, device, rank)
+    psp = arch[:3] == "PSP"          # the reference keys the (out, aux) convention on the arch name (trainer.py:57-62)
 
     def step():
         if dm is not None:
             dm.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
-        out, aux = model(x)
-        loss = crit(out, t) + 0.4 * crit(aux, t)
+        if psp:
+            out, aux = model(x)
+            loss = crit(out, t) + 0.4 * crit(aux, t)
+        else:
+            loss = crit(model(x), t)
         loss.backward()
         if dm is not None:
             dm.finish_gradients()
@@ -198,8 +209,9 @@ def main():
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s-%s %dx3x%dx%d per GPU, %d classes, CE + 0.4*aux CE, SGD(momentum 0.9, wd 1e-4), "
-                                   "BN batch stats%s, dropout on" % (args.config, arch, kw["backbone"], nb, h, w, classes,
+            "config": {"workload": "%s: %s%s %dx3x%dx%d per GPU, %d classes, %s%s, SGD(momentum 0.9, wd 1e-4), "
+                                   "BN batch stats%s, dropout on" % (args.config, arch, "-" + kw["backbone"] if "backbone" in kw else "", nb, h, w,
+                                                                      classes, loss_name, " + 0.4*aux" if psp else "",
                                                                       " (SyncBN)" if args.sync_bn and world > 1 else ""),
                        "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -782,13 +782,23 @@ unsigned span32(long elems) {
     return (b > 0 && b < 0xFFFFFF00L) ? (unsigned)b : 0u;
 }
 
+// Small problems (fewer 128-row tiles than the 512 workgroups the chip holds) run with 64-row tiles: twice the
+// workgroups, three resident per CU (48 KB LDS each) — e.g. Xception's 728->728 1x1 on 32x32 maps: 384 -> 768 tiles.
+bool dma_half_m(int M, int Cd) {
+    const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    if (bn == 32) return false;
+    const long tiles = (long)segmi_cdiv(M, 128) * segmi_cdiv(Cd, bn);
+    return tiles < 2L * SEGMI_NUM_CU && M > 64;
+}
+
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
     const unsigned wb = span32((long)p.Cd * p.R * p.S * p.Cs);
     if (conv_dma() && sb && wb) {
-        if (p.Cd > 64) return launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
-        if (p.Cd > 32) return launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
+        const bool half_m = dma_half_m(p.M, p.Cd);
+        if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
+        if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
         return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, st);
     }
     const bool bk32 = conv_bk() == 32 && p.Cs >= 32;
@@ -942,7 +952,8 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
     const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
-        snprintf(buf, len, "conv_dma_kernel<128, %d, %s, %d>", bn, bn == 32 ? "4, 1" : "2, 2", op);
+        const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op);
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;

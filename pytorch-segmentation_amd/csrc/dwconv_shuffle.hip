@@ -206,10 +206,15 @@ DwGeom dw_geom(const segmi_conv_desc* d) {
     g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
     return g;
 }
-int dw_parts(long rows) {
-    long p = (rows + 255) / 256;
+// number of pixel-range partials of the depthwise wgrad: enough blocks to fill the chip (>= ~4 per CU together with the
+// channel tiles) while every block still reduces >= 32 pixels per row-lane
+int dw_parts(long rows, int C) {
+    RowGeom g = row_geom(rows, C, 1, 1);
+    long want = (4L * SEGMI_NUM_CU + g.grid.x - 1) / g.grid.x;
+    long cap = rows / ((long)g.ry * 8);
+    long p = want < cap ? want : cap;
     if (p < 1) p = 1;
-    if (p > 256) p = 256;
+    if (p > 1024) p = 1024;
     return (int)p;
 }
 
@@ -237,7 +242,7 @@ int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float*
 
 size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d) {
     if (!dw_ok(d)) return 0;
-    return (size_t)dw_parts((long)d->N * d->P * d->Q) * d->R * d->S * d->C * sizeof(float);
+    return (size_t)dw_parts((long)d->N * d->P * d->Q, d->C) * d->R * d->S * d->C * sizeof(float);
 }
 
 int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
@@ -246,7 +251,7 @@ int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* 
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_dwconv2d_wgrad_workspace(d)) return SEGMI_ERR_WORKSPACE;
     const long rows = (long)d->N * d->P * d->Q;
-    const int parts = dw_parts(rows);
+    const int parts = dw_parts(rows, d->C);
     RowGeom g = row_geom(rows, d->C, 1, 1);
     g.grid.y = parts;
     hipStream_t st = (hipStream_t)stream;

@@ -26,23 +26,44 @@ namespace {
 
 constexpr int CHUNK = 2048;   // ranks per scan block (256 threads x 8)
 
+// 8 lanes share a pixel (float4 channel groups, xor-shuffle reductions): coalesced 128-byte row segments
 __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                              long rows, int C, long ignore, float* __restrict__ lse,
                                                              unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */) {
     extern __shared__ unsigned hist[];   // C + 1
     for (int i = threadIdx.x; i <= C; i += 256) hist[i] = 0;
     __syncthreads();
-    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    const int g = threadIdx.x & 7;
+    const int c4n = (C + 3) >> 2;
+    for (long r = (long)blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += (long)gridDim.x * 32) {
         const float* row = logits + r * ld;
         float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+        for (int q = g; q < c4n; q += 8) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            m = fmaxf(m, v.x);
+            if (c + 1 < C) m = fmaxf(m, v.y);
+            if (c + 2 < C) m = fmaxf(m, v.z);
+            if (c + 3 < C) m = fmaxf(m, v.w);
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
-        lse[r] = m + logf(s);
-        const long t = target[r];
-        if (t != ignore) {
-            atomicAdd(&hist[C], 1u);
-            if (t >= 0 && t < C) atomicAdd(&hist[(int)t], 1u);
+        for (int q = g; q < c4n; q += 8) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            s += expf(v.x - m);
+            if (c + 1 < C) s += expf(v.y - m);
+            if (c + 2 < C) s += expf(v.z - m);
+            if (c + 3 < C) s += expf(v.w - m);
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (g == 0) {
+            lse[r] = m + logf(s);
+            const long t = target[r];
+            if (t != ignore) {
+                atomicAdd(&hist[C], 1u);
+                if (t >= 0 && t < C) atomicAdd(&hist[(int)t], 1u);
+            }
         }
     }
     __syncthreads();
@@ -311,7 +332,7 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
 
     hipMemsetAsync(counts, 0, (size_t)(C + 1) * 4, st);
     hipMemsetAsync(G, 0, (size_t)rows * ldg * sizeof(float), st);
-    long pb = (rows + 255) / 256;
+    long pb = (rows + 31) / 32;
     if (pb > SEGMI_MAX_GRID) pb = SEGMI_MAX_GRID;
     hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(C + 1) * 4, st, logits, ld, target, rows, C,
                        ignore_index, lse, counts);

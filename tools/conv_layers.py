@@ -14,20 +14,25 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from segmi.profile import KernelTimer  # noqa: E402
-from utils.losses import CrossEntropyLoss2d  # noqa: E402
+import utils.losses as losses_mod  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 dev = torch.device("cuda:0")
+arch, _, _, _, _, _, _, loss_name, ign = bench.CONFIGS[cfg]
 model = bench.build_model(cfg, dev)
 opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
-crit = CrossEntropyLoss2d(ignore_index=255)
+crit = getattr(losses_mod, loss_name)(ignore_index=ign)
 x, t = bench.synth_batch(cfg, dev, 0)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
-    out, aux = model(x)
-    (crit(out, t) + 0.4 * crit(aux, t)).backward()
+    if arch[:3] == "PSP":
+        out, aux = model(x)
+        loss = crit(out, t) + 0.4 * crit(aux, t)
+    else:
+        loss = crit(model(x), t)
+    loss.backward()
     opt.step()
 
 
