@@ -129,15 +129,18 @@ int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, floa
                    const float* scale, const float* shift, int relu, segmi_stream_t stream);
 /* sums[2*C] = {sum dy', sum dy'*xhat},  dy' = relu ? dy*[y>0] : dy  */
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C);
+/* ReLU mask source: y (the saved output) when given; y == NULL (allowed when no residual was added) recomputes
+ * fmaf(x, scale, shift) > 0 exactly as bn_apply evaluated it, saving one full read of y per pass. */
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
-                        const float* mean, const float* invstd, int relu, float* sums, void* workspace,
-                        size_t workspace_bytes, segmi_stream_t stream);
+                        const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
+                        float* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* dgamma = sums[C:2C], dbeta = sums[0:C];
  * training: dx = scale*(dy' - sums0/count - xhat*sums1/count); eval (frozen): dx = scale*dy'.
  * d_residual (optional) = dy'.  `count` is the (global) element count per channel. */
 int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
-                       const float* mean, const float* invstd, const float* scale, const float* sums, float count,
-                       int relu, int training, float* dx, int lddx, float* dres, int lddres, segmi_stream_t stream);
+                       const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
+                       float count, int relu, int training, float* dx, int lddx, float* dres, int lddres,
+                       segmi_stream_t stream);
 /* standalone ReLU (models/deeplabv3_plus.py:99-101,210) */
 int segmi_relu_fwd(const float* x, int ldx, float* y, int ldy, long rows, int C, segmi_stream_t stream);
 int segmi_relu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, long rows, int C,
@@ -160,11 +163,12 @@ int segmi_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, i
                                int OW, int accumulate, segmi_stream_t stream);
 /* aten::upsample_bilinear2d (+bwd), align_corners in {0,1}: models/pspnet.py:35-36,86,91;
  * models/deeplabv3_plus.py:291,328,361; models/unet.py:46-47.  bwd is the exact transpose in
- * gather form (deterministic, no atomics). */
+ * gather form (deterministic, no atomics), evaluated separably (width pass into the workspace, then height pass). */
 int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH, int OW,
                        int align_corners, segmi_stream_t stream);
+size_t segmi_bilinear_bwd_workspace(int N, int H, int W, int C, int OH, int OW);
 int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
-                       int align_corners, segmi_stream_t stream);
+                       int align_corners, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 
 /* ------------------------------------------------------------------ dropout (K14)
  * nn.Dropout2d(0.1) models/pspnet.py:22,68 (per (n,c) mask) and nn.Dropout models/deeplabv3_plus.py:282,318

@@ -189,17 +189,23 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                             int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ part) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 < c4n;
     float4 s0 = zero4(), s1 = zero4();
     if (cok) {
         const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
+        float4 sc = zero4(), sh = zero4();
+        if (RELU && !y) { sc = ld4(scale + c4 * 4); sh = ld4(shift + c4 * 4); }
         for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
             float4 g = ld4(dy + r * lddy + c4 * 4);
             const float4 v = ld4(x + r * ldx + c4 * 4);
             if (RELU) {
-                const float4 o = ld4(y + r * ldy + c4 * 4);
+                // ReLU mask: from the saved output, or (no residual) recomputed with the forward's own fmaf — bit-identical
+                // to what bn_apply_kernel evaluated, and one full read of y less
+                const float4 o = y ? ld4(y + r * ldy + c4 * 4)
+                                   : make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
                 g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
             }
             s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
@@ -250,13 +256,16 @@ template <bool RELU, bool TRAIN, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                            int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ scale, const float* __restrict__ sums,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ sums,
                                                            float inv_count, float* __restrict__ dx, int lddx,
                                                            float* __restrict__ dres, int lddres) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= c4n) return;
     const int Cp = c4n * 4;
     const float4 sc = ld4(scale + c4 * 4);
+    float4 sh = zero4();
+    if (RELU && !y) sh = ld4(shift + c4 * 4);
     float4 mu = zero4(), is = zero4(), k0 = zero4(), k1 = zero4();
     if (TRAIN) {
         mu = ld4(mean + c4 * 4); is = ld4(invstd + c4 * 4);
@@ -266,14 +275,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
         float4 g = ld4(dy + r * lddy + c4 * 4);
+        float4 v = zero4();
+        if (TRAIN || (RELU && !y)) v = ld4(x + r * ldx + c4 * 4);
         if (RELU) {
-            const float4 o = ld4(y + r * ldy + c4 * 4);
+            const float4 o = y ? ld4(y + r * ldy + c4 * 4)
+                               : make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         }
         if (DRES) st4(dres + r * lddres + c4 * 4, g);
         float4 d;
         if (TRAIN) {
-            const float4 v = ld4(x + r * ldx + c4 * 4);
             d.x = sc.x * (g.x - k0.x - (v.x - mu.x) * is.x * k1.x);
             d.y = sc.y * (g.y - k0.y - (v.y - mu.y) * is.y * k1.y);
             d.z = sc.z * (g.z - k0.z - (v.z - mu.z) * is.z * k1.z);
@@ -395,33 +406,35 @@ size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
 }
 
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
-                        const float* mean, const float* invstd, int relu, float* sums, void* workspace,
-                        size_t workspace_bytes, segmi_stream_t stream) {
-    if (!dy || !x || !mean || !invstd || !sums || rows <= 0 || C <= 0 || (relu && !y)) return SEGMI_ERR_BADARG;
-    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
+                        const float* mean, const float* invstd, const float* scale, const float* shift, int relu, float* sums,
+                        void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!dy || !x || !mean || !invstd || !sums || rows <= 0 || C <= 0 || (relu && !y && (!scale || !shift))) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && y && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_bn_bwd_reduce_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int parts = bwd_parts(rows);
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, (float*)workspace);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (float*)workspace);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (float*)workspace);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
 
 int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
-                       const float* mean, const float* invstd, const float* scale, const float* sums, float count,
-                       int relu, int training, float* dx, int lddx, float* dres, int lddres, segmi_stream_t stream) {
-    if (!dy || !scale || !dx || rows <= 0 || C <= 0 || (relu && !y)) return SEGMI_ERR_BADARG;
+                       const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
+                       float count, int relu, int training, float* dx, int lddx, float* dres, int lddres,
+                       segmi_stream_t stream) {
+    if (!dy || !scale || !dx || rows <= 0 || C <= 0 || (relu && !y && (!x || !shift))) return SEGMI_ERR_BADARG;
     if (training && (!x || !mean || !invstd || !sums || count <= 0.f)) return SEGMI_ERR_BADARG;
-    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(lddx, C) || (training && !ld_ok(ldx, C)) || (relu && !ld_ok(ldy, C)) ||
+    const bool need_x = training || (relu && !y);
+    if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(lddx, C) || (need_x && !ld_ok(ldx, C)) || (relu && y && !ld_ok(ldy, C)) ||
         (dres && !ld_ok(lddres, C)))
         return SEGMI_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
     const float inv = training ? 1.f / count : 0.f;
-#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, sums, inv, dx, lddx, dres, lddres)
+#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, sums, inv, dx, lddx, dres, lddres)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH_BA(false, false, false); break;

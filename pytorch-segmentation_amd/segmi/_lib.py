@@ -50,8 +50,8 @@ SIGNATURES = {
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),
-    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp, vp, sz, vp]),
-    "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp, i32, vp]),
+    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp, i32, vp]),
     "segmi_relu_fwd": (i32, [vp, i32, vp, i32, i64, i32, vp]),
     "segmi_relu_bwd": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "segmi_add": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),
@@ -60,7 +60,8 @@ SIGNATURES = {
     "segmi_adaptive_avgpool_fwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "segmi_adaptive_avgpool_bwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "segmi_bilinear_fwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "segmi_bilinear_bwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "segmi_bilinear_bwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
+    "segmi_bilinear_bwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "segmi_dropout": (i32, [vp, i32, vp, i32, i32, i64, i32, f32, i32, u64, vp]),
     "segmi_ce_workspace": (sz, [i64]),
     "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, sz, vp]),

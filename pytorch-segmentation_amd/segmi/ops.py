@@ -414,7 +414,8 @@ class _BatchNormActFn(torch.autograd.Function):
         check(lib.segmi_bn_apply(x.data_ptr(), ld_of(x), residual.data_ptr() if residual is not None else None,
                                  ld_of(residual) if residual is not None else 0, y.data_ptr(), ld_of(y), rows, C,
                                  scale.data_ptr(), shift.data_ptr(), 1 if relu else 0, st), "bn_apply")
-        ctx.save_for_backward(x, y if relu else None, coef)
+        # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs the saved output)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, coef)
         ctx.cfg = (training, relu, residual is not None, count, sync)
         return y
 
@@ -426,14 +427,14 @@ class _BatchNormActFn(torch.autograd.Function):
         rows = N * H * W
         dev, st = x.device, _stream()
         dy = to_nhwc(dy, "batch_norm.backward")
-        mean, invstd, scale = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C]
+        mean, invstd, scale, shift = coef[0:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:4 * C]
         sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
         nws = lib.segmi_bn_bwd_reduce_workspace(rows, C)
         ws = workspace(nws, dev)
-        yp, ldy = (y.data_ptr(), ld_of(y)) if relu else (None, 0)
+        yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
         check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
-                                      mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(),
-                                      ws.data_ptr(), nws, st), "bn_bwd_reduce")
+                                      mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                      1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, st), "bn_bwd_reduce")
         dgamma = sums[C:2 * C] if ctx.needs_input_grad[1] else None
         dbeta = sums[0:C] if ctx.needs_input_grad[2] else None
         gsums = sums
@@ -447,7 +448,7 @@ class _BatchNormActFn(torch.autograd.Function):
             if want_res and relu:
                 dres = empty_nhwc(N, C, H, W, dev)
             check(lib.segmi_bn_bwd_apply(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
-                                         mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), gsums.data_ptr(),
+                                         mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gsums.data_ptr(),
                                          count, 1 if relu else 0, 1 if training else 0, dx.data_ptr(), ld_of(dx),
                                          dres.data_ptr() if dres is not None else None,
                                          ld_of(dres) if dres is not None else 0, st), "bn_bwd_apply")
@@ -592,8 +593,10 @@ class _BilinearFn(torch.autograd.Function):
         N, C, H, W, OH, OW, ac = ctx.geom
         dy = to_nhwc(dy, "interpolate.backward")
         dx = empty_nhwc(N, C, H, W, dy.device)
+        nws = lib.segmi_bilinear_bwd_workspace(N, H, W, C, OH, OW)
+        ws = workspace(nws, dy.device)
         check(lib.segmi_bilinear_bwd(dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx), N, H, W, C, OH, OW,
-                                     1 if ac else 0, _stream()), "bilinear_bwd")
+                                     1 if ac else 0, ws.data_ptr(), nws, _stream()), "bilinear_bwd")
         return dx, None, None, None
 
 
