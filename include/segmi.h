@@ -216,6 +216,12 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
 int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float* G, int ldg, long rows, int C,
                      const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream);
 
+/* eval_metrics (utils/metrics.py:42-67; trainer.py:84-86,128-129): argmax (first maximal class) + pixel-accuracy counts +
+ * per-class intersection / prediction / label areas, ACCUMULATED into acc[2 + 3*C] int64 =
+ * {correct, labeled, inter[C], pred_area[C], label_area[C]} (union = pred_area + label_area - inter).  The caller zeroes acc
+ * at the start of an epoch and reads it when it wants numbers: no per-iteration host synchronisation. */
+int segmi_seg_metrics(const float* logits, int ld, const int64_t* target, long rows, int C, int64_t* acc, segmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

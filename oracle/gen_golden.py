@@ -181,6 +181,51 @@ def gen_deeplab(models, losses):
     torch.save(rec, os.path.join(GOLD, "deeplab.pt"))
 
 
+def gen_trainer(models, losses):
+    """BASELINE configs[0]: the REAL reference Trainer (trainer.py + base/base_trainer.py) run on CPU through its config.json
+    path for one epoch of 4 iterations of UNet / 2 classes / batch 2 / 256x256 on the synthetic loader
+    (pytorch-segmentation_amd/dataloaders/synth.py, loaded by file path: batches are a pure function of (seed, index)).
+    Records the per-iteration losses, the epoch's metrics and digests of the trained weights."""
+    import importlib.util
+    import json
+    import tempfile
+    sys.path.insert(0, reference_harness.REFERENCE)
+    from trainer import Trainer
+    from utils import Logger          # train.main passes one (train.py:19); without it base_trainer.py:118 hits an unbound `log`
+    spec = importlib.util.spec_from_file_location("segmi_synth", os.path.join(ROOT, "pytorch-segmentation_amd", "dataloaders", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    config = json.load(open(os.path.join(ROOT, "pytorch-segmentation_amd", "config.json")))
+    tmp = tempfile.mkdtemp()
+    config["trainer"].update(epochs=1, val=False, save_dir=tmp, log_dir=tmp, save_period=100)
+    loader = synth.Synth(**config["train_loader"]["args"])
+    torch.manual_seed(0)
+    model = models.UNet(loader.dataset.num_classes, **config["arch"]["args"])
+    man = manifest_of(model.state_dict())
+    model.load_state_dict(synth_state_dict(man, seed=11))
+    seen = []
+
+    class Recording(losses.CrossEntropyLoss2d):
+        def forward(self, output, target):
+            v = super().forward(output, target)
+            seen.append(v.item())
+            return v
+
+    trainer = Trainer(model=model, loss=Recording(ignore_index=config["ignore_index"]), resume=None, config=config,
+                      train_loader=loader, val_loader=None, train_logger=Logger())
+    trainer.train()
+    log = trainer._get_seg_metrics()
+    sd = trainer.model.state_dict()
+    rec = {"config": config, "manifest": man, "losses": seen, "pixel_accuracy": float(log["Pixel_Accuracy"]), "mean_iou": float(log["Mean_IoU"]),
+           "total_correct": float(trainer.total_correct), "total_label": float(trainer.total_label),
+           "total_inter": torch.as_tensor(trainer.total_inter), "total_union": torch.as_tensor(trainer.total_union),
+           "lrs": [g["lr"] for g in trainer.optimizer.param_groups],
+           "weights": {k: {"norm": v.float().norm().item(), "head": v.flatten()[:8].clone()} for k, v in sd.items()
+                       if k.endswith(("start_conv.0.weight", "middle_conv.3.weight", "up4.up.weight", "final_conv.bias", "down2.down_conv.1.running_var"))}}
+    torch.save(rec, os.path.join(GOLD, "trainer_unet.pt"))
+    print("trainer_unet.pt: losses", ["%.5f" % v for v in seen], "acc", rec["pixel_accuracy"], "mIoU", rec["mean_iou"], "keys", list(rec["weights"]))
+
+
 def gen_misc():
     sys.path.insert(0, reference_harness.REFERENCE)
     from utils.metrics import eval_metrics
@@ -212,7 +257,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     models, losses = reference_harness.load()
-    which = sys.argv[1:] or ["losses", "pspnet", "unet", "deeplab", "misc"]
+    which = sys.argv[1:] or ["losses", "pspnet", "unet", "deeplab", "trainer", "misc"]
     if "losses" in which:
         gen_losses(losses)
     if "pspnet" in which:
@@ -221,5 +266,7 @@ if __name__ == "__main__":
         gen_unet(models, losses)
     if "deeplab" in which:
         gen_deeplab(models, losses)
+    if "trainer" in which:
+        gen_trainer(models, losses)
     if "misc" in which:
         gen_misc()

@@ -1,1 +1,2 @@
 from .base_model import BaseModel  # noqa: F401
+from .base_trainer import BaseTrainer  # noqa: F401

@@ -312,6 +312,54 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// eval_metrics  utils/metrics.py:42-67 (torch.max over classes -> first maximal index, +1 shift, labeled = 1 <= target+1 <= C,
+// pixel accuracy counts and torch.histc intersection / prediction / label areas), fused into one pass over the logits and
+// accumulated on the device as integers: acc = {correct, labeled, inter[C], pred_area[C], label_area[C]} (int64, exact,
+// order independent).  Removes the per-iteration host synchronisations of trainer.py:84-86.
+__global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                          long rows, int C, unsigned long long* __restrict__ acc) {
+    extern __shared__ unsigned hist[];   // 2 + 3*C
+    const int nh = 2 + 3 * C;
+    for (int i = threadIdx.x; i < nh; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const int c4n = (C + 3) >> 2;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const float* row = logits + r * ld;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            if (v.x > best) { best = v.x; bi = c; }
+            if (c + 1 < C && v.y > best) { best = v.y; bi = c + 1; }
+            if (c + 2 < C && v.z > best) { best = v.z; bi = c + 2; }
+            if (c + 3 < C && v.w > best) { best = v.w; bi = c + 3; }
+        }
+#pragma unroll
+        for (int o = 1; o < LPP; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (g == 0) {
+            const long t = target[r] + 1;               // labels shifted to 1..C like the reference
+            const int pred = bi + 1;
+            if (t > 0 && t <= C) {
+                atomicAdd(&hist[1], 1u);
+                atomicAdd(&hist[2 + C + (pred - 1)], 1u);
+                atomicAdd(&hist[2 + 2 * C + (int)(t - 1)], 1u);
+                if (pred == t) { atomicAdd(&hist[0], 1u); atomicAdd(&hist[2 + (pred - 1)], 1u); }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh; i += 256)
+        if (hist[i]) atomicAdd(&acc[i], (unsigned long long)hist[i]);
+}
+
 int ce_blocks(long rows) {
     long b = (rows + 31) / 32;
     if (b < 1) b = 1;
@@ -393,6 +441,14 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
     if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
                        ignore_index, gamma, grad_out, dlogits, lddl);
+    return segmi_launch_status();
+}
+
+int segmi_seg_metrics(const float* logits, int ld, const int64_t* target, long rows, int C, int64_t* acc, segmi_stream_t stream) {
+    if (!logits || !target || !acc || rows <= 0 || C <= 0 || C > 4000) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    hipLaunchKernelGGL(seg_metrics_kernel, dim3(ce_blocks(rows)), dim3(256), (size_t)(2 + 3 * C) * sizeof(unsigned), (hipStream_t)stream,
+                       logits, ld, target, rows, C, (unsigned long long*)acc);
     return segmi_launch_status();
 }
 

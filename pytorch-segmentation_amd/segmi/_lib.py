@@ -74,6 +74,7 @@ SIGNATURES = {
     "segmi_lovasz_workspace": (sz, [i64, i32]),
     "segmi_lovasz_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, i32, vp, vp, sz, vp]),
     "segmi_lovasz_bwd": (i32, [vp, i32, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),
+    "segmi_seg_metrics": (i32, [vp, i32, vp, i64, i32, vp, vp]),
 }
 
 

@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
+    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
 
@@ -821,3 +821,14 @@ class _LovaszFn(torch.autograd.Function):
 def lovasz_softmax(logits, target, ignore_index=255):
     """LovaszSoftmax.forward of the reference (softmax + lovasz_softmax(classes='present', per_image=False, ignore=...))."""
     return _LovaszFn.apply(logits, target, int(ignore_index))
+
+
+def seg_metrics_accumulate(logits, target, acc):
+    """Fused argmax + accuracy / IoU counting (utils/metrics.py:59-67 of the reference) accumulated into the int64 device
+    tensor `acc` of 2 + 3*C entries {correct, labeled, inter[C], pred_area[C], label_area[C]}; no host synchronisation."""
+    logits, rows, C = _loss_inputs(logits.detach(), target, "seg_metrics")
+    if acc.dtype != torch.int64 or not acc.is_cuda or acc.numel() != 2 + 3 * C or not acc.is_contiguous():
+        raise SegmiError("seg_metrics: acc must be a contiguous int64 CUDA tensor of %d entries" % (2 + 3 * C))
+    check(lib.segmi_seg_metrics(logits.data_ptr(), ld_of(logits), target.contiguous().data_ptr(), rows, C, acc.data_ptr(), _stream()),
+          "seg_metrics")
+    return acc

@@ -1,0 +1,119 @@
+"""Trainer — the hot loop (reference: trainer.py:12-193), re-hosted on the segmi path.
+
+Per iteration, as trainer.py:49-72: lr_scheduler.step(epoch-1) -> zero_grad -> model(data) -> loss (+0.4*aux for PSP*, keyed on
+the arch name like the reference) -> backward -> [gradient all-reduce finishes] -> optimizer.step.
+What changed: the reference synchronises with the host twice per iteration (`loss.item()` :72, `eval_metrics` -> numpy :84-86);
+here the loss sum and the accuracy / IoU counters stay on the device (segmi_seg_metrics) and are read every `log_step`
+iterations and at the end of the epoch.  `iteration_losses` keeps the per-iteration loss tensors of the last epoch for tests.
+"""
+import time
+
+import numpy as np
+import torch
+
+from base import BaseTrainer
+from utils.metrics import AverageMeter, SegMetrics
+
+
+class Trainer(BaseTrainer):
+    def __init__(self, model, loss, resume, config, train_loader, val_loader=None, train_logger=None, prefetch=True):
+        super().__init__(model, loss, resume, config, train_loader, val_loader, train_logger)
+        self.wrt_mode, self.wrt_step = "train_", 0
+        self.log_step = config["trainer"].get("log_per_iter", int(np.sqrt(self.train_loader.batch_size)))
+        if config["trainer"].get("log_per_iter"):
+            self.log_step = int(self.log_step / self.train_loader.batch_size) + 1
+        self.log_step = max(1, self.log_step)
+        self.num_classes = self.train_loader.dataset.num_classes
+        self.metrics = SegMetrics(self.num_classes, self.device)
+        self.psp = self.config["arch"]["type"][:3] == "PSP"
+        self.iteration_losses = []
+
+    def _forward_loss(self, data, target):
+        output = self.model(data)
+        if self.psp and isinstance(output, tuple):
+            assert output[0].size()[2:] == target.size()[1:]
+            assert output[0].size()[1] == self.num_classes
+            loss = self.loss(output[0], target) + self.loss(output[1], target) * 0.4
+            output = output[0]
+        else:
+            assert output.size()[2:] == target.size()[1:]
+            assert output.size()[1] == self.num_classes
+            loss = self.loss(output, target)
+        return output, loss
+
+    def _train_epoch(self, epoch):
+        self.model.train()
+        if self.config["arch"]["args"].get("freeze_bn"):
+            self.model.module.freeze_bn()
+        self.wrt_mode = "train"
+        self._reset_metrics()
+        self.iteration_losses = []
+        loss_sum = torch.zeros((), device=self.device)
+        tic = time.time()
+        n_iter = 0
+        for batch_idx, (data, target) in enumerate(self.train_loader):
+            self.data_time.update(time.time() - tic)
+            data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
+            self.lr_scheduler.step(epoch=epoch - 1)
+
+            self.model.zero_grad()
+            output, loss = self._forward_loss(data, target)
+            loss.backward()
+            self.model.finish_gradients()
+            self.optimizer.step()
+
+            loss_d = loss.detach()
+            loss_sum += loss_d
+            self.iteration_losses.append(loss_d)
+            self.metrics.update(output, target)           # device-side accumulation, no sync
+            n_iter += 1
+            self.batch_time.update(time.time() - tic)
+            tic = time.time()
+
+            if batch_idx % self.log_step == 0 and self.rank == 0:
+                self.wrt_step = (epoch - 1) * len(self.train_loader) + batch_idx
+                s = self.metrics.summary()                # the only host synchronisation of the loop
+                avg = float(loss_sum) / n_iter
+                self.writer.add_scalar("%s/loss" % self.wrt_mode, float(loss_d), self.wrt_step)
+                self.logger.info("TRAIN (%d) [%d/%d] | Loss: %.3f | Acc %.2f mIoU %.2f | B %.2f D %.2f |" % (
+                    epoch, batch_idx, len(self.train_loader), avg, s["Pixel_Accuracy"], s["Mean_IoU"],
+                    self.batch_time.average, self.data_time.average))
+
+        self.total_loss.update(float(loss_sum) / max(n_iter, 1), n_iter)
+        seg_metrics = self.metrics.summary()
+        for k, v in list(seg_metrics.items())[:-1]:
+            self.writer.add_scalar("%s/%s" % (self.wrt_mode, k), v, self.wrt_step)
+        for i, g in enumerate(self.optimizer.param_groups):
+            self.writer.add_scalar("%s/Learning_rate_%d" % (self.wrt_mode, i), g["lr"], self.wrt_step)
+        return {"loss": self.total_loss.average, **seg_metrics}
+
+    def _valid_epoch(self, epoch):
+        if self.val_loader is None:
+            self.logger.warning("Not data loader was passed for the validation step, No validation is performed !")
+            return {}
+        self.logger.info("\n###### EVALUATION ######")
+        self.model.eval()
+        self.wrt_mode = "val"
+        self._reset_metrics()
+        loss_sum = torch.zeros((), device=self.device)
+        n_iter = 0
+        with torch.no_grad():
+            for data, target in self.val_loader:
+                data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
+                output = self.model(data)
+                loss_sum += self.loss(output, target)
+                self.metrics.update(output, target)
+                n_iter += 1
+        self.total_loss.update(float(loss_sum) / max(n_iter, 1), n_iter)
+        self.wrt_step = epoch * len(self.val_loader)
+        self.writer.add_scalar("%s/loss" % self.wrt_mode, self.total_loss.average, self.wrt_step)
+        seg_metrics = self.metrics.summary()
+        for k, v in list(seg_metrics.items())[:-1]:
+            self.writer.add_scalar("%s/%s" % (self.wrt_mode, k), v, self.wrt_step)
+        return {"val_loss": self.total_loss.average, **seg_metrics}
+
+    def _reset_metrics(self):
+        self.batch_time = AverageMeter()
+        self.data_time = AverageMeter()
+        self.total_loss = AverageMeter()
+        self.metrics.reset()
