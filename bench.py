@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
     ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
+    ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,8 +122,10 @@ def main():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from segmi.distributed import DistributedModel
@@ -131,10 +134,10 @@ def main():
 
     arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)
-    if args.sync_bn and world > 1:
+    if args.sync_bn and ddp:
         from utils.sync_batchnorm import convert_model
         model = convert_model(model)
-    dm = DistributedModel(model) if world > 1 else None
+    dm = DistributedModel(model, always_reduce=args.force_ddp) if ddp else None
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     crit = getattr(losses_mod, loss_name)(ignore_index=ign)
     x, t = synth_batch(args.config, device, rank)
@@ -157,7 +160,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +172,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -196,7 +199,7 @@ def main():
                 "step_frac": round(value / world * flops_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                  "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
-    if world > 1:
+    if ddp:
         dist.barrier()
 
     cpu = None
@@ -212,12 +215,12 @@ def main():
             "config": {"workload": "%s: %s%s %dx3x%dx%d per GPU, %d classes, %s%s, SGD(momentum 0.9, wd 1e-4), "
                                    "BN batch stats%s, dropout on" % (args.config, arch, "-" + kw["backbone"] if "backbone" in kw else "", nb, h, w,
                                                                       classes, loss_name, " + 0.4*aux" if psp else "",
-                                                                      " (SyncBN)" if args.sync_bn and world > 1 else ""),
+                                                                      " (SyncBN)" if args.sync_bn and ddp else ""),
                        "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

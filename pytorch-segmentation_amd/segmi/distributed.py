@@ -34,10 +34,12 @@ class GradAllReducer:
     Usage per iteration:  zero_grad() -> forward -> loss.backward() -> finish() -> optimizer.step().
     """
 
-    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True):
+    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True, always_reduce=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if _is_dist() else 1
         self.average = average
+        # always_reduce: issue the collectives even in a single-rank group (exercises the RCCL call path on a 1-GPU box)
+        self.collective = self.world > 1 or (always_reduce and _is_dist())
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradAllReducer: no trainable parameters")
@@ -97,7 +99,7 @@ class GradAllReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world == 1:
+        if not self.collective:
             return
         op = dist.ReduceOp.SUM
         if self.side is not None:
@@ -198,7 +200,7 @@ class DistributedModel(torch.nn.Module):
     base/base_trainer.py:47-51, trainer.py:41-43) plus the gradient reducer.  Parameters are
     broadcast from rank 0 at construction so all replicas start identical."""
 
-    def __init__(self, module, process_group=None, bucket_bytes=64 << 20):
+    def __init__(self, module, process_group=None, bucket_bytes=64 << 20, always_reduce=False):
         super().__init__()
         self.module = module
         if _is_dist() and dist.get_world_size(process_group) > 1:
@@ -209,7 +211,7 @@ class DistributedModel(torch.nn.Module):
                     # collectives on non-contiguous tensors may act on a temporary copy
                     d = torch.as_strided(d, (d.numel(),), (1,), d.storage_offset())
                 dist.broadcast(d, src=0, group=process_group)
-        self.reducer = GradAllReducer(module.parameters(), process_group, bucket_bytes)
+        self.reducer = GradAllReducer(module.parameters(), process_group, bucket_bytes, always_reduce=always_reduce)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

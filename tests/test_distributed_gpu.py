@@ -177,3 +177,48 @@ def test_two_rank_syncbn_step_equals_global_batch_step(cuda):
         errs.append((g0.double() - gref.double()).norm().item() / (gref.double().norm().item() + 1e-30))
     errs.sort()
     assert errs[len(errs) // 2] <= 0.1 and errs[-1] <= 0.3, (errs[len(errs) // 2], errs[-1])
+
+
+def _nccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "pytorch-segmentation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # backend "nccl" IS RCCL on ROCm
+    try:
+        from segmi.distributed import GradAllReducer, SyncBNContext
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 10)).to(dev)
+        red = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, always_reduce=True)
+        x = torch.randn(32, 64, device=dev)
+        red.zero_grad()
+        net(x).square().mean().backward()
+        red.finish()
+        got = {k: p.grad.clone() for k, p in net.named_parameters()}
+        for p in net.parameters():
+            p.grad = None
+        red.remove()
+        net(x).square().mean().backward()
+        ok = all(torch.allclose(got[k], p.grad, rtol=1e-6, atol=1e-8) for k, p in net.named_parameters())
+        ctx = SyncBNContext()
+        part = torch.arange(12.0, device=dev)
+        parts, n, cnt = ctx.gather_stats(part, 7)
+        dist.barrier()
+        t = torch.ones(3, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        ret[rank] = {"ok": ok, "nb": len(red.buckets), "gather": (n, cnt)}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_call_path_single_rank(cuda):
+    """The exact torch.distributed calls bench.py / DistributedModel make at N > 1 (init with device_id, async all_reduce with
+    ReduceOp.AVG on the side stream, wait, barrier, MAX reduce), executed over RCCL in a single-rank group on the one GPU of
+    the test box: averaged gradients of a 1-rank group equal the local gradients."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0]["ok"] and ret[0]["nb"] >= 2 and ret[0]["gather"] == (1, 7.0)
