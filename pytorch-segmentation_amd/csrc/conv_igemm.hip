@@ -242,7 +242,10 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voffset, unsig
                  :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
+// keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
+// an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
 __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -286,6 +289,22 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         a_ok[i] = ok;
     }
     const int RS = p.R * p.S;
+    int a_base[A_IT];
+    unsigned a_mask[A_IT];
+    if (FAST) {
+        const int sgn = MODE == MODE_FPROP ? 1 : -1;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            a_base[i] = (a_pix[i] + a_bh[i] * p.Ws + a_bw[i]) * p.lds;
+            unsigned mk = 0;
+            for (int t2 = 0; t2 < RS; ++t2) {
+                const int r2 = t2 / p.S, s2 = t2 - r2 * p.S;
+                const int hs = a_bh[i] + sgn * r2 * p.dil, ws = a_bw[i] + sgn * s2 * p.dil;
+                if (a_ok[i] && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws) mk |= 1u << t2;
+            }
+            a_mask[i] = mk;
+        }
+    }
     unsigned b_off[B_IT];                                // element offset of the filter row, OOB if k >= Cd
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -297,6 +316,15 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BM * BK * 4;   // LDS byte addresses (wave's 8-row slice)
         const int c = c0 + kg * 4;
         const bool cok = c < p.Cs;
+        if (FAST) {
+            const int tap = r * p.S + s;
+            const int tap_off = (MODE == MODE_FPROP ? 1 : -1) * (r * p.dil * p.Ws + s * p.dil) * p.lds + c;   // wave-uniform + lane's channel
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = cok && ((a_mask[i] >> tap) & 1u);
+                dma16(src_rsrc, ok ? (unsigned)(a_base[i] + tap_off) * 4u : OOB, As + i * (32 * BK * 4));
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             int hs, ws;
@@ -542,7 +570,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // unpadded [BKP][BM] layout is already conflict-free for the per-lane ds_read_b32 operand reads
 // (lanes read consecutive channels of one pixel).  Out-of-image taps / rows past the split's pixel range /
 // channels past K (C) get an out-of-range offset and arrive as zeros.
-template <int BM, int BN>
+// ROWQ (Q % 32 == 0): a 32-pixel chunk never straddles an output row, so (n, p, q0) of the chunk are wave-uniform scalars
+// advanced with SALU, and a lane only adds its fixed in-chunk column: ~20 VALU per chunk instead of ~130 (the m -> (n,p,q)
+// bookkeeping per lane and per load is what kept the generic path's waves off the matrix pipe: 125 vs 136 TF/s of fprop).
+template <int BM, int BN, bool ROWQ>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int BKP = 32, WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -594,8 +625,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     }
     const int tap_h = -p.pad + r * p.dil, tap_w = -p.pad + s * p.dil;
 
+    // ROWQ state: chunk-uniform scalars + per-lane constants
+    int cn = 0, cp = 0, cq = 0;
+    unsigned a_const[A_IT];
+    int b_ws[B_IT];
+    if (ROWQ) {
+        const int mm = mbeg < p.M ? mbeg : 0;
+        cn = __builtin_amdgcn_readfirstlane(mm / PQ);
+        const int rem = mm - cn * PQ;
+        cp = __builtin_amdgcn_readfirstlane(rem / p.Q);
+        cq = __builtin_amdgcn_readfirstlane(rem - cp * p.Q);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            a_const[i] = a_cok ? ((unsigned)(((i * 4 + wave) * A_RPI + a_rl) * p.ldy + k0 + a_col)) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_ws[i] = ((i * 4 + wave) * B_RPI + b_rl) * p.stride + tap_w;
+    }
+
     auto issue = [&](int mb, int buf) {
         const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BKP * BM * 4;
+        if (ROWQ) {
+            const unsigned a_chunk = (unsigned)mb * (unsigned)p.ldy * 4u;                       // scalar
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                dma16(dy_rsrc, a_const[i] == OOB ? OOB : a_chunk + a_const[i], As + (i * 4 + wave) * A_RPI * (BM * 4));
+            const int hs = cp * p.stride + tap_h;                                               // scalar
+            const bool hok = (unsigned)hs < (unsigned)p.H;
+            const int rowbase = ((cn * p.H + hs) * p.W) * p.ldx + c0 + b_col;
+            const int wq = cq * p.stride;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int ws = wq + b_ws[i];
+                const bool ok = hok && b_cok && (unsigned)ws < (unsigned)p.W;
+                dma16(x_rsrc, ok ? (unsigned)(rowbase + ws * p.ldx) * 4u : OOB, Bs + (i * 4 + wave) * B_RPI * (BN * 4));
+            }
+            cq += BKP;
+            if (cq >= p.Q) { cq = 0; if (++cp == p.P) { cp = 0; ++cn; } }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int row0 = (i * 4 + wave) * A_RPI;
@@ -763,8 +830,9 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     p.tiles_m = segmi_cdiv(p.M, BM);
     p.tiles_n = segmi_cdiv(p.Cd, BN);
     const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-    auto kern = conv_dma_kernel<BM, BN, WM, WN, MODE>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    const bool fast = p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
+    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
     return segmi_launch_status();
 }
 
@@ -829,21 +897,34 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     const long tiles = (long)pl.tiles_k * pl.tiles_c * d->R * d->S;
     const long M = (long)d->N * d->P * d->Q;
     const long chunks = (M + WG_BKP - 1) / WG_BKP;
-    // Split the pixel reduction so that the grid fills whole "rounds" of resident workgroups: two
-    // 256-thread workgroups (64 KB LDS each) live on a CU, i.e. 512 slots.  1152 tiles unsplit are 2.25
-    // rounds (75 % efficient: measured 100 vs 127 TF/s for the PSP bottleneck); x4 gives exactly 9.
+    // Split the pixel reduction until the grid is >= 8 "rounds" of the 512 resident workgroups (two 64 KB-LDS workgroups
+    // per CU): with that many workgroups the dispatcher's dynamic scheduling hides the round quantisation (the PSP
+    // bottleneck's 1152 tiles unsplit are 2.25 rounds: 110 TF/s; x4: 125 TF/s), and the partial-sum traffic
+    // (nsplit * |dW| * 8 B) stays ~1 % of the kernel.
     const long slots = 2L * SEGMI_NUM_CU;
     long max_split = chunks / 8 > 0 ? chunks / 8 : 1;            // >= 256 pixels per split
     if (max_split > 512) max_split = 512;
-    long ns = 1;
+    const long ns_rounds = (8 * slots + tiles - 1) / tiles;       // >= 8 rounds of resident workgroups
+    const long ns_fill = (slots + tiles - 1) / tiles;             // at least one workgroup per slot
+    const long ns_long = chunks / 64 > 0 ? chunks / 64 : 1;       // but keep >= 64 chunks (2048 pixels) of K loop per workgroup
+    long lo = ns_fill > ns_long ? ns_fill : ns_long;              //   unless filling the chip needs more
+    long hi = ns_rounds < max_split ? ns_rounds : max_split;
+    if (lo > hi) lo = hi;
+    if (lo < 1) lo = 1;
+    // below 8 rounds the round quantisation is real (576 workgroups on 512 slots run as two rounds): take the first split in
+    // [lo, hi] whose last round is >= 90 % full, else the fullest
+    long ns = lo;
     double best = -1.0;
-    for (long c = 1; c <= max_split; ++c) {
+    for (long c = lo; c <= hi; ++c) {
         const long wg = tiles * c;
-        if (wg < slots && c < max_split) continue;               // fill the chip first
         const long rounds = (wg + slots - 1) / slots;
-        const double eff = (double)wg / (double)(rounds * slots);
+        const double eff = rounds >= 8 ? 1.0 : (double)wg / (double)(rounds * slots);
         if (eff > best + 1e-9) { best = eff; ns = c; }
-        if (eff >= 0.92 || rounds >= 12) break;                  // good enough: keep the split (and its traffic) small
+        if (eff >= 0.9) break;
+    }
+    if (const char* e = getenv("SEGMI_WGRAD_SPLIT")) {           // tuning hook
+        const long f = atol(e);
+        if (f >= 1 && f <= max_split) ns = f;
     }
     pl.chunks_per_split = (int)((chunks + ns - 1) / ns);
     pl.nsplit = (int)((chunks + pl.chunks_per_split - 1) / pl.chunks_per_split);
@@ -861,7 +942,11 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
     dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * p.R * p.S), (unsigned)pl.nsplit);
     unsigned xb, dyb;
-    if (wgrad_dma(p, &xb, &dyb)) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN>), grid, dim3(256), lds, st, p, xb, dyb);
+    if (wgrad_dma(p, &xb, &dyb)) {
+        // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
+        if (p.Q % WG_BKP == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
+        else                   hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
+    }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();
 }
@@ -944,7 +1029,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
         const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
-        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d> splitk=%d", pl.bm, pl.bn, pl.nsplit);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", pl.nsplit);
         else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
@@ -953,7 +1038,9 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op);
+        const bool fast = d->R * d->S <= 32 && (op == 0 || d->stride == 1);
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
+                 fast ? "true" : "false");
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
