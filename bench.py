@@ -185,13 +185,20 @@ def main():
         with KernelTimer() as kt:
             step()
         summ = kt.summary()
+        # HBM traffic of the same scope cannot be measured live (PMC passes need rocprofv3): the committed summary of the
+        # offline FETCH_SIZE / WRITE_SIZE passes is reported (bytes per step over the conv launches, cfg2 only)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_cfg2_conv_traffic.json")
+        if args.config == "cfg2" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["traffic_bytes_per_step"]
         tot_ms = sum(r["total_ms"] for r in summ.values())
         tot_fl = sum(r["flops"] for r in summ.values())
         top_name, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "scope": "all conv implicit-GEMM launches of one step (fwd+dgrad+wgrad), HIP events per launch",
+                "traffic_note": "HBM+MALL bytes per step over the conv launches from rocprofv3 PMC passes (profiles/r01_cfg2_conv_traffic.json); algorithmic ~29 GB",
                 "conv_launches": sum(r["launches"] for r in summ.values()), "conv_ms_per_step": round(tot_ms, 2),
                 "conv_flops_per_step": tot_fl,
                 "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
