@@ -260,9 +260,17 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
+    // Tile order: each XCD owns a contiguous range of tile ids; ids run over groups of GN = 8 n-tiles, inside a group m-major
+    // with the n-tile fastest.  The 64 workgroups resident on an XCD are then an 8 x 8 block of tiles sharing 8 A panels and
+    // 8 filter panels in that XCD's L2 (with all n-tiles of a wide output in flight the 75 MB CRSK filter of the PSP
+    // bottleneck's dgrad was re-streamed from the Infinity Cache once per pair of m-tiles: 9.5 GB per launch).
     const unsigned ntiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned t = xcd_swizzle(blockIdx.x, ntiles);
-    const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+    constexpr unsigned GN = 8;
+    const unsigned per_group = GN * (unsigned)p.tiles_m;
+    const unsigned grp = t / per_group, in_grp = t - grp * per_group;
+    const unsigned gw = min(GN, (unsigned)p.tiles_n - grp * GN);          // width of this (possibly last, narrower) group
+    const int tm = in_grp / gw, tn = grp * GN + in_grp % gw;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const i32x4 src_rsrc = make_rsrc(p.src, src_bytes);
