@@ -416,14 +416,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         const float bv = (kreal && p.bias) ? p.bias[k] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float prev[16];
+            if (p.accumulate) {   // all 16 reads of the tile column in flight at once (a load-add-store chain per element is latency bound)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                    prev[e] = (kok && m < p.M) ? p.dst[(long)m * p.ldd + k] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
                 if (kok && m < p.M) {
-                    float* o = p.dst + (long)m * p.ldd + k;
                     float v = acc[i][j][e] + bv;
-                    if (p.accumulate) v += *o;
-                    *o = kreal ? v : 0.f;
+                    if (p.accumulate) v += prev[e];
+                    p.dst[(long)m * p.ldd + k] = kreal ? v : 0.f;
                 }
             }
         }

@@ -34,8 +34,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
+        if self.downsample is None:
+            out, identity = self.conv1(x, with_skip=True)
+        else:
+            out, identity = self.conv1(x), self.downsample(x)
+        out = self.bn1(out, relu=True)
         return self.bn2(self.conv2(out), residual=identity, relu=True)
 
 
@@ -56,8 +59,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
+        if self.downsample is None:
+            out, identity = self.conv1(x, with_skip=True)     # the skip gradient is accumulated by conv1's dgrad, no autograd add
+        else:
+            out, identity = self.conv1(x), self.downsample(x)
+        out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         return self.bn3(self.conv3(out), residual=identity, relu=True)
 

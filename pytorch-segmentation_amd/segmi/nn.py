@@ -32,9 +32,13 @@ class Conv2d(nn.Conv2d):
         if not self.depthwise and (self.kernel_size[0] > 1 or self.kernel_size[1] > 1):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x):
+    def forward(self, x, with_skip=False):
         if self.depthwise:
             return ops.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
+        if with_skip:   # (conv(x), x): residual fork whose backward accumulates dgrad onto the skip gradient (ops.conv2d_skip)
+            if self.bias is not None:
+                raise ValueError("with_skip is for the bias-free first convolution of a residual block")
+            return ops.conv2d_skip(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
 
 

@@ -17,7 +17,7 @@ from ._lib import ConvDesc, SegmiError, check, lib
 from .profile import span
 
 __all__ = [
-    "conv2d", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
+    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
     "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
@@ -246,6 +246,55 @@ class _Conv2dFn(torch.autograd.Function):
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """aten::conv2d replacement (groups == 1, symmetric stride/padding/dilation)."""
     return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+class _Conv2dSkipFn(torch.autograd.Function):
+    """y, skip = conv(x, w), x — the residual fork of a ResNet block expressed as ONE autograd node, so that its backward can
+    ACCUMULATE the data gradient of the convolution onto the gradient that arrives through the skip (dgrad kernel with
+    accumulate=1) instead of leaving a separate full-size `add` to autograd (16 such adds per PSPNet-R50 step).
+    Contract: the gradient arriving at `skip` must be exclusively owned by this node (it is overwritten in place); that holds
+    for batch_norm_act(residual=skip, relu=True), whose backward allocates the residual gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil):
+        x = to_nhwc(x, "conv2d")
+        y = _Conv2dFn.forward(ctx, x, weight, None, stride, pad, dil)
+        return y, x[:]
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        if dskip is None or not ctx.needs_input_grad[0]:
+            dx, dw, _, _, _, _ = _Conv2dFn.backward(ctx, dy)
+            if dskip is not None and dx is not None:
+                dx = add(dx, dskip)
+            return (dx if dx is not None else dskip), dw, None, None, None
+        x, weight = ctx.saved_tensors
+        N, C, H, W, K, R, S, P, Q, stride, pad, dil = ctx.geom
+        dy = to_nhwc(dy, "conv2d.backward")
+        dskip = to_nhwc(dskip, "conv2d.backward")
+        Ce, Kp, st = pad4(C), pad4(K), _stream()
+        w = _filter_krsc(weight, Ce)
+        wt = torch.empty(Ce * R * S * Kp, device=x.device, dtype=torch.float32)
+        check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
+        d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dskip), ld_of(dy))
+        with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dskip.data_ptr(), 1, st), "conv2d_dgrad(+=)")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
+            nws = lib.segmi_conv2d_wgrad_workspace(d)
+            ws = workspace(nws, x.device) if nws else None
+            dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
+                                             ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
+            dw = _filter_grad_like(dwb, weight, Ce)
+        return dskip, dw, None, None, None
+
+
+def conv2d_skip(x, weight, stride=1, padding=0, dilation=1):
+    """(conv2d(x, weight), x) with a fused backward: see _Conv2dSkipFn for the ownership contract of the skip gradient."""
+    return _Conv2dSkipFn.apply(x, weight, int(stride), int(padding), int(dilation))
 
 
 # --------------------------------------------------------------------------- depthwise convolution
