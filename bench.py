@@ -138,7 +138,8 @@ def main():
         from utils.sync_batchnorm import convert_model
         model = convert_model(model)
     dm = DistributedModel(model, always_reduce=args.force_ddp) if ddp else None
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    from segmi.optim import SGD          # torch.optim.SGD semantics, one fused launch
+    opt = SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     crit = getattr(losses_mod, loss_name)(ignore_index=ign)
     x, t = synth_batch(args.config, device, rank)
     psp = arch[:3] == "PSP"          # the reference keys the (out, aux) convention on the arch name (trainer.py:57-62)

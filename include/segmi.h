@@ -222,6 +222,24 @@ int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float*
  * at the start of an epoch and reads it when it wants numbers: no per-iteration host synchronisation. */
 int segmi_seg_metrics(const float* logits, int ld, const int64_t* target, long rows, int C, int64_t* acc, segmi_stream_t stream);
 
+/* ------------------------------------------------------------------ fused SGD
+ * torch.optim.SGD.step as the reference configures it (config.json:48-52; differential learning rates
+ * base/base_trainer.py:46-57): g = grad + wd*p; buf = momentum*buf + g; p -= lr*buf, over every tensor in ONE launch.
+ * `table` is a DEVICE array of chunks the caller builds once (a tensor is cut into ranges of segmi_sgd_chunk_elems()
+ * elements; `vec4` = 1 when the three pointers are 16-byte aligned and count % 4 == 0); per-group hyper-parameters are HOST
+ * arrays read at call time (schedulers change them every iteration; ngroups <= 8).  Momentum buffers start zeroed. */
+typedef struct segmi_sgd_chunk {
+    float* param;
+    const float* grad;
+    float* momentum;
+    long count;
+    int group;
+    int vec4;
+} segmi_sgd_chunk;
+int segmi_sgd_chunk_elems(void);
+int segmi_sgd_step(const segmi_sgd_chunk* table, int nchunks, const float* lr_host, const float* weight_decay_host,
+                   const float* momentum_host, int ngroups, segmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 import utils.lr_scheduler
+from segmi import optim as segmi_optim
 from segmi.distributed import DistributedModel
 from utils import helpers
 from utils.sync_batchnorm import convert_model
@@ -81,7 +82,12 @@ class BaseTrainer:
             trainable_params = [g for g in trainable_params if g["params"]]
         else:
             trainable_params = [p for p in self.model.parameters() if p.requires_grad]
-        self.optimizer = get_instance(torch.optim, "optimizer", config, trainable_params)
+        # same by-name resolution as the reference (`getattr(torch.optim, type)`); optimizers that exist as fused libsegmi
+        # kernels (SGD) are taken from segmi.optim — identical update rule and state layout
+        otype = config["optimizer"]["type"]
+        oargs = config["optimizer"]["args"]
+        fused = hasattr(segmi_optim, otype) and not oargs.get("nesterov") and not oargs.get("dampening")
+        self.optimizer = get_instance(segmi_optim if fused else torch.optim, "optimizer", config, trainable_params)
         self.lr_scheduler = getattr(utils.lr_scheduler, config["lr_scheduler"]["type"])(self.optimizer, self.epochs, len(train_loader))
 
         # MONITORING

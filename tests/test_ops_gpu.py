@@ -353,3 +353,46 @@ def test_lovasz_softmax_vs_oracle(cuda, case):
     assert abs(ld.item() - lr.item()) <= 1e-5 * abs(lr.item()) + 1e-6, (ld.item(), lr.item())
     assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-8), (xd.grad.cpu() - xr.grad).abs().max()
     assert float(xd.grad.cpu()[:, :, :2, :].abs().max()) == 0.0     # ignored pixels get no gradient
+
+
+def test_fused_sgd_matches_torch_sgd(cuda):
+    """segmi.optim.SGD (one launch over all tensors) vs torch.optim.SGD over 3 steps: two parameter groups with different lr
+    (the reference's differential learning rates), momentum 0.9, weight decay 1e-4, lr changed between steps (schedulers do),
+    a channels_last filter, a 1x1 filter whose gradient has permuted size-1 strides, ragged sizes."""
+    from segmi.optim import SGD
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (48, 64, 1, 1), (64,), (7,), (150, 256, 1, 1), (3, 5)]
+
+    def make():
+        ps = []
+        for i, s in enumerate(shapes):
+            t = torch.randn(s, generator=torch.Generator().manual_seed(i)).to(cuda)
+            if len(s) == 4 and s[2] > 1:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t))
+        return ps
+
+    pa, pb = make(), make()
+    groups = lambda ps: [{"params": ps[:3]}, {"params": ps[3:], "lr": 0.001}]
+    oa = SGD(groups(pa), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(groups(pb), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn(a.shape, generator=torch.Generator().manual_seed(100 * step + i)).to(cuda)
+            if a.dim() == 4 and a.shape[2] == 1:
+                g = g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # same memory order, different size-1 strides
+            elif a.dim() == 4:
+                g = g.contiguous(memory_format=torch.channels_last)
+            a.grad, b.grad = g.clone(), g.clone()
+        for o in (oa, ob):
+            for gi, grp in enumerate(o.param_groups):
+                grp["lr"] = (0.01 if gi == 0 else 0.001) * (1 - 0.2 * step)
+        oa.step()
+        ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            # values are O(1); fma contraction vs torch's separate mul/add differs by ~1 ulp of the LARGER operand when
+            # momentum*buf and the gradient cancel, hence an absolute tolerance
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), (step, i, (a - b).abs().max())
+            assert torch.allclose(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"], rtol=1e-6, atol=2e-6), (step, i)
+    # state layout interchangeable with torch.optim.SGD
+    ob.load_state_dict(oa.state_dict())
