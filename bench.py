@@ -139,6 +139,8 @@ def main():
         model = convert_model(model)
     dm = DistributedModel(model, always_reduce=args.force_ddp) if ddp else None
     from segmi.optim import SGD          # torch.optim.SGD semantics, one fused launch
+    if os.environ.get("SEGMI_BENCH_TORCH_SGD") == "1":
+        SGD = torch.optim.SGD            # A/B hook
     opt = SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     crit = getattr(losses_mod, loss_name)(ignore_index=ign)
     x, t = synth_batch(args.config, device, rank)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, per-layer conv table, rocprof kernel stats.
-# Outputs under gpurun_out/.   usage: ./tools_gpu_round.sh [tests] [bench] [layers] [prof] [pmc]
+# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc]
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
