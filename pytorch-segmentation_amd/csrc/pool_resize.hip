@@ -256,6 +256,142 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------ fused pyramid pooling
+// The PSP module (models/pspnet.py:25-37) pools the SAME [N, 2048, 64, 64] map (268 MB at cfg2) with bins 1, 2, 3 and 6: four
+// reads forward, and backward four full-size gradient maps that autograd then adds.  Fused: the union of all window
+// boundaries cuts the map into <= 24 x 24 cells; pass 1 reduces x to per-cell sums in ONE read, pass 2 assembles every bin of
+// every pyramid level from cells (a few KB); backward writes dx ONCE from the four small dy tensors.
+constexpr int PYR_MAX_LEVELS = 4, PYR_MAX_BIN = 8, PYR_MAX_SEG = 2 * PYR_MAX_LEVELS * PYR_MAX_BIN + 1;
+struct PyrAxis {
+    int nseg;
+    int brk[PYR_MAX_SEG + 1];                       // segment k = [brk[k], brk[k+1])
+    int lo[PYR_MAX_LEVELS][PYR_MAX_BIN], hi[PYR_MAX_LEVELS][PYR_MAX_BIN];   // window i of level l = segments [lo, hi)
+};
+struct PyrGeom {
+    int N, H, W, C, nl;
+    int bins[PYR_MAX_LEVELS];
+    PyrAxis ah, aw;
+};
+struct PyrPtrs {
+    float* y[PYR_MAX_LEVELS];
+    const float* dy[PYR_MAX_LEVELS];
+    int ld[PYR_MAX_LEVELS];
+};
+
+// cells[n][sh][sw][C] = sum over the cell's pixels; grid (channel tiles, nsh*nsw, N)
+__global__ __launch_bounds__(256) void pyramid_cells_kernel(const float* __restrict__ x, int ldx, float* __restrict__ cells, PyrGeom g) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 * 4 < g.C;
+    const int sh = blockIdx.y / g.aw.nseg, sw = blockIdx.y % g.aw.nseg, n = blockIdx.z;
+    const int h0 = g.ah.brk[sh], h1 = g.ah.brk[sh + 1], w0 = g.aw.brk[sw], w1 = g.aw.brk[sw + 1];
+    const int cw = w1 - w0, cnt = (h1 - h0) * cw;
+    float4 acc = zero4();
+    if (cok)
+        for (int i = threadIdx.y; i < cnt; i += blockDim.y) {
+            const int h = h0 + i / cw, w = w0 + i % cw;
+            const float4 v = ld4(x + ((long)(n * g.H + h) * g.W + w) * ldx + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    __shared__ float4 sm[256];
+    const int tix = threadIdx.y * blockDim.x + threadIdx.x;
+    sm[tix] = acc;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            sm[tix] = a;
+        }
+        __syncthreads();
+    }
+    const int Cp = (g.C + 3) & ~3;
+    if (threadIdx.y == 0 && cok) st4(cells + ((long)(n * g.ah.nseg + sh) * g.aw.nseg + sw) * Cp + c4 * 4, sm[tix]);
+}
+
+// y_l[n, i, j, c] = (sum of the cells of window (i, j) of level l) / window area; grid (channel tiles, sum_l b_l^2, N)
+__global__ __launch_bounds__(256) void pyramid_assemble_kernel(const float* __restrict__ cells, PyrGeom g, PyrPtrs p) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= g.C || threadIdx.y) return;
+    int item = blockIdx.y, l = 0;
+    while (item >= g.bins[l] * g.bins[l]) { item -= g.bins[l] * g.bins[l]; ++l; }
+    const int b = g.bins[l], i = item / b, j = item % b, n = blockIdx.z;
+    const int Cp = (g.C + 3) & ~3;
+    float4 acc = zero4();
+    for (int sh = g.ah.lo[l][i]; sh < g.ah.hi[l][i]; ++sh)
+        for (int sw = g.aw.lo[l][j]; sw < g.aw.hi[l][j]; ++sw) {
+            const float4 v = ld4(cells + ((long)(n * g.ah.nseg + sh) * g.aw.nseg + sw) * Cp + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    const float inv = 1.f / (float)((g.ah.brk[g.ah.hi[l][i]] - g.ah.brk[g.ah.lo[l][i]]) * (g.aw.brk[g.aw.hi[l][j]] - g.aw.brk[g.aw.lo[l][j]]));
+    st4(p.y[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+}
+
+// dx[n,h,w,c] = sum_l sum_{windows (i,j) of level l containing (h,w)} dy_l[n,i,j,c] / area
+__global__ __launch_bounds__(256) void pyramid_bwd_kernel(float* __restrict__ dx, int lddx, PyrGeom g, PyrPtrs p) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= g.C) return;
+    const long rows = (long)g.N * g.H * g.W;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int w = (int)(r % g.W);
+        const long t = r / g.W;
+        const int h = (int)(t % g.H), n = (int)(t / g.H);
+        float4 acc = zero4();
+        for (int l = 0; l < g.nl; ++l) {
+            const int b = g.bins[l];
+            const int ic = (int)(((long)h * b) / g.H), jc = (int)(((long)w * b) / g.W);
+            for (int i = max(ic - 1, 0); i <= min(ic + 1, b - 1); ++i) {
+                const int h0 = aap_start(i, g.H, b), h1 = aap_end(i, g.H, b);
+                if (h < h0 || h >= h1) continue;
+                for (int j = max(jc - 1, 0); j <= min(jc + 1, b - 1); ++j) {
+                    const int w0 = aap_start(j, g.W, b), w1 = aap_end(j, g.W, b);
+                    if (w < w0 || w >= w1) continue;
+                    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                    const float4 v = ld4(p.dy[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4);
+                    acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
+                }
+            }
+        }
+        st4(dx + r * lddx + c4 * 4, acc);
+    }
+}
+
+static bool pyr_axis(int in, int nl, const int* bins, PyrAxis* a) {
+    int pts[PYR_MAX_SEG + 1], np = 0;
+    for (int l = 0; l < nl; ++l)
+        for (int i = 0; i < bins[l]; ++i) {
+            pts[np++] = (int)(((long)i * in) / bins[l]);
+            pts[np++] = (int)(((long)(i + 1) * in + bins[l] - 1) / bins[l]);
+        }
+    for (int i = 1; i < np; ++i) {                 // insertion sort + unique (<= 64 points)
+        int v = pts[i], j = i - 1;
+        while (j >= 0 && pts[j] > v) { pts[j + 1] = pts[j]; --j; }
+        pts[j + 1] = v;
+    }
+    int nu = 0;
+    for (int i = 0; i < np; ++i)
+        if (nu == 0 || pts[i] != a->brk[nu - 1]) a->brk[nu++] = pts[i];
+    a->nseg = nu - 1;
+    if (a->nseg < 1 || a->brk[0] != 0 || a->brk[nu - 1] != in) return false;
+    for (int l = 0; l < nl; ++l)
+        for (int i = 0; i < bins[l]; ++i) {
+            const int s = (int)(((long)i * in) / bins[l]), e = (int)(((long)(i + 1) * in + bins[l] - 1) / bins[l]);
+            int lo = 0, hi = 0;
+            while (a->brk[lo] != s) ++lo;
+            hi = lo;
+            while (a->brk[hi] != e) ++hi;
+            a->lo[l][i] = lo; a->hi[l][i] = hi;
+        }
+    return true;
+}
+static bool pyr_geom(int N, int H, int W, int C, int nl, const int* bins, PyrGeom* g) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || nl <= 0 || nl > PYR_MAX_LEVELS || !bins) return false;
+    for (int l = 0; l < nl; ++l)
+        if (bins[l] <= 0 || bins[l] > PYR_MAX_BIN || bins[l] > H || bins[l] > W) return false;
+    g->N = N; g->H = H; g->W = W; g->C = C; g->nl = nl;
+    for (int l = 0; l < PYR_MAX_LEVELS; ++l) g->bins[l] = l < nl ? bins[l] : 0;
+    return pyr_axis(H, nl, bins, &g->ah) && pyr_axis(W, nl, bins, &g->aw);
+}
+
 bool ldok(int ld, int C) { return ld >= ((C + 3) & ~3) && (ld & 3) == 0; }
 
 }  // namespace
@@ -330,6 +466,50 @@ int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, in
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0>), g0.grid, g0.block, 0, st, dy, lddy, tmp, ldt, N, H, W, C, OH, OW, ac);
     RowGeom g1 = row_geom((long)N * H * W, C, 1, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), g1.grid, g1.block, 0, st, (const float*)tmp, ldt, dx, lddx, N, H, W, C, OH, OW, ac);
+    return segmi_launch_status();
+}
+
+size_t segmi_pyramid_pool_workspace(int N, int H, int W, int C, int nlevels, const int* bins) {
+    PyrGeom g;
+    if (!pyr_geom(N, H, W, C, nlevels, bins, &g)) return 0;
+    return (size_t)N * g.ah.nseg * g.aw.nseg * ((C + 3) & ~3) * sizeof(float);
+}
+
+int segmi_pyramid_pool_fwd(const float* x, int ldx, int N, int H, int W, int C, int nlevels, const int* bins, float* const* y,
+                           const int* ldy, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    PyrGeom g;
+    if (!x || !y || !ldy || !pyr_geom(N, H, W, C, nlevels, bins, &g) || N > 65535) return SEGMI_ERR_BADARG;
+    if (!ldok(ldx, C)) return SEGMI_ERR_ALIGN;
+    PyrPtrs p;
+    int items = 0;
+    for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
+        p.y[l] = l < nlevels ? y[l] : nullptr; p.dy[l] = nullptr; p.ld[l] = l < nlevels ? ldy[l] : 0;
+        if (l < nlevels) {
+            if (!y[l]) return SEGMI_ERR_BADARG;
+            if (!ldok(ldy[l], C)) return SEGMI_ERR_ALIGN;
+            items += bins[l] * bins[l];
+        }
+    }
+    if (!workspace || workspace_bytes < segmi_pyramid_pool_workspace(N, H, W, C, nlevels, bins) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    RowGeom rg = row_geom(1, C, 1, 1);
+    hipLaunchKernelGGL(pyramid_cells_kernel, dim3(rg.grid.x, (unsigned)(g.ah.nseg * g.aw.nseg), (unsigned)N), rg.block, 0, st, x, ldx, (float*)workspace, g);
+    hipLaunchKernelGGL(pyramid_assemble_kernel, dim3(rg.grid.x, (unsigned)items, (unsigned)N), rg.block, 0, st, (const float*)workspace, g, p);
+    return segmi_launch_status();
+}
+
+int segmi_pyramid_pool_bwd(const float* const* dy, const int* lddy, float* dx, int lddx, int N, int H, int W, int C, int nlevels,
+                           const int* bins, segmi_stream_t stream) {
+    PyrGeom g;
+    if (!dy || !lddy || !dx || !pyr_geom(N, H, W, C, nlevels, bins, &g)) return SEGMI_ERR_BADARG;
+    if (!ldok(lddx, C)) return SEGMI_ERR_ALIGN;
+    PyrPtrs p;
+    for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
+        p.y[l] = nullptr; p.dy[l] = l < nlevels ? dy[l] : nullptr; p.ld[l] = l < nlevels ? lddy[l] : 0;
+        if (l < nlevels && (!dy[l] || !ldok(lddy[l], C))) return dy[l] ? SEGMI_ERR_ALIGN : SEGMI_ERR_BADARG;
+    }
+    RowGeom rg = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(pyramid_bwd_kernel, rg.grid, rg.block, 0, (hipStream_t)stream, dx, lddx, g, p);
     return segmi_launch_status();
 }
 

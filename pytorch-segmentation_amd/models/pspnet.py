@@ -37,9 +37,14 @@ class _PSPModule(nn.Module):
 
     def forward(self, features):
         size = (features.size(2), features.size(3))
+        bins = [stage[0].output_size if isinstance(stage[0].output_size, int) else stage[0].output_size[0] for stage in self.stages]
+        fused = len(bins) <= 4 and max(bins) <= 8 and min(size) >= max(bins)
+        # all pyramid levels pooled in ONE pass over the feature map (and one gradient write in backward); the
+        # AdaptiveAvgPool2d modules stay in `stages` so checkpoint keys / indices are the reference's
+        pooled = ops.pyramid_pool(features, bins) if fused else [stage[0](features) for stage in self.stages]
         pyramid = [features]
-        for stage in self.stages:
-            pyramid.append(ops.interpolate_bilinear(stage(features), size, align_corners=True))
+        for stage, p in zip(self.stages, pooled):
+            pyramid.append(ops.interpolate_bilinear(snn.run_fused(list(stage)[1:], p), size, align_corners=True))
         return self.bottleneck(ops.cat(pyramid))
 
 

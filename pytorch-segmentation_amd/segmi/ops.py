@@ -17,7 +17,7 @@ from ._lib import ConvDesc, SegmiError, check, lib
 from .profile import span
 
 __all__ = [
-    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "interpolate_bilinear",
+    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "interpolate_bilinear",
     "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
 ]
 
@@ -623,6 +623,46 @@ def adaptive_avg_pool2d(x, output_size):
     if isinstance(output_size, int):
         output_size = (output_size, output_size)
     return _AdaptiveAvgPoolFn.apply(x, int(output_size[0]), int(output_size[1]))
+
+
+class _PyramidPoolFn(torch.autograd.Function):
+    """(AdaptiveAvgPool2d(b)(x) for b in bins) in one read of x; backward writes dx once (see segmi_pyramid_pool_*)."""
+
+    @staticmethod
+    def forward(ctx, x, *bins):
+        x = to_nhwc(x, "pyramid_pool")
+        N, C, H, W = x.shape
+        nl = len(bins)
+        barr = (ctypes.c_int * nl)(*bins)
+        nws = lib.segmi_pyramid_pool_workspace(N, H, W, C, nl, barr)
+        if nws == 0:
+            raise SegmiError("pyramid_pool: unsupported bins %s for a %dx%d map (<= 4 levels, bins <= 8)" % (bins, H, W))
+        ws = workspace(nws, x.device)
+        ys = [empty_nhwc(N, C, b, b, x.device) for b in bins]
+        yp = (ctypes.c_void_p * nl)(*[y.data_ptr() for y in ys])
+        ld = (ctypes.c_int * nl)(*[ld_of(y) for y in ys])
+        check(lib.segmi_pyramid_pool_fwd(x.data_ptr(), ld_of(x), N, H, W, C, nl, barr, yp, ld, ws.data_ptr(), nws, _stream()), "pyramid_pool_fwd")
+        ctx.geom = (N, C, H, W, tuple(bins))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        N, C, H, W, bins = ctx.geom
+        nl = len(bins)
+        dev = next(d for d in dys if d is not None).device
+        dys = [to_nhwc(d, "pyramid_pool.backward") if d is not None else torch.zeros((N, b, b, pad4(C)), device=dev).permute(0, 3, 1, 2)[:, :C]
+               for d, b in zip(dys, bins)]
+        dx = empty_nhwc(N, C, H, W, dev)
+        dp = (ctypes.c_void_p * nl)(*[d.data_ptr() for d in dys])
+        ld = (ctypes.c_int * nl)(*[ld_of(d) for d in dys])
+        barr = (ctypes.c_int * nl)(*bins)
+        check(lib.segmi_pyramid_pool_bwd(dp, ld, dx.data_ptr(), ld_of(dx), N, H, W, C, nl, barr, _stream()), "pyramid_pool_bwd")
+        return (dx,) + (None,) * nl
+
+
+def pyramid_pool(x, bins):
+    """[F.adaptive_avg_pool2d(x, b) for b in bins] — the PSP pyramid (models/pspnet.py:25-37) — fused."""
+    return _PyramidPoolFn.apply(x, *[int(b) for b in bins])
 
 
 # --------------------------------------------------------------------------- bilinear resize

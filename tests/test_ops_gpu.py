@@ -396,3 +396,24 @@ def test_fused_sgd_matches_torch_sgd(cuda):
             assert torch.allclose(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"], rtol=1e-6, atol=2e-6), (step, i)
     # state layout interchangeable with torch.optim.SGD
     ob.load_state_dict(oa.state_dict())
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, (1, 2, 3, 6)), (3, 20, 13, 17, (1, 2, 3, 6)), (2, 8, 12, 12, (1, 2, 3, 6)), (1, 36, 97, 97, (1, 2, 3, 6)),
+                                  (2, 16, 9, 7, (2, 5))])
+def test_pyramid_pool_fused(cuda, case):
+    """The PSP pyramid (AdaptiveAvgPool2d 1, 2, 3, 6 of one map, models/pspnet.py:25-37) fused; overlapping adaptive windows
+    (64 -> 3, 6; odd sizes) and the summed backward."""
+    from segmi import ops
+    N, C, H, W, bins = case
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    refs = [F.adaptive_avg_pool2d(xr, b) for b in bins]
+    gys = [torch.randn(r.shape, generator=g) for r in refs]
+    torch.autograd.backward(refs, gys)
+    xd = x.to(cuda).requires_grad_(True)
+    outs = ops.pyramid_pool(xd, bins)
+    for o, r in zip(outs, refs):
+        _close(o, r, 1e-5, 1e-6, "pyramid level")
+    torch.autograd.backward(outs, [gy.to(cuda) for gy in gys])
+    _close(xd.grad, xr.grad, 1e-5, 1e-6, "pyramid dx")

@@ -89,7 +89,10 @@ def test_pspnet_step_matches_reference_golden(cuda, regime):
     assert d <= 1e-3 * rec["out"].abs().max().item(), d
     assert (aux.detach().cpu()[:, :, ::2, ::2] - rec["aux"]).abs().max().item() <= 1e-3 * rec["aux"].abs().max().item()
     assert abs(loss.item() - rec["loss"].item()) < 1e-4
-    tol_norm, tol_el = (1e-3, 1e-3) if regime == "frozen" else (0.1, 0.25)  # batch-stat grads: coarse (see module doc)
+    # frozen BN: per-tensor norm within 1e-3; sampled elements within 3e-3 of the tensor's max (on these 13x13 maps one ReLU
+    # whose pre-activation is ~1e-7 landing on the other side of zero moves single elements by ~1e-3).
+    # batch statistics: coarse (see module doc)
+    tol_norm, tol_el = (1e-3, 3e-3) if regime == "frozen" else (0.1, 0.25)
     named = dict(m.named_parameters())
     for k, dg in rec["grads"].items():
         g = named[k].grad.detach().cpu().reshape(-1)
