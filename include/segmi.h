@@ -60,9 +60,13 @@ typedef struct segmi_conv_desc {
     int ldx, ldy;
 } segmi_conv_desc;
 
-/* y = conv(x, w) (+ bias[k]) (+ y if accumulate) */
+/* y = conv(x, w) (+ bias[k]) (+ y if accumulate).  Problems with very few output tiles and a long reduction (the PSP
+ * pyramid's 1x1 convolutions on 1x1..6x6 maps) split the reduction across workgroups through `workspace`
+ * (segmi_conv2d_fwd_workspace() bytes, 0 for everything else; deterministic fixed-order sum; passing workspace = NULL
+ * opts out of the split). */
+size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d);
 int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
-                     int accumulate, segmi_stream_t stream);
+                     int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* dx = conv_transpose(dy, w) (+ dx if accumulate).  w_crsk is the filter re-laid as [C,R,S,K]
  * (segmi_filter_krsc_to_crsk); requires K % 4 == 0 padding handled by the caller via ldy. */
 int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,

@@ -36,6 +36,10 @@ struct GatherParams {
     int M;  // N*Hd*Wd
     int accumulate;
     int tiles_m, tiles_n;
+    // split of the reduction (channel chunks x taps) over blockIdx.y for problems with too few output tiles to fill the chip
+    // (LDS-DMA kernel only): partial tiles go to `ws` [ksplit][M][ldd] and are summed by splitk_reduce_kernel
+    int ksplit, its_per_split;
+    float* ws;
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -368,8 +372,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nchunk = (p.Cs + BK - 1) / BK;
-    const int T = nchunk * RS;
-    int r = 0, s = 0, c0 = 0;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
+    const int Tall = nchunk * RS;
+    const int it0 = blockIdx.y * p.its_per_split;        // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
+    const int T = min(Tall, it0 + p.its_per_split);
+    int c0 = (it0 / RS) * BK, r = (it0 % RS) / p.S, s = (it0 % RS) % p.S;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
     auto advance = [&]() {
         if (++s == p.S) { s = 0; if (++r == p.R) { r = 0; c0 += BK; } }
     };
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
-    for (int it = 0; it < T; ++it) {
+    for (int it = it0; it < T; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
         const float* Ab = smem + buf * STAGE;
         const float* Bb = Ab + BM * BK;
@@ -409,6 +415,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
 
     // ---- epilogue (same C/D mapping as the register-staged kernel)
     const int cd4 = min((p.Cd + 3) & ~3, p.ldd);
+    if (p.ksplit > 1) {                                  // partial tile -> workspace slice of this split (no bias / accumulate)
+        float* out = p.ws + (long)blockIdx.y * p.M * p.ldd;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn0 + j * 32 + lrow32;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                    if (k < cd4 && m < p.M) out[(long)m * p.ldd + k] = k < p.Cd ? acc[i][j][e] : 0.f;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int k = n0 + wn0 + j * 32 + lrow32;
@@ -846,8 +867,17 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     p.tiles_n = segmi_cdiv(p.Cd, BN);
     const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
     const bool fast = p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
-    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    const int Tall = segmi_cdiv(p.Cs, 32) * p.R * p.S;
+    if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall; }
+    const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
+    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    if (p.ksplit > 1) {
+        const long n4 = (long)p.M * p.ldd / 4;
+        int rg = (int)((n4 + 255) / 256);
+        if (rg > SEGMI_MAX_GRID) rg = SEGMI_MAX_GRID;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, (const float*)p.ws, p.dst, n4, p.ksplit, n4);
+    }
     return segmi_launch_status();
 }
 
@@ -946,6 +976,28 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     return pl;
 }
 
+// Forward split-K: only for problems whose output has so few tiles that the chip idles while ONE workgroup walks a long
+// reduction chunk by chunk (the four pyramid 1x1 convs 2048->512 on 1x1..6x6 maps: M = 8..288 rows, 64 chunks: 140 us each).
+struct FwdSplit { int ksplit, its_per_split; };
+FwdSplit plan_fwd_split(const segmi_conv_desc* d) {
+    FwdSplit f = {1, 0};
+    const long M = (long)d->N * d->P * d->Q;
+    const int bn = d->K > 64 ? 128 : (d->K > 32 ? 64 : 32);
+    const long tiles = (long)segmi_cdiv(M, dma_half_m((int)M, d->K) ? 64 : 128) * segmi_cdiv(d->K, bn);
+    const int T = segmi_cdiv(d->C, 32) * d->R * d->S;
+    if (tiles > 32 || T < 16 || (d->ldy & 3)) return f;
+    long ks = (2L * SEGMI_NUM_CU) / tiles;                     // fill the 512 resident slots
+    if (ks > T / 4) ks = T / 4;                                // >= 4 iterations per split
+    if (ks > 64) ks = 64;
+    if (ks < 2) return f;
+    f.its_per_split = (int)((T + ks - 1) / ks);
+    f.ksplit = (T + f.its_per_split - 1) / f.its_per_split;
+    return f;
+}
+bool dma_eligible_fwd(const segmi_conv_desc* d) {
+    return conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->K * d->R * d->S * d->C);
+}
+
 bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
     *xb = span32((long)p.N * p.H * p.W * p.ldx);
     *dyb = span32((long)p.N * p.P * p.Q * p.ldy);
@@ -970,8 +1022,14 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
 
 extern "C" {
 
+size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d) {
+    if (!desc_ok(d) || !dma_eligible_fwd(d)) return 0;
+    const FwdSplit fs = plan_fwd_split(d);
+    return fs.ksplit > 1 ? (size_t)fs.ksplit * d->N * d->P * d->Q * d->ldy * sizeof(float) : 0;
+}
+
 int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                     int accumulate, segmi_stream_t stream) {
+                     int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     if (!desc_ok(d) || !x || !w || !y) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || d->ldy < d->K || !aligned16(x) || !aligned16(w)) return SEGMI_ERR_ALIGN;
     GatherParams p;
@@ -980,6 +1038,12 @@ int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, c
     p.Hd = d->P; p.Wd = d->Q; p.Cd = d->K; p.ldd = d->ldy;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->P * d->Q; p.accumulate = accumulate;
+    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr;
+    const FwdSplit fs = plan_fwd_split(d);
+    if (fs.ksplit > 1 && !accumulate && !bias && dma_eligible_fwd(d) && workspace) {      // workspace == NULL: caller opts out of the split
+        if (workspace_bytes < segmi_conv2d_fwd_workspace(d) || !aligned16(workspace)) return SEGMI_ERR_WORKSPACE;
+        p.ksplit = fs.ksplit; p.its_per_split = fs.its_per_split; p.ws = (float*)workspace;
+    }
     return dispatch_gather<MODE_FPROP>(p, (hipStream_t)stream);
 }
 
@@ -995,6 +1059,7 @@ int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w
     p.Hd = d->H; p.Wd = d->W; p.Cd = d->C; p.ldd = d->ldx;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->H * d->W; p.accumulate = accumulate;
+    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr;
     return dispatch_gather<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 

@@ -30,7 +30,8 @@ SIGNATURES = {
     "segmi_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "segmi_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "segmi_copy_rows": (i32, [vp, i32, vp, i32, i64, i32, i32, vp]),
-    "segmi_conv2d_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp]),
+    "segmi_conv2d_fwd_workspace": (sz, [PD]),
+    "segmi_conv2d_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_conv2d_dgrad": (i32, [PD, vp, vp, vp, i32, vp]),
     "segmi_conv2d_wgrad_workspace": (sz, [PD]),
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),

@@ -200,9 +200,11 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, K, P, Q, x.device)
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
+        nws = lib.segmi_conv2d_fwd_workspace(d) if bias is None else 0
+        ws = workspace(nws, x.device) if nws else None
         with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                       y.data_ptr(), 0, _stream()), "conv2d_fwd")
+                                       y.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, _stream()), "conv2d_fwd")
         ctx.save_for_backward(x, weight)
         ctx.geom = (N, C, H, W, K, R, S, P, Q, stride, pad, dil)
         ctx.has_bias = bias is not None
@@ -370,7 +372,10 @@ class _ConvTranspose2x2Fn(torch.autograd.Function):
         t = empty_nhwc(N, K4, H, W, x.device)
         d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(t))
         with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
-            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w2.data_ptr(), None, t.data_ptr(), 0, st), "convT conv2d_fwd")
+            nws = lib.segmi_conv2d_fwd_workspace(d)
+            ws = workspace(nws, x.device) if nws else None
+            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w2.data_ptr(), None, t.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st),
+                  "convT conv2d_fwd")
         y = empty_nhwc(N, K, 2 * H, 2 * W, x.device)
         check(lib.segmi_depth_to_space2(t.data_ptr(), ld_of(t), y.data_ptr(), ld_of(y), bias.data_ptr() if bias is not None else None,
                                         N, H, W, K, st), "depth_to_space2")

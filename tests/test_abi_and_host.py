@@ -46,14 +46,14 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 2
+    assert lib.segmi_abi_version() == 3
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
     d = ConvDesc(1, 8, 8, 4, 8, 3, 3, 7, 8, 1, 1, 1, 4, 8)  # P inconsistent with H/pad/dil
-    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None) == -1
+    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None, 0, None) == -1
     d = ConvDesc(1, 8, 8, 6, 8, 3, 3, 8, 8, 1, 1, 1, 6, 8)  # C % 4 != 0
-    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None) == -2
+    assert lib.segmi_conv2d_fwd(d, 16, 16, None, 16, 0, None, 0, None) == -2
     # split-K planning: a 64->64 3x3 on a 256x256 map at batch 8 must split its 524288-pixel reduction
     d = ConvDesc(8, 256, 256, 64, 64, 3, 3, 256, 256, 1, 1, 1, 64, 64)
     ws = lib.segmi_conv2d_wgrad_workspace(d)

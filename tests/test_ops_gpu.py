@@ -417,3 +417,28 @@ def test_pyramid_pool_fused(cuda, case):
         _close(o, r, 1e-5, 1e-6, "pyramid level")
     torch.autograd.backward(outs, [gy.to(cuda) for gy in gys])
     _close(xd.grad, xr.grad, 1e-5, 1e-6, "pyramid dx")
+
+
+@pytest.mark.parametrize("case", [(8, 2048, 1, 1, 512, 1, 1, 0, 1), (8, 2048, 2, 2, 512, 1, 1, 0, 1), (8, 2048, 6, 6, 512, 1, 1, 0, 1),
+                                  (2, 512, 5, 5, 96, 3, 1, 2, 2), (1, 1024, 3, 4, 40, 3, 1, 1, 1)])
+def test_conv_fwd_splitk_tiny_outputs(cuda, case):
+    """Few output tiles + long reduction (the PSP pyramid's 1x1 convs on 1x1..6x6 maps): the forward splits the reduction over
+    workgroups through a workspace; result and gradients must still match."""
+    from segmi import ops
+    from segmi._lib import ConvDesc, lib
+    N, C, H, W, K, R, stride, pad, dil = case
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    P = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    d = ConvDesc(N, H, W, C, K, R, R, P, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1, stride, pad, dil, C, (K + 3) & ~3)
+    assert lib.segmi_conv2d_fwd_workspace(d) > 0          # these shapes must take the split path
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, wd = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, None, stride, pad, dil)
+    yd.backward(gy.to(cuda))
+    for a, r, what in ((yd, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
+        assert (a.detach().cpu() - r.detach()).abs().max().item() <= 1e-4 * r.detach().abs().max().item() + 1e-6, what
