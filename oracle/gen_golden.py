@@ -240,7 +240,24 @@ def gen_misc():
     m2 = eval_metrics(lg, tg, 6)
     bn = SynchronizedBatchNorm2d(2)
     mean, inv_std = bn._compute_mean_std(torch.tensor([10.0, -4.0]), torch.tensor([30.0, 4.000001]), 8)
+    # learning-rate / momentum sequences of the reference's schedulers, stepped exactly as trainer.py:52 does
+    from utils import lr_scheduler as ref_sched
+
+    def run_sched(cls, **kw):
+        ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+        opt = torch.optim.SGD([{"params": ps[:1]}, {"params": ps[1:], "lr": 0.001}], lr=0.01, momentum=0.9)
+        sch = cls(opt, 3, 5, **kw)
+        seq = []
+        for epoch in range(1, 4):
+            for _ in range(5):
+                sch.step(epoch=epoch - 1)
+                seq.append([g["lr"] for g in opt.param_groups] + [g["momentum"] for g in opt.param_groups])
+        return torch.tensor(seq, dtype=torch.float64)
+
+    sched = {"Poly": run_sched(ref_sched.Poly), "Poly_warmup": run_sched(ref_sched.Poly, warmup_epochs=1),
+             "OneCycle": run_sched(ref_sched.OneCycle)}
     rec = {
+        "schedulers": sched,
         "metrics_appendix_c": {"logits": logits, "target": target, "correct": float(correct), "labeled": float(labeled),
                                "inter": torch.as_tensor(inter), "union": torch.as_tensor(union)},
         "metrics_rand": {"logits": lg, "target": tg, "correct": float(m2[0]), "labeled": float(m2[1]),

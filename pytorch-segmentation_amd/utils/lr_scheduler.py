@@ -1,56 +1,76 @@
-"""Per-iteration learning-rate schedules (reference: utils/lr_scheduler.py).  Host-side arithmetic, stepped once per
-iteration with `step(epoch=epoch-1)` exactly as trainer.py:52 does."""
+"""Per-iteration learning-rate schedules resolved by name from config.json (`lr_scheduler.type`), stepped by the trainer
+once per iteration as `scheduler.step(epoch=epoch-1)` (reference call site trainer.py:52; schedules utils/lr_scheduler.py).
+
+Both schedules are functions of the global iteration  T = epoch * iters_per_epoch + i  (i = position inside the epoch,
+tracked by the scheduler itself because the trainer only passes the epoch):
+
+  Poly      lr_g(T) = base_g * (1 - T / N)^0.9, with an optional linear warm-up  lr_g = base_g * T / W  for T < W
+  OneCycle  cosine ramp from base/div_factor up to base during the first `phase1` fraction of training, then a cosine decay
+            to base/(div_factor*1e4); momentum runs the opposite way between momentums[0] and momentums[1]
+
+Host-side scalar arithmetic only; the values reach the device as kernel arguments of the fused SGD step.
+"""
 import math
 
 from torch.optim.lr_scheduler import _LRScheduler
 
 
-class Poly(_LRScheduler):
-    """lr = base_lr * (1 - T/N)^0.9 with T the global iteration, optional linear warm-up (reference :4-21)."""
+class _IterationSchedule(_LRScheduler):
+    """Keeps the within-epoch position and hands the global iteration to `rates(T)`."""
 
+    def __init__(self, optimizer, num_epochs, iters_per_epoch, last_epoch=-1):
+        self.iters_per_epoch = iters_per_epoch
+        self.total_iters = num_epochs * iters_per_epoch
+        self.pos = 0
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        t_global = self.last_epoch * self.iters_per_epoch + self.pos
+        self.pos = self.pos % self.iters_per_epoch + 1      # wraps to 1 at the start of the next epoch
+        return self.rates(t_global)
+
+    def rates(self, t_global):
+        raise NotImplementedError
+
+
+class Poly(_IterationSchedule):
     def __init__(self, optimizer, num_epochs, iters_per_epoch=0, warmup_epochs=0, last_epoch=-1):
-        self.iters_per_epoch = iters_per_epoch
-        self.cur_iter = 0
-        self.N = num_epochs * iters_per_epoch
         self.warmup_iters = warmup_epochs * iters_per_epoch
-        super().__init__(optimizer, last_epoch)
+        super().__init__(optimizer, num_epochs, iters_per_epoch, last_epoch)
 
-    def get_lr(self):
-        T = self.last_epoch * self.iters_per_epoch + self.cur_iter
-        factor = pow((1 - 1.0 * T / self.N), 0.9)
-        if self.warmup_iters > 0 and T < self.warmup_iters:
-            factor = 1.0 * T / self.warmup_iters
-        self.cur_iter %= self.iters_per_epoch
-        self.cur_iter += 1
-        return [base_lr * factor for base_lr in self.base_lrs]
+    def rates(self, t_global):
+        if 0 < self.warmup_iters and t_global < self.warmup_iters:
+            scale = t_global / float(self.warmup_iters)
+        else:
+            scale = math.pow(1.0 - t_global / float(self.total_iters), 0.9)
+        return [base * scale for base in self.base_lrs]
 
 
-class OneCycle(_LRScheduler):
-    """Cosine one-cycle schedule with inverse momentum cycling (reference :24-60)."""
+def _half_cosine(x):
+    """1 at x = 0, 0 at x = 1."""
+    return 0.5 * (1.0 + math.cos(math.pi * x))
 
+
+class OneCycle(_IterationSchedule):
     def __init__(self, optimizer, num_epochs, iters_per_epoch=0, last_epoch=-1, momentums=(0.85, 0.95), div_factor=25, phase1=0.3):
-        self.iters_per_epoch = iters_per_epoch
-        self.cur_iter = 0
-        self.N = num_epochs * iters_per_epoch
-        self.phase1_iters = int(self.N * phase1)
-        self.phase2_iters = self.N - self.phase1_iters
+        total = num_epochs * iters_per_epoch
+        self.up_iters = int(total * phase1)
+        self.down_iters = total - self.up_iters
         self.momentums = momentums
-        self.mom_diff = momentums[1] - momentums[0]
-        self.low_lrs = [g["lr"] / div_factor for g in optimizer.param_groups]
-        self.final_lrs = [g["lr"] / (div_factor * 1e4) for g in optimizer.param_groups]
-        super().__init__(optimizer, last_epoch)
+        self.start_lrs = [g["lr"] / div_factor for g in optimizer.param_groups]
+        self.end_lrs = [g["lr"] / (div_factor * 1e4) for g in optimizer.param_groups]
+        super().__init__(optimizer, num_epochs, iters_per_epoch, last_epoch)
 
-    def get_lr(self):
-        T = self.last_epoch * self.iters_per_epoch + self.cur_iter
-        self.cur_iter %= self.iters_per_epoch
-        self.cur_iter += 1
-        if T <= self.phase1_iters:
-            cos = (1 + math.cos(math.pi * T / self.phase1_iters)) / 2
-            for g in self.optimizer.param_groups:
-                g["momentum"] = self.momentums[0] + self.mom_diff * cos
-            return [b - (b - lo) * cos for b, lo in zip(self.base_lrs, self.low_lrs)]
-        T -= self.phase1_iters
-        cos = (1 + math.cos(math.pi * T / self.phase2_iters)) / 2
-        for g in self.optimizer.param_groups:
-            g["momentum"] = self.momentums[1] - self.mom_diff * cos
-        return [f + (b - f) * cos for b, f in zip(self.base_lrs, self.final_lrs)]
+    def _set_momentum(self, value):
+        for group in self.optimizer.param_groups:
+            group["momentum"] = value
+
+    def rates(self, t_global):
+        m_lo, m_hi = self.momentums
+        if t_global <= self.up_iters:                     # warm-up: lr start -> base, momentum hi -> lo
+            c = _half_cosine(t_global / float(self.up_iters))
+            self._set_momentum(m_lo + (m_hi - m_lo) * c)
+            return [base - (base - start) * c for base, start in zip(self.base_lrs, self.start_lrs)]
+        c = _half_cosine((t_global - self.up_iters) / float(self.down_iters))   # anneal: lr base -> end, momentum lo -> hi
+        self._set_momentum(m_hi - (m_hi - m_lo) * c)
+        return [end + (base - end) * c for base, end in zip(self.base_lrs, self.end_lrs)]

@@ -138,3 +138,28 @@ def test_unet_and_deeplab_plugin_surface_matches_reference_manifests():
     assert m16.backbone.layer4[2].conv2.dilation == (2, 2) and m16.backbone.layer4[0].downsample[0].stride == (1, 1)
     with pytest.raises(FileNotFoundError):
         models.DeepLab(3, backbone="xception", pretrained=True)
+
+
+def test_lr_schedulers_match_reference_sequences():
+    """Poly (with and without warm-up) and OneCycle, two parameter groups, stepped as trainer.py:52 does, against sequences
+    recorded from the reference's utils/lr_scheduler.py (tests/golden/misc.pt)."""
+    import warnings
+    from utils import lr_scheduler
+    gold = torch.load(os.path.join(GOLD, "misc.pt"), weights_only=False)["schedulers"]
+
+    def run(cls, **kw):
+        ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+        opt = torch.optim.SGD([{"params": ps[:1]}, {"params": ps[1:], "lr": 0.001}], lr=0.01, momentum=0.9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sch = cls(opt, 3, 5, **kw)
+            seq = []
+            for epoch in range(1, 4):
+                for _ in range(5):
+                    sch.step(epoch=epoch - 1)
+                    seq.append([g["lr"] for g in opt.param_groups] + [g["momentum"] for g in opt.param_groups])
+        return torch.tensor(seq, dtype=torch.float64)
+
+    assert torch.allclose(run(lr_scheduler.Poly), gold["Poly"], rtol=1e-12, atol=0)
+    assert torch.allclose(run(lr_scheduler.Poly, warmup_epochs=1), gold["Poly_warmup"], rtol=1e-12, atol=0)
+    assert torch.allclose(run(lr_scheduler.OneCycle), gold["OneCycle"], rtol=1e-12, atol=1e-18)
