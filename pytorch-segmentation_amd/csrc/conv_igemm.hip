@@ -430,29 +430,36 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         }
         return;
     }
+    // Full tiles leave through LDS: the MFMA accumulator layout holds ONE channel per lane (column lane%32, 16 rows), which
+    // would be 64 single-dword stores per lane — store-issue bound (MI355X_MICROARCH.md: ~7 B/clk/CU), a quarter of the
+    // runtime of short-reduction (1x1, C = 256) tiles.  Each wave transposes its 64x32 column block in its own LDS slice
+    // (the pipeline stages are free now) and emits 16-byte stores of 4 consecutive channels: 16 instead of 64 per lane.
+    constexpr int EP = 36;                                // padded row pitch (floats) of the staging slice
+    float* stage = smem + wave * (TM * 32 * EP);          // TM*32 rows x 32 columns per pass
+    const int er = lane >> 3, ec = (lane & 7) * 4;        // store role: row er (+8 per step), channels ec..ec+3
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int k = n0 + wn0 + j * 32 + lrow32;
-        const bool kreal = k < p.Cd, kok = k < cd4;
-        const float bv = (kreal && p.bias) ? p.bias[k] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float prev[16];
-            if (p.accumulate) {   // all 16 reads of the tile column in flight at once (a load-add-store chain per element is latency bound)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    prev[e] = (kok && m < p.M) ? p.dst[(long)m * p.ldd + k] : 0.f;
-                }
-            }
+            for (int e = 0; e < 16; ++e) stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * EP + lrow32] = acc[i][j][e];
+        const int k = n0 + wn0 + j * 32 + ec;
+        const bool kok = k < cd4;
+        float4 bv = zero4();
+        if (p.bias && kok) {
+            bv.x = k < p.Cd ? p.bias[k] : 0.f; bv.y = k + 1 < p.Cd ? p.bias[k + 1] : 0.f;
+            bv.z = k + 2 < p.Cd ? p.bias[k + 2] : 0.f; bv.w = k + 3 < p.Cd ? p.bias[k + 3] : 0.f;
+        }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                if (kok && m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    if (p.accumulate) v += prev[e];
-                    p.dst[(long)m * p.ldd + k] = kreal ? v : 0.f;
-                }
+        for (int q = 0; q < TM * 4; ++q) {
+            const int row = q * 8 + er;
+            const int m = m0 + wm0 + row;
+            float4 v = ld4(stage + row * EP + ec);        // same wave wrote it: LDS is in order per wave
+            if (kok && m < p.M) {
+                float* o = p.dst + (long)m * p.ldd + k;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.accumulate) { const float4 u = ld4(o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                st4(o, v);
             }
         }
     }
@@ -1031,7 +1038,9 @@ size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d) {
 int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                      int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     if (!desc_ok(d) || !x || !w || !y) return SEGMI_ERR_BADARG;
-    if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || d->ldy < d->K || !aligned16(x) || !aligned16(w)) return SEGMI_ERR_ALIGN;
+    if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < ((d->K + 3) & ~3) || !aligned16(x) || !aligned16(w) ||
+        !aligned16(y))
+        return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = x; p.wgt = w; p.bias = bias; p.dst = y;
     p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.Cs = d->C; p.lds = d->ldx;
@@ -1052,7 +1061,8 @@ int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w
     if (!desc_ok(d) || !dy || !w_crsk || !dx) return SEGMI_ERR_BADARG;
     // the reduction axis is K here: the caller pads it to a multiple of 4 (Kpad = round_up(K,4) <= ldy)
     const int Kpad = (d->K + 3) & ~3;
-    if ((d->ldy & 3) || d->ldy < Kpad || d->ldx < d->C || !aligned16(dy) || !aligned16(w_crsk)) return SEGMI_ERR_ALIGN;
+    if ((d->ldy & 3) || d->ldy < Kpad || (d->ldx & 3) || d->ldx < ((d->C + 3) & ~3) || !aligned16(dy) || !aligned16(w_crsk) || !aligned16(dx))
+        return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = dy; p.wgt = w_crsk; p.bias = nullptr; p.dst = dx;
     p.N = d->N; p.Hs = d->P; p.Ws = d->Q; p.Cs = Kpad; p.lds = d->ldy;
