@@ -222,7 +222,8 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
  * per_image=False: softmax; ignored pixels dropped; per present class sort |fg - p_c| descending, Jaccard-gradient dot;
  * mean over present classes.  One device-wide radix sort of C*rows (class, error) keys replaces the C per-class sorts.
  * G[rows, ldg] receives d loss_c / d p (un-normalised) and is consumed by the backward; loss_out[2] = {loss, n_present}.
- * rows < 2^24 (the reference's fp32 cumsums are exact only below that).  workspace must be 256-byte aligned. */
+ * rows < 2^24 (the reference's fp32 cumsums are exact only below that) and log2(C) + log2(rows) <= 32.  workspace must be
+ * 256-byte aligned. */
 size_t segmi_lovasz_workspace(long rows, int C);
 int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
                      float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);

@@ -5,11 +5,12 @@
 //
 // MI355X formulation — all HBM-bound streaming, no host synchronisation:
 //   1. lovasz_prepare   per pixel: log-sum-exp; histogram of labels (class presence, |fg_c|), number of valid pixels
-//   2. lovasz_emit      one 64-bit key per (class, pixel):  class << 33 | invalid << 32 | ~bits(|fg - p_c|)
-//                       value = pixel index | fg << 31.  Ascending key order == classes ascending, errors DESCENDING,
-//                       ignored pixels last inside their class.
-//   3. ONE device-wide radix sort of C*P pairs over 33 + log2(C) bits (rocPRIM radix_sort_pairs, double buffered) — the
-//      per-class sorts of the reference become a single bandwidth-bound pass set (8 B + 4 B per element per pass).
+//   2. lovasz_emit      one 64-bit word per (class, pixel):  [class | invalid | ~bits30(|fg - p_c|) | fg | pixel index]
+//                       (errors lie in [0, 2): their float bits fit 30 bits).  Ascending order of the upper field == classes
+//                       ascending, errors DESCENDING, ignored pixels last inside their class; the low PB + 1 bits are payload.
+//   3. ONE device-wide radix sort of C*P keys over the upper 31 + log2(C) bits only (rocPRIM radix_sort_keys, double buffered,
+//      begin_bit = PB + 1): the per-class sorts of the reference become a single bandwidth-bound pass set of 8 B per element
+//      per pass with the payload riding inside the key (key + value pairs over 41 bits cost 1.8x the traffic).
 //   4. lovasz_chunk_count / lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index
 //      at every rank in the same float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels),
 //      first difference, dot with the sorted errors, and scatter of d loss / d p into G[pixel, class].
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
 
 // thread per pixel, loop over classes: writes are coalesced along pixels for each class
 __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
-                                                          const float* __restrict__ lse, long rows, int C, long ignore,
-                                                          unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                          const float* __restrict__ lse, long rows, int C, long ignore, int PB,
+                                                          unsigned long long* __restrict__ keys) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     const long t = target[r];
@@ -85,25 +86,24 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restric
         const float p = expf(row[c] - l);
         const bool fg = valid && t == c;
         const float e = fabsf((fg ? 1.f : 0.f) - p);
-        const unsigned long long key = ((unsigned long long)c << 33) | ((unsigned long long)(valid ? 0 : 1) << 32) |
-                                       (unsigned long long)(~__float_as_uint(e));
-        keys[(long)c * rows + r] = key;
-        vals[(long)c * rows + r] = (unsigned)r | (fg ? 0x80000000u : 0u);
+        const unsigned long long inv30 = (unsigned long long)((~__float_as_uint(e)) & 0x3FFFFFFFu);
+        keys[(long)c * rows + r] = ((((unsigned long long)c << 1 | (valid ? 0ull : 1ull)) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
+                                   (unsigned long long)r;
     }
 }
 
 // chunk_fg[c][k] = number of fg elements among ranks [k*CHUNK, (k+1)*CHUNK) (ranks < n_valid only)
-__global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned* __restrict__ vals, long rows, int nchunks,
-                                                                 const unsigned* __restrict__ counts, int C,
+__global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned long long* __restrict__ keys, long rows, int nchunks,
+                                                                 const unsigned* __restrict__ counts, int C, int PB,
                                                                  unsigned* __restrict__ chunk_fg) {
     const int c = blockIdx.y, k = blockIdx.x;
     if (counts[c] == 0) return;                          // absent class: skipped by classes='present'
     const long nv = counts[C];
-    const unsigned* v = vals + (long)c * rows;
+    const unsigned long long* v = keys + (long)c * rows;
     unsigned n = 0;
     for (int j = threadIdx.x; j < CHUNK; j += 256) {
         const long i = (long)k * CHUNK + j;
-        if (i < nv) n += v[i] >> 31;
+        if (i < nv) n += (unsigned)((v[i] >> PB) & 1ull);
     }
     n = (unsigned)wave_sum((float)n);                    // < 2048: exact in fp32
     __shared__ unsigned sm[4];
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
 }
 
 // Jaccard gradient at every rank, dot product with the sorted errors, scatter of d loss_c / d p into G
-__global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
-                                                              long rows, int nchunks, const unsigned* __restrict__ counts, int C,
+__global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys,
+                                                              long rows, int nchunks, const unsigned* __restrict__ counts, int C, int PB,
                                                               const unsigned* __restrict__ chunk_fg, float* __restrict__ G, int ldg,
                                                               double* __restrict__ part) {
     const int c = blockIdx.y, k = blockIdx.x;
@@ -146,15 +146,14 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
     const long nv = counts[C];
     const float gts = (float)counts[c];
     const unsigned long long* kk = keys + (long)c * rows;
-    const unsigned* v = vals + (long)c * rows;
     // each thread owns 8 consecutive ranks
     const long i0 = (long)k * CHUNK + threadIdx.x * 8;
-    unsigned vv[8];
+    unsigned long long vv[8];
     unsigned local = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        vv[j] = (i0 + j < nv) ? v[i0 + j] : 0u;
-        local += vv[j] >> 31;
+        vv[j] = (i0 + j < nv) ? kk[i0 + j] : 0ull;
+        local += (unsigned)((vv[j] >> PB) & 1ull);
     }
     // block exclusive scan of `local`
     __shared__ unsigned sm[256];
@@ -172,11 +171,11 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
     for (int j = 0; j < 8; ++j) {
         const long i = i0 + j;
         if (i < nv) {
-            const unsigned fg = vv[j] >> 31;
-            const unsigned pix = vv[j] & 0x7fffffffu;
-            const unsigned long long key = kk[i];
-            const bool invalid = (key >> 32) & 1ull;       // an ignored pixel inside the valid range only through an e == 0 tie
-            const float e = invalid ? 0.f : __uint_as_float(~(unsigned)(key & 0xffffffffull));
+            const unsigned long long key = vv[j];
+            const unsigned fg = (unsigned)((key >> PB) & 1ull);
+            const unsigned pix = (unsigned)(key & ((1ull << PB) - 1ull));
+            const bool invalid = (key >> (PB + 31)) & 1ull;       // cannot occur below n_valid (ignored pixels sort last); kept as a guard
+            const float e = invalid ? 0.f : __uint_as_float((~(unsigned)(key >> (PB + 1))) & 0x3FFFFFFFu);
             // lovasz_grad (utils/lovasz_losses.py:19-31) in the same fp32 arithmetic
             const float cum_prev = (float)cum, cum_now = (float)(cum + fg);
             const float inter = gts - cum_now, uni = gts + ((float)(i + 1) - cum_now);
@@ -272,8 +271,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
 }
 
 struct LovaszLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, chunk_fg, counts, part, temp, total;
-    int nchunks, end_bit;
+    size_t keys_a, keys_b, chunk_fg, counts, part, temp, total;
+    int nchunks, begin_bit, end_bit, PB;
     size_t temp_bytes;
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -284,20 +283,22 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
     L->nchunks = (int)((rows + CHUNK - 1) / CHUNK);
     int cb = 1;
     while ((1 << cb) < C) ++cb;
-    L->end_bit = 33 + cb;
+    int pb = 1;
+    while ((1L << pb) < rows) ++pb;
+    if (cb + pb + 32 > 64) return false;                  // class | invalid | 30-bit error | fg | pixel must fit one 64-bit key
+    L->PB = pb;
+    L->begin_bit = pb + 1;
+    L->end_bit = pb + 32 + cb;
     size_t off = 0;
     L->keys_a = off; off += align256(n * 8);
     L->keys_b = off; off += align256(n * 8);
-    L->vals_a = off; off += align256(n * 4);
-    L->vals_b = off; off += align256(n * 4);
     L->chunk_fg = off; off += align256((size_t)C * L->nchunks * 4);
     L->counts = off; off += align256((size_t)(C + 1) * 4);
     L->part = off; off += align256((size_t)C * L->nchunks * 8);
     // rocPRIM temporary storage (histograms / lookback state): a host-side size query, nothing is launched
     size_t tb = 0;
     rocprim::double_buffer<unsigned long long> dk(nullptr, nullptr);
-    rocprim::double_buffer<unsigned> dv(nullptr, nullptr);
-    if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0u, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
+    if (rocprim::radix_sort_keys(nullptr, tb, dk, n, (unsigned)L->begin_bit, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
     L->temp_bytes = tb;
     L->temp = off; off += align256(tb);
     L->total = off;
@@ -324,8 +325,6 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     char* ws = (char*)workspace;
     unsigned long long* ka = (unsigned long long*)(ws + L.keys_a);
     unsigned long long* kb = (unsigned long long*)(ws + L.keys_b);
-    unsigned* va = (unsigned*)(ws + L.vals_a);
-    unsigned* vb = (unsigned*)(ws + L.vals_b);
     unsigned* chunk_fg = (unsigned*)(ws + L.chunk_fg);
     unsigned* counts = (unsigned*)(ws + L.counts);
     double* part = (double*)(ws + L.part);
@@ -337,17 +336,15 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(C + 1) * 4, st, logits, ld, target, rows, C,
                        ignore_index, lse, counts);
     hipLaunchKernelGGL(lovasz_emit_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ld, target, (const float*)lse,
-                       rows, C, ignore_index, ka, va);
+                       rows, C, ignore_index, L.PB, ka);
     rocprim::double_buffer<unsigned long long> dk(ka, kb);
-    rocprim::double_buffer<unsigned> dv(va, vb);
     size_t tb = L.temp_bytes;
-    if (rocprim::radix_sort_pairs(ws + L.temp, tb, dk, dv, (size_t)rows * C, 0u, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
+    if (rocprim::radix_sort_keys(ws + L.temp, tb, dk, (size_t)rows * C, (unsigned)L.begin_bit, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
     const unsigned long long* ks = dk.current();
-    const unsigned* vs = dv.current();
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
-    hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, vs, rows, L.nchunks, (const unsigned*)counts, C, chunk_fg);
+    hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
-    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid, dim3(256), 0, st, ks, vs, rows, L.nchunks, (const unsigned*)counts, C,
+    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
                        (const unsigned*)chunk_fg, G, ldg, part);
     hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
     return segmi_launch_status();
