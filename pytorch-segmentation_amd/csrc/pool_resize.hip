@@ -335,17 +335,19 @@ __global__ __launch_bounds__(256) void pyramid_bwd_kernel(float* __restrict__ dx
         const int w = (int)(r % g.W);
         const long t = r / g.W;
         const int h = (int)(t % g.H), n = (int)(t / g.H);
+        // the pixel's cell (no divisions: <= 24 breakpoints per axis), then every window whose segment range covers the cell
+        int sh = 0, sw = 0;
+        while (g.ah.brk[sh + 1] <= h) ++sh;
+        while (g.aw.brk[sw + 1] <= w) ++sw;
         float4 acc = zero4();
         for (int l = 0; l < g.nl; ++l) {
             const int b = g.bins[l];
-            const int ic = (int)(((long)h * b) / g.H), jc = (int)(((long)w * b) / g.W);
-            for (int i = max(ic - 1, 0); i <= min(ic + 1, b - 1); ++i) {
-                const int h0 = aap_start(i, g.H, b), h1 = aap_end(i, g.H, b);
-                if (h < h0 || h >= h1) continue;
-                for (int j = max(jc - 1, 0); j <= min(jc + 1, b - 1); ++j) {
-                    const int w0 = aap_start(j, g.W, b), w1 = aap_end(j, g.W, b);
-                    if (w < w0 || w >= w1) continue;
-                    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+            for (int i = 0; i < b; ++i) {
+                if (sh < g.ah.lo[l][i] || sh >= g.ah.hi[l][i]) continue;
+                const int hh = g.ah.brk[g.ah.hi[l][i]] - g.ah.brk[g.ah.lo[l][i]];
+                for (int j = 0; j < b; ++j) {
+                    if (sw < g.aw.lo[l][j] || sw >= g.aw.hi[l][j]) continue;
+                    const float inv = 1.f / (float)(hh * (g.aw.brk[g.aw.hi[l][j]] - g.aw.brk[g.aw.lo[l][j]]));
                     const float4 v = ld4(p.dy[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4);
                     acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
                 }
