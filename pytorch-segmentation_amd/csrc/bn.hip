@@ -90,15 +90,23 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
     const bool cok = c < Cp;
     float n = 0.f, m = 0.f, q = 0.f;
     if (cok) {
-#pragma unroll 4
-        for (int i = threadIdx.y; i < nparts; i += 16) {
-            const float* p = part + (long)i * 3 * Cp;
-            const float nb = p[c];
-            if (nb > 0.f) {
-                const float nn = n + nb;
-                chan1(n, m, q, nb, p[Cp + c], p[2 * Cp + c], nn);
-                n = nn;
+        // four partials per step are loaded unconditionally BEFORE the (serial) Chan merges, so 12 loads are in flight at once
+        for (int i0 = threadIdx.y; i0 < nparts; i0 += 64) {
+            float nb[4], mb[4], qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 16 * u;
+                const bool ok = i < nparts;
+                const float* p = part + (long)(ok ? i : 0) * 3 * Cp;
+                nb[u] = ok ? p[c] : 0.f; mb[u] = p[Cp + c]; qb[u] = p[2 * Cp + c];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (nb[u] > 0.f) {
+                    const float nn = n + nb[u];
+                    chan1(n, m, q, nb[u], mb[u], qb[u], nn);
+                    n = nn;
+                }
         }
     }
     __shared__ float sn[16][17], sm[16][17], sq[16][17];
@@ -238,9 +246,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
     const int i = blockIdx.x * 32 + threadIdx.x;
     float a = 0.f;
-    if (i < n)
-#pragma unroll 4
-        for (int p = threadIdx.y; p < nparts; p += 8) a += part[(long)p * n + i];
+    if (i < n) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent loads per step
+        int p = threadIdx.y;
+        for (; p + 24 < nparts; p += 32) {
+            a0 += part[(long)p * n + i]; a1 += part[(long)(p + 8) * n + i];
+            a2 += part[(long)(p + 16) * n + i]; a3 += part[(long)(p + 24) * n + i];
+        }
+        for (; p < nparts; p += 8) a0 += part[(long)p * n + i];
+        a = (a0 + a1) + (a2 + a3);
+    }
     __shared__ float sm[8][33];
     sm[threadIdx.y][threadIdx.x] = a;
     __syncthreads();
