@@ -774,19 +774,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         }
     }
 
+    // epilogue through LDS like the fprop kernel: 16-byte stores of 4 consecutive input channels
     float* out = p.out + (long)split * p.split_stride;
     const int RS = p.R * p.S;
+    constexpr int EP = 36;
+    float* stage = smem + wave * (TM * 32 * EP);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int c = c0 + wn0 + j * 32 + lrow32;
-        const bool cok = c < p.C;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = k0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                if (cok && k < p.K) out[((long)k * RS + tap) * p.C + c] = acc[i][j][e];
-            }
+            for (int e = 0; e < 16; ++e) stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * EP + lrow32] = acc[i][j][e];
+        const int c = c0 + wn0 + j * 32 + ec;
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) {
+            const int row = q * 8 + er;
+            const int k = k0 + wm0 + row;
+            const float4 v = ld4(stage + row * EP + ec);
+            if (c < p.C && k < p.K) st4(out + ((long)k * RS + tap) * p.C + c, v);
         }
     }
 }
