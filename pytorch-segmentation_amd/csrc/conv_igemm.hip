@@ -40,6 +40,9 @@ struct GatherParams {
     // (LDS-DMA kernel only): partial tiles go to `ws` [ksplit][M][ldd] and are summed by splitk_reduce_kernel
     int ksplit, its_per_split;
     float* ws;
+    // fprop with Cs == 4 (the RGB stems, channels padded 3 -> 4): the reduction axis is re-indexed as j = tap*4 + c so that a
+    // 32-wide chunk holds 8 taps x 4 channels instead of one tap's 4 channels + 28 zeros (7x7 stem: 7 chunks instead of 49)
+    int pack4;
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -336,6 +339,20 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
                 const bool ok = cok && ((a_mask[i] >> tap) & 1u);
                 dma16(src_rsrc, ok ? (unsigned)(a_base[i] + tap_off) * 4u : OOB, As + i * (32 * BK * 4));
             }
+        } else if (MODE == MODE_FPROP && p.pack4) {
+            const int tapl = (c0 >> 2) + kg;                 // this lane's tap: 8 taps x 4 channels per chunk
+            const bool tok = tapl < RS;
+            const int r2 = tapl / p.S, s2 = tapl - r2 * p.S;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int hs = a_bh[i] + r2 * p.dil, ws = a_bw[i] + s2 * p.dil;
+                const bool ok = a_ok[i] && tok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+                dma16(src_rsrc, ok ? (unsigned)(a_pix[i] + hs * p.Ws + ws) * (unsigned)p.lds * 4u : OOB, As + i * (32 * BK * 4));
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                dma16(wgt_rsrc, (tok && b_off[i] != OOB) ? (b_off[i] + (unsigned)tapl * 4u) * 4u : OOB, Bs + i * (32 * BK * 4));
+            return;
         } else
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -371,12 +388,15 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nchunk = (p.Cs + BK - 1) / BK;
-    const int Tall = nchunk * RS;
+    const bool pk = MODE == MODE_FPROP && !FAST && p.pack4;
+    const int RSl = pk ? 1 : RS;                         // taps folded into the chunk axis when packed
+    const int nchunk = ((pk ? RS * 4 : p.Cs) + BK - 1) / BK;
+    const int Tall = nchunk * RSl;
     const int it0 = blockIdx.y * p.its_per_split;        // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
     const int T = min(Tall, it0 + p.its_per_split);
-    int c0 = (it0 / RS) * BK, r = (it0 % RS) / p.S, s = (it0 % RS) % p.S;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
+    int c0 = (it0 / RSl) * BK, r = (it0 % RSl) / p.S, s = (it0 % RSl) % p.S;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
     auto advance = [&]() {
+        if (pk) { c0 += BK; return; }
         if (++s == p.S) { s = 0; if (++r == p.R) { r = 0; c0 += BK; } }
     };
 
@@ -477,6 +497,7 @@ struct WgradParams {
     int tiles_k, tiles_c;
     int chunks_per_split;  // in units of BKP pixels
     long split_stride;     // K*R*S*C
+    int pack4;             // C == 4: the N axis of the GEMM is j = tap*4 + c (all taps in one tile) instead of one tile per tap
 };
 
 template <int BM, int BN, int BKP, int WM, int WN>
@@ -635,12 +656,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 
     // tile = (c-tile, k-tile, tap) with the tap fastest, and each XCD owning a contiguous range of tile ids:
     // an XCD's L2 then holds only ITS channel slices of x (read once per tap from L2, not from HBM) plus dy.
-    const int RSn = p.R * p.S;
+    const int RSn = p.pack4 ? 1 : p.R * p.S;
     int tidx = (int)xcd_swizzle(blockIdx.x, gridDim.x);
     const int tap = tidx % RSn; tidx /= RSn;
     const int tk = tidx % p.tiles_k; tidx /= p.tiles_k;
     const int tc = tidx;
-    const int r = tap / p.S, s = tap - r * p.S;
     const int k0 = tk * BM, c0 = tc * BN;
     const int split = blockIdx.y;
     const int mbeg = split * p.chunks_per_split * BKP;
@@ -655,7 +675,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     const int a_rl = lane / A_LPR, a_col = (lane % A_LPR) * 4;
     const int b_rl = lane / B_LPR, b_col = (lane % B_LPR) * 4;
     const bool a_cok = (k0 + a_col) < ((p.K + 3) & ~3);          // dy rows own zero-filled channel padding up to 4
-    const bool b_cok = (c0 + b_col) < p.C;
+    // B columns: channels c0 + b_col of the tile's tap, or (pack4) tap (c0 + b_col)/4 with all 4 channels — per-lane tap then
+    const int ltap = p.pack4 ? (c0 + b_col) >> 2 : tap;
+    const int r = ltap / p.S, s = ltap - r * p.S;
+    const bool b_cok = p.pack4 ? ltap < p.R * p.S : (c0 + b_col) < p.C;
+    const int b_ch = p.pack4 ? 0 : c0 + b_col;                   // channel offset inside the source pixel
     int b_n[B_IT], b_p[B_IT], b_q[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -694,7 +718,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 dma16(dy_rsrc, a_const[i] == OOB ? OOB : a_chunk + a_const[i], As + (i * 4 + wave) * A_RPI * (BM * 4));
             const int hs = cp * p.stride + tap_h;                                               // scalar
             const bool hok = (unsigned)hs < (unsigned)p.H;
-            const int rowbase = ((cn * p.H + hs) * p.W) * p.ldx + c0 + b_col;
+            const int rowbase = ((cn * p.H + hs) * p.W) * p.ldx + b_ch;
             const int wq = cq * p.stride;
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             const int m = mb + row0 + b_rl;
             const int hs = b_p[i] * p.stride + tap_h, ws = b_q[i] * p.stride + tap_w;
             const bool ok = b_cok && m < mend && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
-            const unsigned off = ((unsigned)((b_n[i] * p.H + hs) * p.W + ws) * (unsigned)p.ldx + (unsigned)(c0 + b_col)) * 4u;
+            const unsigned off = ((unsigned)((b_n[i] * p.H + hs) * p.W + ws) * (unsigned)p.ldx + (unsigned)b_ch) * 4u;
             dma16(x_rsrc, ok ? off : OOB, Bs + row0 * (BN * 4));
             b_q[i] += BKP;
             while (b_q[i] >= p.Q) {
@@ -792,7 +816,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             const int row = q * 8 + er;
             const int k = k0 + wm0 + row;
             const float4 v = ld4(stage + row * EP + ec);
-            if (c < p.C && k < p.K) st4(out + ((long)k * RS + tap) * p.C + c, v);
+            if (c < (p.pack4 ? RS * 4 : p.C) && k < p.K) st4(out + ((long)k * RS + tap) * p.C + c, v);   // pack4: tap == 0, c runs over tap*4 + ch
         }
     }
 }
@@ -888,8 +912,9 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     p.tiles_m = segmi_cdiv(p.M, BM);
     p.tiles_n = segmi_cdiv(p.Cd, BN);
     const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-    const bool fast = p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
-    const int Tall = segmi_cdiv(p.Cs, 32) * p.R * p.S;
+    p.pack4 = (MODE == MODE_FPROP && p.Cs == 4 && p.R * p.S > 1 && p.ksplit <= 1) ? 1 : 0;
+    const bool fast = !p.pack4 && p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
+    const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
     if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
@@ -953,15 +978,18 @@ bool desc_ok(const segmi_conv_desc* d) {
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-struct WgradPlan { int bm, bn, tiles_k, tiles_c, nsplit, chunks_per_split; };
+struct WgradPlan { int bm, bn, tiles_k, tiles_c, nsplit, chunks_per_split, pack4; };
 constexpr int WG_BKP = 32;
+bool wgrad_dma_desc(const segmi_conv_desc* d);
 WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     WgradPlan pl;
+    pl.pack4 = (d->C == 4 && d->R * d->S > 1 && wgrad_dma_desc(d)) ? 1 : 0;   // RGB stems: fold the taps into the N axis
+    const int Cv = pl.pack4 ? d->R * d->S * 4 : d->C;
     pl.bm = d->K > 64 ? 128 : 64;
-    pl.bn = d->C > 64 ? 128 : 64;
+    pl.bn = Cv > 64 ? 128 : 64;
     pl.tiles_k = segmi_cdiv(d->K, pl.bm);
-    pl.tiles_c = segmi_cdiv(d->C, pl.bn);
-    const long tiles = (long)pl.tiles_k * pl.tiles_c * d->R * d->S;
+    pl.tiles_c = segmi_cdiv(Cv, pl.bn);
+    const long tiles = (long)pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : d->R * d->S);
     const long M = (long)d->N * d->P * d->Q;
     const long chunks = (M + WG_BKP - 1) / WG_BKP;
     // Split the pixel reduction until the grid is >= 8 "rounds" of the 512 resident workgroups (two 64 KB-LDS workgroups
@@ -1020,6 +1048,9 @@ bool dma_eligible_fwd(const segmi_conv_desc* d) {
     return conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->K * d->R * d->S * d->C);
 }
 
+bool wgrad_dma_desc(const segmi_conv_desc* d) {
+    return conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
+}
 bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
     *xb = span32((long)p.N * p.H * p.W * p.ldx);
     *dyb = span32((long)p.N * p.P * p.Q * p.ldy);
@@ -1029,7 +1060,7 @@ bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
 template <int BM, int BN>
 int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
-    dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * p.R * p.S), (unsigned)pl.nsplit);
+    dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : p.R * p.S)), (unsigned)pl.nsplit);
     unsigned xb, dyb;
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
@@ -1111,7 +1142,7 @@ int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy
     p.P = d->P; p.Q = d->Q; p.K = d->K; p.ldy = d->ldy;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->P * d->Q;
-    p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c; p.chunks_per_split = pl.chunks_per_split;
+    p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c; p.chunks_per_split = pl.chunks_per_split; p.pack4 = pl.pack4;
     p.split_stride = (long)d->K * d->R * d->S * d->C;
     int rc;
     if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128>(p, pl, st);
@@ -1143,7 +1174,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
-        const bool fast = d->R * d->S <= 32 && (op == 0 || d->stride == 1);
+        const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1);
         snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
                  fast ? "true" : "false");
         return SEGMI_OK;
