@@ -43,6 +43,12 @@ struct GatherParams {
     // fprop with Cs == 4 (the RGB stems, channels padded 3 -> 4): the reduction axis is re-indexed as j = tap*4 + c so that a
     // 32-wide chunk holds 8 taps x 4 channels instead of one tap's 4 channels + 28 zeros (7x7 stem: 7 chunks instead of 49)
     int pack4;
+    // dgrad with stride > 1, decomposed by output parity class (ph, pw): the rows of this launch are the pixels
+    // (n, hc*os + ph, wc*os + pw); only the taps whose source index is integral for the class are visited (a 3x3 stride-2
+    // dgrad evaluates 1/2/2/4 of its 9 taps per class instead of 9 zero-padded ones), with per-tap source offsets and filter
+    // tap ids from the tables below.  R = 1, S = ntaps for the loop logic; wRS = the filter's real tap count.
+    int sub, Hc, Wc, ph, pw, os, wRS;
+    int tab_r[16], tab_s[16], tab_w[16];
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -295,15 +301,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         const int m = m0 + i * 32 + rl;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int hw = p.Hd * p.Wd;
+        const bool sub = MODE == MODE_DGRAD && FAST && p.sub;
+        const int Hr = sub ? p.Hc : p.Hd, Wr = sub ? p.Wc : p.Wd;   // row space of this launch
+        const int hw = Hr * Wr;
         const int n = mm / hw, rem = mm - n * hw;
-        const int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+        const int hd = rem / Wr, wd = rem - hd * Wr;
         a_pix[i] = n * p.Hs * p.Ws;
         if (MODE == MODE_FPROP) { a_bh[i] = hd * p.stride - p.pad; a_bw[i] = wd * p.stride - p.pad; }
+        else if (sub)           { a_bh[i] = hd;                    a_bw[i] = wd; }
         else                    { a_bh[i] = hd + p.pad;            a_bw[i] = wd + p.pad; }
         a_ok[i] = ok;
     }
     const int RS = p.R * p.S;
+    const bool subm = MODE == MODE_DGRAD && FAST && p.sub;
     int a_base[A_IT];
     unsigned a_mask[A_IT];
     if (FAST) {
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             unsigned mk = 0;
             for (int t2 = 0; t2 < RS; ++t2) {
                 const int r2 = t2 / p.S, s2 = t2 - r2 * p.S;
-                const int hs = a_bh[i] + sgn * r2 * p.dil, ws = a_bw[i] + sgn * s2 * p.dil;
+                const int hs = subm ? a_bh[i] + p.tab_r[t2] : a_bh[i] + sgn * r2 * p.dil;
+                const int ws = subm ? a_bw[i] + p.tab_s[t2] : a_bw[i] + sgn * s2 * p.dil;
                 if (a_ok[i] && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws) mk |= 1u << t2;
             }
             a_mask[i] = mk;
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int k = n0 + i * 32 + rl;
-        b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)(RS * p.Cs) : OOB;
+        b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)((subm ? p.wRS : RS) * p.Cs) : OOB;
     }
 
     auto issue = [&](int r, int s, int c0, int buf) {
@@ -333,11 +344,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         const bool cok = c < p.Cs;
         if (FAST) {
             const int tap = r * p.S + s;
-            const int tap_off = (MODE == MODE_FPROP ? 1 : -1) * (r * p.dil * p.Ws + s * p.dil) * p.lds + c;   // wave-uniform + lane's channel
+            const int tap_off = (subm ? (p.tab_r[tap] * p.Ws + p.tab_s[tap]) * p.lds
+                                      : (MODE == MODE_FPROP ? 1 : -1) * (r * p.dil * p.Ws + s * p.dil) * p.lds) + c;   // wave-uniform + lane's channel
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const bool ok = cok && ((a_mask[i] >> tap) & 1u);
                 dma16(src_rsrc, ok ? (unsigned)(a_base[i] + tap_off) * 4u : OOB, As + i * (32 * BK * 4));
+            }
+            if (subm) {
+                const unsigned tapc2 = (unsigned)(p.tab_w[tap] * p.Cs + c);
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i)
+                    dma16(wgt_rsrc, (cok && b_off[i] != OOB) ? (b_off[i] + tapc2) * 4u : OOB, Bs + i * (32 * BK * 4));
+                return;
             }
         } else if (MODE == MODE_FPROP && p.pack4) {
             const int tapl = (c0 >> 2) + kg;                 // this lane's tap: 8 taps x 4 channels per chunk
@@ -389,18 +408,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const bool pk = MODE == MODE_FPROP && !FAST && p.pack4;
-    const int RSl = pk ? 1 : RS;                         // taps folded into the chunk axis when packed
+    const int RSl = pk ? 1 : (RS > 0 ? RS : 1);          // taps folded into the chunk axis when packed (RS == 0: empty parity class)
     const int nchunk = ((pk ? RS * 4 : p.Cs) + BK - 1) / BK;
     const int Tall = nchunk * RSl;
     const int it0 = blockIdx.y * p.its_per_split;        // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
     const int T = min(Tall, it0 + p.its_per_split);
-    int c0 = (it0 / RSl) * BK, r = (it0 % RSl) / p.S, s = (it0 % RSl) % p.S;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
+    const int Sl = p.S > 0 ? p.S : 1;
+    int c0 = (it0 / RSl) * BK, r = (it0 % RSl) / Sl, s = (it0 % RSl) % Sl;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
     auto advance = [&]() {
         if (pk) { c0 += BK; return; }
         if (++s == p.S) { s = 0; if (++r == p.R) { r = 0; c0 += BK; } }
     };
 
-    issue(r, s, c0, 0);
+    if (it0 < T) issue(r, s, c0, 0);                     // T == 0: a parity class without taps (its pixels are zeros)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
@@ -476,7 +496,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             const int m = m0 + wm0 + row;
             float4 v = ld4(stage + row * EP + ec);        // same wave wrote it: LDS is in order per wave
             if (kok && m < p.M) {
-                float* o = p.dst + (long)m * p.ldd + k;
+                long pix = m;
+                if (subm) {                               // parity-class launch: row -> (n, hc*os + ph, wc*os + pw)
+                    const int hw = p.Hc * p.Wc;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int hc = rem / p.Wc, wc = rem - hc * p.Wc;
+                    pix = ((long)n * p.Hd + (hc * p.os + p.ph)) * p.Wd + (wc * p.os + p.pw);
+                }
+                float* o = p.dst + pix * p.ldd + k;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (p.accumulate) { const float4 u = ld4(o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
                 st4(o, v);
@@ -915,7 +942,7 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     p.pack4 = (MODE == MODE_FPROP && p.Cs == 4 && p.R * p.S > 1 && p.ksplit <= 1) ? 1 : 0;
     const bool fast = !p.pack4 && p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
-    if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall; }
+    if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
     if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
     else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
@@ -954,7 +981,7 @@ bool dma_half_m(int M, int Cd) {
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
-    const unsigned wb = span32((long)p.Cd * p.R * p.S * p.Cs);
+    const unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
     if (conv_dma() && sb && wb) {
         const bool half_m = dma_half_m(p.M, p.Cd);
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
@@ -1093,7 +1120,7 @@ int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, c
     p.Hd = d->P; p.Wd = d->Q; p.Cd = d->K; p.ldd = d->ldy;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->P * d->Q; p.accumulate = accumulate;
-    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr;
+    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
     const FwdSplit fs = plan_fwd_split(d);
     if (fs.ksplit > 1 && !accumulate && !bias && dma_eligible_fwd(d) && workspace) {      // workspace == NULL: caller opts out of the split
         if (workspace_bytes < segmi_conv2d_fwd_workspace(d) || !aligned16(workspace)) return SEGMI_ERR_WORKSPACE;
@@ -1115,8 +1142,37 @@ int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w
     p.Hd = d->H; p.Wd = d->W; p.Cd = d->C; p.ldd = d->ldx;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->H * d->W; p.accumulate = accumulate;
-    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr;
-    return dispatch_gather<MODE_DGRAD>(p, (hipStream_t)stream);
+    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
+    const int st = d->stride;
+    const bool dma_ok = conv_dma() && span32((long)d->N * d->P * d->Q * d->ldy) && span32((long)d->C * d->R * d->S * Kpad);
+    if (st == 1 || !dma_ok || d->R * d->S > 16) return dispatch_gather<MODE_DGRAD>(p, (hipStream_t)stream);
+    // stride > 1: one launch per output parity class, visiting only the taps that exist for the class
+    for (int ph = 0; ph < st && ph < d->H; ++ph)
+        for (int pw = 0; pw < st && pw < d->W; ++pw) {
+            GatherParams q = p;
+            q.sub = 1; q.ph = ph; q.pw = pw; q.os = st; q.wRS = d->R * d->S;
+            q.Hc = (d->H - ph + st - 1) / st; q.Wc = (d->W - pw + st - 1) / st;
+            q.M = d->N * q.Hc * q.Wc;
+            int nt = 0;
+            for (int r = 0; r < d->R; ++r) {
+                const int th = ph + d->pad - r * d->dil;
+                if (((th % st) + st) % st) continue;
+                for (int s2 = 0; s2 < d->S; ++s2) {
+                    const int tw = pw + d->pad - s2 * d->dil;
+                    if (((tw % st) + st) % st) continue;
+                    // floor division (th may be negative: such sources are out of range and masked per row)
+                    q.tab_r[nt] = (th >= 0 ? th / st : -((-th + st - 1) / st));
+                    q.tab_s[nt] = (tw >= 0 ? tw / st : -((-tw + st - 1) / st));
+                    q.tab_w[nt] = r * d->S + s2;
+                    ++nt;
+                }
+            }
+            if (nt == 0 && accumulate) continue;    // nothing to add to this class's pixels
+            q.R = 1; q.S = nt; q.stride = 1;        // loop logic of the kernel: nt taps, unit stride in the class's row space
+            const int rc = dispatch_gather<MODE_DGRAD>(q, (hipStream_t)stream);
+            if (rc != SEGMI_OK) return rc;
+        }
+    return SEGMI_OK;
 }
 
 size_t segmi_conv2d_wgrad_workspace(const segmi_conv_desc* d) {
@@ -1174,7 +1230,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
-        const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1);
+        const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
         snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
                  fast ? "true" : "false");
         return SEGMI_OK;

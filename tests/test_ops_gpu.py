@@ -442,3 +442,23 @@ def test_conv_fwd_splitk_tiny_outputs(cuda, case):
     yd.backward(gy.to(cuda))
     for a, r, what in ((yd, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
         assert (a.detach().cpu() - r.detach()).abs().max().item() <= 1e-4 * r.detach().abs().max().item() + 1e-6, what
+
+
+@pytest.mark.parametrize("case", [(2, 16, 17, 19, 24, 3, 2, 1, 1), (2, 32, 16, 16, 64, 1, 2, 0, 1), (1, 8, 21, 20, 12, 3, 2, 2, 2), (2, 12, 15, 15, 8, 3, 3, 1, 1),
+                                  (2, 8, 13, 16, 16, 2, 2, 0, 1), (3, 4, 9, 9, 8, 3, 2, 1, 1)])
+def test_strided_dgrad_parity_classes(cuda, case):
+    """dgrad of strided convolutions is decomposed by output parity class (only existing taps are visited): odd sizes, 1x1
+    stride 2 (three classes without taps -> zeros), dilation with stride, stride 3, even kernels."""
+    from segmi import ops
+    N, C, H, W, K, R, stride, pad, dil = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * 0.2
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    yd = ops.conv2d(xd, w.to(cuda), None, stride, pad, dil)
+    yd.backward(gy.to(cuda))
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-5 * xr.grad.abs().max().item() + 1e-6
