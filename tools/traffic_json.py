@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Build profiles/r01_cfg2_conv_traffic.json from the two rocprofv3 PMC passes of `tools/gpu_round.sh pmc`
+(gpurun_out/pmc/{fetch,write}/r_counter_collection.csv): HBM/MALL bytes of the conv implicit-GEMM launches of ONE cfg2 step.
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-counts
+16 B/lane streaming reads by 2x; WRITE_SIZE is used as reported.  bench.py was run with --steps 1 --warmup 1, so every
+kernel's counters are summed over two steps and halved.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_cfg2_conv_traffic.json"
+STEPS = 2.0
+CONV = ("conv_dma_kernel", "conv_wgrad_dma_kernel", "splitk_reduce_kernel", "conv_gather_kernel", "conv_wgrad_kernel")
+
+
+def short(n):
+    return n.replace("void (anonymous namespace)::", "").split("(")[0]
+
+
+def load(sub, counter):
+    per, total = collections.Counter(), 0.0
+    for r in csv.DictReader(open(os.path.join(root, sub, "r_counter_collection.csv"))):
+        if r["Counter_Name"] != counter:
+            continue
+        v = float(r["Counter_Value"]) / STEPS
+        total += v
+        per[short(r["Kernel_Name"])] += v
+    return per, total
+
+
+fetch, fetch_all = load("fetch", "FETCH_SIZE")
+write, write_all = load("write", "WRITE_SIZE")
+cf = sum(v for k, v in fetch.items() if k.startswith(CONV)) * 1024.0
+cw = sum(v for k, v in write.items() if k.startswith(CONV)) * 1024.0
+doc = {
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 "
+              "--warmup 1 --no-cpu --no-roofline; MI355X, round 1 (tools/gpu_round.sh pmc + tools/traffic_json.py)",
+    "scope": "all conv implicit-GEMM launches (conv_dma_kernel*, conv_wgrad_dma_kernel*, splitk_reduce_kernel) of ONE cfg2 training step",
+    "fetch_bytes_raw": cf,
+    "fetch_bytes_corrected": 2 * cf,
+    "write_bytes": cw,
+    "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+    "traffic_bytes_per_step": 2 * cf + cw,
+    "all_kernels_fetch_bytes_raw": fetch_all * 1024.0,
+    "all_kernels_write_bytes": write_all * 1024.0,
+    "by_kernel_fetch_kb_raw": {k: int(v) for k, v in fetch.most_common(12) if k.startswith(CONV)},
+    "by_kernel_write_kb": {k: int(v) for k, v in write.most_common(12) if k.startswith(CONV)},
+    "notes": ["fetch counts Infinity-Cache (MALL) hits as well as HBM reads"],
+}
+json.dump(doc, open(out, "w"), indent=1)
+print(json.dumps({k: doc[k] for k in ("fetch_bytes_corrected", "write_bytes", "traffic_bytes_per_step")}))
