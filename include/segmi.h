@@ -124,6 +124,12 @@ int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gam
                       float momentum, int clamp_mode, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                       segmi_stream_t stream);
+/* Single-device batch statistics in one call: segmi_bn_stats followed by segmi_bn_finalize(nparts = 1) with the merge
+ * and the finalize fused into one launch (bit-identical to the two-call sequence; workspace as segmi_bn_stats). */
+int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, int clamp_mode, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                            void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* eval / frozen BN: scale/shift from running statistics */
 int segmi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                          float eps, int C, float* mean, float* invstd, float* scale, float* shift,

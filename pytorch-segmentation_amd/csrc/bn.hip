@@ -81,11 +81,34 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
+struct FinalizeArgs {               // per-channel epilogue of the statistics (bn_finalize_kernel's arithmetic)
+    const float* gamma; const float* beta; float eps, momentum; int clamp_mode;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    float* mean; float* invstd; float* scale; float* shift;
+};
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& f, int c, float n, float m, float q) {
+    const float var = q / n;  // biased
+    const float is = f.clamp_mode ? 1.f / sqrtf(fmaxf(var, f.eps)) : 1.f / sqrtf(var + f.eps);
+    f.mean[c] = m;
+    f.invstd[c] = is;
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * is;
+    f.scale[c] = sc;
+    f.shift[c] = b - m * sc;
+    if (f.running_mean) {
+        const float unbiased = q / fmaxf(n - 1.f, 1.f);
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+    }
+}
+
 // merge nparts packed partials (stride 3*Cp each) into out[3*Cp].  Block = (16 channels, 16 part lanes):
 // each lane folds parts y, y+16, ... serially (<= 32 steps at the 512-part cap), then a Chan tree over
 // the 16 lanes in LDS — the serial one-thread-per-channel form cost 160 us per BN layer.
+// FINAL: single-device BN — the merged statistics go straight to mean/invstd/scale/shift (no packed partial, no second launch)
+template <bool FINAL>
 __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int nparts, int Cp,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, FinalizeArgs fin) {
     const int c = blockIdx.x * 16 + threadIdx.x;
     const bool cok = c < Cp;
     float n = 0.f, m = 0.f, q = 0.f;
@@ -125,7 +148,12 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
         __syncthreads();
     }
     if (threadIdx.y == 0 && cok) {
-        out[c] = sn[0][threadIdx.x]; out[Cp + c] = sm[0][threadIdx.x]; out[2 * Cp + c] = sq[0][threadIdx.x];
+        if (FINAL) {
+            if (c == 0 && fin.num_batches_tracked) *fin.num_batches_tracked += 1;
+            finalize_channel(fin, c, sn[0][threadIdx.x], sm[0][threadIdx.x], sq[0][threadIdx.x]);
+        } else {
+            out[c] = sn[0][threadIdx.x]; out[Cp + c] = sm[0][threadIdx.x]; out[2 * Cp + c] = sq[0][threadIdx.x];
+        }
     }
 }
 
@@ -146,19 +174,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, i
             n = nn;
         }
     }
-    const float var = q / n;  // biased
-    const float is = clamp_mode ? 1.f / sqrtf(fmaxf(var, eps)) : 1.f / sqrtf(var + eps);
-    mean[c] = m;
-    invstd[c] = is;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sc = g * is;
-    scale[c] = sc;
-    shift[c] = b - m * sc;
-    if (running_mean) {
-        const float unbiased = q / fmaxf(n - 1.f, 1.f);
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
+    const FinalizeArgs f = {gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, nullptr, mean, invstd, scale, shift};
+    finalize_channel(f, c, n, m, q);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
@@ -206,19 +223,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
         float4 sc = zero4(), sh = zero4();
         if (RELU && !y) { sc = ld4(scale + c4 * 4); sh = ld4(shift + c4 * 4); }
-        for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
-            float4 g = ld4(dy + r * lddy + c4 * 4);
-            const float4 v = ld4(x + r * ldx + c4 * 4);
+        // four rows per trip: all 8 (12 with a saved output) loads are issued before the first use
+        const long stride = (long)gridDim.y * blockDim.y;
+        auto fold = [&](float4 g, const float4& v, const float4& o) {
             if (RELU) {
-                // ReLU mask: from the saved output, or (no residual) recomputed with the forward's own fmaf — bit-identical
-                // to what bn_apply_kernel evaluated, and one full read of y less
-                const float4 o = y ? ld4(y + r * ldy + c4 * 4)
-                                   : make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
                 g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
             }
             s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
             s1.x += g.x * (v.x - mu.x) * is.x; s1.y += g.y * (v.y - mu.y) * is.y;
             s1.z += g.z * (v.z - mu.z) * is.z; s1.w += g.w * (v.w - mu.w) * is.w;
+        };
+        // ReLU mask: from the saved output, or (no residual) recomputed with the forward's own fmaf — bit-identical
+        // to what bn_apply_kernel evaluated, and one full read of y less
+        auto outv = [&](long r, const float4& v) {
+            return y ? ld4(y + r * ldy + c4 * 4)
+                     : make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        };
+        long r = (long)blockIdx.y * blockDim.y + threadIdx.y;
+        for (; r + 3 * stride < rows; r += 4 * stride) {
+            float4 g[4], v[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { g[u] = ld4(dy + (r + u * stride) * lddy + c4 * 4); v[u] = ld4(x + (r + u * stride) * ldx + c4 * 4); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = RELU ? outv(r + u * stride, v[u]) : zero4();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold(g[u], v[u], o[u]);
+        }
+        for (; r < rows; r += stride) {
+            const float4 g = ld4(dy + r * lddy + c4 * 4), v = ld4(x + r * ldx + c4 * 4);
+            fold(g, v, RELU ? outv(r, v) : zero4());
         }
     }
     __shared__ float4 sm0[256], sm1[256];
@@ -372,7 +405,25 @@ int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, voi
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
-    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial);
+    hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial, FinalizeArgs{});
+    return segmi_launch_status();
+}
+
+int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, int clamp_mode, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                            void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!x || rows <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return SEGMI_ERR_BADARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SEGMI_ERR_BADARG;
+    if ((C & 3) || !ld_ok(ld, C)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_bn_stats_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = stats_parts(rows);
+    RowGeom g = row_geom(rows, C, 1, 1);
+    g.grid.y = parts;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
+    const FinalizeArgs f = {gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
+    hipLaunchKernelGGL((bn_stats_merge_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, (float*)nullptr, f);
     return segmi_launch_status();
 }
 
@@ -409,15 +460,20 @@ int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, floa
     return segmi_launch_status();
 }
 
-static int bwd_parts(long rows) {
-    long p = (rows + 255) / 256;
+// Row partials of the backward reduction: about 2048 blocks in total (8 per CU) whatever the channel count — a 256-channel
+// layer is one block column wide and ran on half the chip with the former rows/256 rule — but >= 16 rows per thread.
+static int bwd_parts(long rows, int C) {
+    const RowGeom g = row_geom(rows, C, 1, 1);
+    long p = 2048 / (long)g.grid.x;
+    const long cap = (rows + (long)g.ry * 16 - 1) / ((long)g.ry * 16);
+    if (p > cap) p = cap;
     if (p < 1) p = 1;
     if (p > STATS_MAX_PARTS) p = STATS_MAX_PARTS;
     return (int)p;
 }
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
     const int Cp = (C + 3) & ~3;
-    return (size_t)bwd_parts(rows) * 2 * Cp * sizeof(float);
+    return (size_t)bwd_parts(rows, C) * 2 * Cp * sizeof(float);
 }
 
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
@@ -427,7 +483,7 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && y && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_bn_bwd_reduce_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int parts = bwd_parts(rows);
+    const int parts = bwd_parts(rows, C);
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (float*)workspace);

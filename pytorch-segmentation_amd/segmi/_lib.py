@@ -48,6 +48,7 @@ SIGNATURES = {
     "segmi_bn_stats_workspace": (sz, [i64, i32]),
     "segmi_bn_stats": (i32, [vp, i32, i64, i32, vp, vp, sz, vp]),
     "segmi_bn_finalize": (i32, [vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "segmi_bn_stats_finalize": (i32, [vp, i32, i64, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),

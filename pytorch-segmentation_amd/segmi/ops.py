@@ -443,21 +443,26 @@ class _BatchNormActFn(torch.autograd.Function):
         gp = gamma.data_ptr() if gamma is not None else None
         bp = beta.data_ptr() if beta is not None else None
         count = float(rows)
-        if training:
+        rm = running_mean.data_ptr() if running_mean is not None else None
+        rv = running_var.data_ptr() if running_var is not None else None
+        nbt = num_batches_tracked.data_ptr() if num_batches_tracked is not None else None
+        if training and sync is None:
+            if rows <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            nws = lib.segmi_bn_stats_workspace(rows, C)
+            ws = workspace(nws, dev)
+            check(lib.segmi_bn_stats_finalize(x.data_ptr(), ld_of(x), rows, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
+                                              mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              ws.data_ptr(), nws, st), "bn_stats_finalize")
+        elif training:
             nws = lib.segmi_bn_stats_workspace(rows, C)
             ws = workspace(nws, dev)
             part = torch.empty(3 * C, device=dev, dtype=torch.float32)
             check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st), "bn_stats")
-            nparts, clamp = 1, 0
-            if sync is not None:
-                part, nparts, count = sync.gather_stats(part, rows)
-                clamp = sync.clamp_mode
+            part, nparts, count = sync.gather_stats(part, rows)
             if count <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
-            check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, clamp,
-                                        running_mean.data_ptr() if running_mean is not None else None,
-                                        running_var.data_ptr() if running_var is not None else None,
-                                        num_batches_tracked.data_ptr() if num_batches_tracked is not None else None,
+            check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
                                         mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
                   "bn_finalize")
         else:

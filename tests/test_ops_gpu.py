@@ -462,3 +462,36 @@ def test_strided_dgrad_parity_classes(cuda, case):
     yd = ops.conv2d(xd, w.to(cuda), None, stride, pad, dil)
     yd.backward(gy.to(cuda))
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-5 * xr.grad.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 17, 19), (8, 256, 64, 64), (1, 12, 5, 3)])
+def test_bn_stats_finalize_fused_equals_two_calls(cuda, shape):
+    """segmi_bn_stats_finalize (merge + finalize in one launch) is bit-identical to segmi_bn_stats -> segmi_bn_finalize."""
+    from segmi import ops
+    from segmi._lib import lib
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = ops.to_nhwc((torch.randn(N, C, H, W, generator=g) * 3 + 1).to(cuda))
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    rows, st = N * H * W, torch.cuda.current_stream().cuda_stream
+    nws = lib.segmi_bn_stats_workspace(rows, C)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=cuda)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.full((C,), 0.25, device=cuda), torch.full((C,), 2.0, device=cuda)
+        nbt = torch.zeros((), dtype=torch.int64, device=cuda)
+        coef = torch.empty(4, C, device=cuda)
+        ptrs = [coef[i].data_ptr() for i in range(4)]
+        if fused:
+            rc = lib.segmi_bn_stats_finalize(x.data_ptr(), ops.ld_of(x), rows, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 0,
+                                             rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), *ptrs, ws.data_ptr(), nws, st)
+            assert rc == 0
+        else:
+            part = torch.empty(3 * C, device=cuda)
+            assert lib.segmi_bn_stats(x.data_ptr(), ops.ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st) == 0
+            assert lib.segmi_bn_finalize(part.data_ptr(), 1, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 0, rm.data_ptr(),
+                                         rv.data_ptr(), nbt.data_ptr(), *ptrs, st) == 0
+        outs.append((coef.clone(), rm, rv, nbt))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[1][3].item()) == 1

@@ -25,6 +25,9 @@ PROBLEMS = {
     "l4_1x1_down": (8, 2048, 64, 64, 512, 1, 1, 0, 1),
     "l3_1x1_up": (8, 256, 64, 64, 1024, 1, 1, 0, 1),
     "l1_1x1": (8, 64, 128, 128, 256, 1, 1, 0, 1),
+    "l3_1x1_down": (8, 1024, 64, 64, 256, 1, 1, 0, 1),
+    "l2_1x1_up": (8, 128, 64, 64, 512, 1, 1, 0, 1),
+    "l1_1x1_down": (8, 256, 128, 128, 64, 1, 1, 0, 1),
     "stem2": (8, 64, 256, 256, 64, 3, 1, 1, 1),
     "stem3": (8, 64, 256, 256, 128, 3, 1, 1, 1),
     "aux_3x3": (8, 1024, 64, 64, 512, 3, 1, 1, 1),
