@@ -1,2 +1,3 @@
 from .base_model import BaseModel  # noqa: F401
 from .base_trainer import BaseTrainer  # noqa: F401
+from .base_dataloader import DataPrefetcher  # noqa: F401

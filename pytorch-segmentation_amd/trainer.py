@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-from base import BaseTrainer
+from base import BaseTrainer, DataPrefetcher
 from utils.metrics import AverageMeter, SegMetrics
 
 
@@ -27,6 +27,11 @@ class Trainer(BaseTrainer):
         self.metrics = SegMetrics(self.num_classes, self.device)
         self.psp = self.config["arch"]["type"][:3] == "PSP"
         self.iteration_losses = []
+        # side-stream H2D staging of the next batch (reference trainer.py:30-33); loaders that already yield device tensors pass through
+        if prefetch and self.device.type == "cuda":
+            self.train_loader = DataPrefetcher(self.train_loader, device=self.device)
+            if self.val_loader is not None:
+                self.val_loader = DataPrefetcher(self.val_loader, device=self.device)
 
     def _forward_loss(self, data, target):
         output = self.model(data)

@@ -163,3 +163,10 @@ def test_lr_schedulers_match_reference_sequences():
     assert torch.allclose(run(lr_scheduler.Poly), gold["Poly"], rtol=1e-12, atol=0)
     assert torch.allclose(run(lr_scheduler.Poly, warmup_epochs=1), gold["Poly_warmup"], rtol=1e-12, atol=0)
     assert torch.allclose(run(lr_scheduler.OneCycle), gold["OneCycle"], rtol=1e-12, atol=1e-18)
+
+
+def test_data_prefetcher_refuses_cpu_device():
+    """The prefetcher only stages into HBM; the trainer (like the reference, trainer.py:30) turns prefetch off on CPU."""
+    from base import DataPrefetcher
+    with pytest.raises(ValueError):
+        DataPrefetcher([], device="cpu")

@@ -86,3 +86,28 @@ def test_train_main_runs_config_json(cuda, tmp_path):
     tr = train.main(config, None)
     assert len(tr.iteration_losses) == 4 and all(torch.isfinite(v) for v in tr.iteration_losses)
     assert tr.mnt_best > 0 and os.path.exists(os.path.join(tr.checkpoint_dir, "checkpoint-epoch2.pth"))
+
+
+def test_data_prefetcher_stages_host_batches_in_order(cuda):
+    """DataPrefetcher (reference base/base_dataloader.py:49-85): pinned double-buffered side-stream H2D; batches arrive on the
+    device, in order, intact across slot reuse; stop_after keeps the reference's `count > stop_after` semantics."""
+    from base import DataPrefetcher
+    from dataloaders import Synth
+    host = Synth(num_classes=5, batch_size=2, height=64, width=48, iters=7, seed=3)
+    pf = DataPrefetcher(host, device=cuda)
+    assert len(pf) == 7 and pf.dataset is host.dataset and pf.batch_size == 2
+    seen = 0
+    for i, (x, t) in enumerate(pf):
+        assert x.is_cuda and t.is_cuda and x.dtype == torch.float32 and t.dtype == torch.int64
+        y = (x * 2.0).sum()                                   # consume on the compute stream while the next batch is in flight
+        xr, tr = host.batch(i)
+        assert torch.equal(x.cpu(), xr) and torch.equal(t.cpu(), tr)
+        assert torch.isfinite(y)
+        seen += 1
+    assert seen == 7
+    assert len(pf.slots[0].buffers) == 2 and len(pf.slots[1].buffers) == 2      # pinned buffers are reused, not re-allocated
+    assert sum(1 for _ in DataPrefetcher(host, device=cuda, stop_after=2)) == 3
+    # device-resident loaders pass through untouched
+    dev_loader = Synth(num_classes=5, batch_size=2, height=32, width=32, iters=2, seed=4, device=cuda)
+    got = [b for b in DataPrefetcher(dev_loader, device=cuda)]
+    assert len(got) == 2 and got[0][0].is_cuda
