@@ -227,7 +227,8 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
 /* LovaszSoftmax (utils/losses.py:79-89 -> utils/lovasz_losses.py:153-218, lovasz_grad :19-31), classes='present',
  * per_image=False: softmax; ignored pixels dropped; per present class sort |fg - p_c| descending, Jaccard-gradient dot;
  * mean over present classes.  One device-wide radix sort of C*rows (class, error) keys replaces the C per-class sorts.
- * G[rows, ldg] receives d loss_c / d p (un-normalised) and is consumed by the backward; loss_out[2] = {loss, n_present}.
+ * G (rows*ldg floats, ldg >= round_up(C,4); layout private to the library: class-major planes) receives d loss_c / d p
+ * (un-normalised) and is consumed by the backward; loss_out[2] = {loss, n_present}.  At most 1820 classes.
  * rows < 2^24 (the reference's fp32 cumsums are exact only below that) and log2(C) + log2(rows) <= 32.  workspace must be
  * 256-byte aligned. */
 size_t segmi_lovasz_workspace(long rows, int C);

@@ -13,7 +13,7 @@
 //      per pass with the payload riding inside the key (key + value pairs over 41 bits cost 1.8x the traffic).
 //   4. lovasz_chunk_count / lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index
 //      at every rank in the same float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels),
-//      first difference, dot with the sorted errors, and scatter of d loss / d p into G[pixel, class].
+//      first difference, dot with the sorted errors, and scatter of d loss / d p into the class-major G[class][pixel].
 //   5. lovasz_finalize  loss = mean over present classes.
 //   backward: dz_c = g * p_c * (G_c - sum_j G_j p_j) / n_present   (softmax Jacobian; G = 0 for absent classes / ignored pixels)
 //
@@ -72,23 +72,43 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
         if (hist[i]) atomicAdd(&counts[i], hist[i]);
 }
 
-// thread per pixel, loop over classes: writes are coalesced along pixels for each class
+// Block = 256 pixels.  The logits are pixel-major (a pixel's C classes are contiguous) and the keys class-major (a class's
+// pixels are contiguous): 32 classes at a time go through an LDS tile — read as 128-byte row segments (8 lanes x 16 B per
+// pixel), written as 2 KB runs of one class.  (Thread-per-pixel reads straight from HBM were 600-byte-strided dwords: 3.5 ms
+// for cfg5's 1.26 GB of logits, 4x the stream time.)
 __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                           const float* __restrict__ lse, long rows, int C, long ignore, int PB,
                                                           unsigned long long* __restrict__ keys) {
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const long t = target[r];
-    const bool valid = t != ignore;
-    const float l = lse[r];
-    const float* row = logits + r * ld;
-    for (int c = 0; c < C; ++c) {
-        const float p = expf(row[c] - l);
-        const bool fg = valid && t == c;
-        const float e = fabsf((fg ? 1.f : 0.f) - p);
-        const unsigned long long inv30 = (unsigned long long)((~__float_as_uint(e)) & 0x3FFFFFFFu);
-        keys[(long)c * rows + r] = ((((unsigned long long)c << 1 | (valid ? 0ull : 1ull)) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
-                                   (unsigned long long)r;
+    __shared__ float tile[256][33];
+    const long r0 = (long)blockIdx.x * 256;
+    const long r = r0 + threadIdx.x;
+    const bool rok = r < rows;
+    const long t = rok ? target[r] : ignore;
+    const bool valid = rok && t != ignore;
+    const float l = rok ? lse[r] : 0.f;
+    const int lr = threadIdx.x >> 3, lq = (threadIdx.x & 7) * 4;     // load role: pixel lr (+32 per pass), classes lq..lq+3 of the group
+    for (int cb = 0; cb < C; cb += 32) {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int pl = pass * 32 + lr;
+            const long rr = r0 + pl;
+            float4 v = zero4();
+            if (rr < rows && cb + lq < ld) v = ld4(logits + rr * ld + cb + lq);      // ld is a multiple of 4: whole float4 or none
+            tile[pl][lq] = v.x; tile[pl][lq + 1] = v.y; tile[pl][lq + 2] = v.z; tile[pl][lq + 3] = v.w;
+        }
+        __syncthreads();
+        const int cn = min(32, C - cb);
+        if (rok)
+            for (int j = 0; j < cn; ++j) {
+                const int c = cb + j;
+                const float p = expf(tile[threadIdx.x][j] - l);
+                const bool fg = valid && t == c;
+                const float e = fabsf((fg ? 1.f : 0.f) - p);
+                const unsigned long long inv30 = (unsigned long long)((~__float_as_uint(e)) & 0x3FFFFFFFu);
+                keys[(long)c * rows + r] = ((((unsigned long long)c << 1 | (valid ? 0ull : 1ull)) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
+                                           (unsigned long long)r;
+            }
+        __syncthreads();
     }
 }
 
@@ -139,10 +159,14 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
 // Jaccard gradient at every rank, dot product with the sorted errors, scatter of d loss_c / d p into G
 __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys,
                                                               long rows, int nchunks, const unsigned* __restrict__ counts, int C, int PB,
-                                                              const unsigned* __restrict__ chunk_fg, float* __restrict__ G, int ldg,
+                                                              const unsigned* __restrict__ chunk_fg, float* __restrict__ G,
                                                               double* __restrict__ part) {
-    const int c = blockIdx.y, k = blockIdx.x;
-    if (counts[c] == 0) return;
+    // 1-D grid; block b runs on XCD b % 8 and takes class (b/8 / nchunks)*8 + b%8: all chunks of a class scatter into that
+    // class's plane of G from ONE XCD, whose L2 (with the Infinity Cache behind it) merges the 4-byte writes into full lines.
+    // (A pixel-major G[pixel][class] received its 32 dwords per line from 32 classes at 32 different times: 4.9 ms for cfg5.)
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int c = (jb / nchunks) * 8 + xcd, k = jb % nchunks;
+    if (c >= C || counts[c] == 0) return;
     const long nv = counts[C];
     const float gts = (float)counts[c];
     const unsigned long long* kk = keys + (long)c * rows;
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
             dot += e * grad;
             // d|fg - p| / dp = -sign(fg - p);  e == 0 -> 0 (torch's abs backward uses sign)
             const float sgn = invalid || e == 0.f ? 0.f : (fg ? -1.f : 1.f);
-            G[(long)pix * ldg + c] = sgn * grad;
+            G[(long)c * rows + pix] = sgn * grad;
             cum += fg;
         }
     }
@@ -233,41 +257,62 @@ __device__ __forceinline__ float grp_sum8(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
     return v;
 }
-// dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j)
+// dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j).  G is class-major (G[c][pixel]); a block stages the [C][TP] slab of
+// its TP pixels in LDS (coalesced TP*4-byte runs per class), then 8 lanes share a pixel like the forward's prepare kernel.
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ lse,
-                                                         const float* __restrict__ G, int ldg, long rows, int C,
+                                                         const float* __restrict__ G, long rows, int C, int TP,
                                                          const float* __restrict__ loss_out, const float* __restrict__ grad_out,
                                                          float* __restrict__ dl, int lddl) {
+    extern __shared__ float gs_tile[];                   // [C][TP + 1]
+    const int pitch = TP + 1;
     const int g = threadIdx.x & (LPP - 1);
-    const long ppb = 256 / LPP;
     const int c4n = (C + 3) >> 2;
     const float np = loss_out[1];
     const float gs = np > 0.f ? grad_out[0] / np : 0.f;
-    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
-        const float l = lse[r];
-        const float* row = logits + r * ld;
-        const float* gr = G + r * ldg;
-        float s = 0.f;
-        for (int q = g; q < c4n; q += LPP) {
-            const float4 v = ld4(row + q * 4), w = ld4(gr + q * 4);
-            const int c = q * 4;
-            s += w.x * expf(v.x - l);
-            if (c + 1 < C) s += w.y * expf(v.y - l);
-            if (c + 2 < C) s += w.z * expf(v.z - l);
-            if (c + 3 < C) s += w.w * expf(v.w - l);
+    const long ntiles = (rows + TP - 1) / TP;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = tile * TP;
+        __syncthreads();                                 // previous tile's readers are done
+        for (int idx = threadIdx.x; idx < C * TP; idx += 256) {
+            const int c = idx / TP, pl = idx - c * TP;
+            gs_tile[c * pitch + pl] = r0 + pl < rows ? G[(long)c * rows + r0 + pl] : 0.f;
         }
-        s = grp_sum8(s);
-        for (int q = g; q < c4n; q += LPP) {
-            const float4 v = ld4(row + q * 4), w = ld4(gr + q * 4);
-            const int c = q * 4;
-            float4 d;
-            d.x = gs * expf(v.x - l) * (w.x - s);
-            d.y = c + 1 < C ? gs * expf(v.y - l) * (w.y - s) : 0.f;
-            d.z = c + 2 < C ? gs * expf(v.z - l) * (w.z - s) : 0.f;
-            d.w = c + 3 < C ? gs * expf(v.w - l) * (w.w - s) : 0.f;
-            st4(dl + r * lddl + q * 4, d);
+        __syncthreads();
+        for (int pl = threadIdx.x / LPP; pl < TP; pl += 256 / LPP) {
+            const long r = r0 + pl;
+            if (r >= rows) continue;                     // whole 8-lane group leaves together: the shuffles below stay matched
+            const float l = lse[r];
+            const float* row = logits + r * ld;
+            const float* gr = gs_tile + pl;
+            float s = 0.f;
+            for (int q = g; q < c4n; q += LPP) {
+                const float4 v = ld4(row + q * 4);
+                const int c = q * 4;
+                s += gr[c * pitch] * expf(v.x - l);
+                if (c + 1 < C) s += gr[(c + 1) * pitch] * expf(v.y - l);
+                if (c + 2 < C) s += gr[(c + 2) * pitch] * expf(v.z - l);
+                if (c + 3 < C) s += gr[(c + 3) * pitch] * expf(v.w - l);
+            }
+            s = grp_sum8(s);
+            for (int q = g; q < c4n; q += LPP) {
+                const float4 v = ld4(row + q * 4);
+                const int c = q * 4;
+                float4 d;
+                d.x = gs * expf(v.x - l) * (gr[c * pitch] - s);
+                d.y = c + 1 < C ? gs * expf(v.y - l) * (gr[(c + 1) * pitch] - s) : 0.f;
+                d.z = c + 2 < C ? gs * expf(v.z - l) * (gr[(c + 2) * pitch] - s) : 0.f;
+                d.w = c + 3 < C ? gs * expf(v.w - l) * (gr[(c + 3) * pitch] - s) : 0.f;
+                st4(dl + r * lddl + q * 4, d);
+            }
         }
     }
+}
+
+// pixels per backward tile: the [C][TP+1] fp32 slab must fit 64 KB of LDS
+int lovasz_bwd_tp(int C) {
+    for (int tp = 64; tp >= 8; tp >>= 1)
+        if ((size_t)C * (tp + 1) * sizeof(float) <= 64u * 1024u) return tp;
+    return 0;
 }
 
 struct LovaszLayout {
@@ -344,8 +389,9 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
     hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
-    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
-                       (const unsigned*)chunk_fg, G, ldg, part);
+    const dim3 grid1((unsigned)(8 * ((C + 7) / 8)) * (unsigned)L.nchunks);
+    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid1, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
+                       (const unsigned*)chunk_fg, G, part);
     hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
     return segmi_launch_status();
 }
@@ -354,10 +400,12 @@ int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float*
                      const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
     if (!logits || !lse || !G || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
-    long b = (rows + 31) / 32;
-    if (b > SEGMI_MAX_GRID) b = SEGMI_MAX_GRID;
-    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, logits, ld, lse, G, ldg, rows, C, loss_out,
-                       grad_out, dlogits, lddl);
+    const int tp = lovasz_bwd_tp(C);
+    if (tp == 0) return SEGMI_ERR_BADARG;               // > 1820 classes
+    long b = (rows + tp - 1) / tp;
+    if (b > 4 * SEGMI_MAX_GRID) b = 4 * SEGMI_MAX_GRID;
+    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), (size_t)C * (tp + 1) * sizeof(float), (hipStream_t)stream, logits, ld,
+                       lse, G, rows, C, tp, loss_out, grad_out, dlogits, lddl);
     return segmi_launch_status();
 }
 
