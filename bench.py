@@ -13,10 +13,11 @@ step — the reference's inner loop trainer.py:55-71.  Workload at every N: BASE
 reference's dtype; convolutions on v_mfma_f32_32x32x2_f32).
 
 Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
-  roofline     : the conv implicit-GEMM kernel family (MFMA-bound) measured with HIP events per launch
-                 in an extra instrumented step; `kernel` is the variant with the largest total time,
-                 `avg_us` its mean launch duration (compare with profiles/*kernel_stats*), `achieved`
-                 = algorithmic FLOPs / measured time over ALL conv launches of the step.
+  roofline     : the dominant kernel = the conv implicit-GEMM variant (MFMA-bound) with the largest total time,
+                 measured with HIP events per launch in an extra instrumented step: `achieved` = its algorithmic
+                 FLOPs per launch / its mean launch duration `avg_us` (compare with profiles/*kernel_stats*),
+                 `traffic` = its HBM bytes per launch from the committed rocprofv3 PMC passes; `all_conv` holds the
+                 same quantities over ALL conv launches of the step.
   cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on
                  this host's cores on a bounded sample (batch 2 of the same 512x512 workload).
 """
@@ -188,24 +189,30 @@ def main():
         with KernelTimer() as kt:
             step()
         summ = kt.summary()
-        # HBM traffic of the same scope cannot be measured live (PMC passes need rocprofv3): the committed summary of the
-        # offline FETCH_SIZE / WRITE_SIZE passes is reported (bytes per step over the conv launches, cfg2 only)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_cfg2_conv_traffic.json")
-        if args.config == "cfg2" and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["traffic_bytes_per_step"]
         tot_ms = sum(r["total_ms"] for r in summ.values())
         tot_fl = sum(r["flops"] for r in summ.values())
         top_name, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        all_ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+        # HBM traffic cannot be measured live (PMC passes need rocprofv3): the committed summary of the offline FETCH_SIZE /
+        # WRITE_SIZE passes over this same command is reported, per launch of the dominant kernel like `achieved` (cfg2 only)
+        traffic = step_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_cfg2_conv_traffic.json")
+        if args.config == "cfg2" and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            step_traffic = tj["traffic_bytes_per_step"]
+            traffic = tj.get("per_kernel", {}).get(top_name, {}).get("traffic_bytes_per_launch")
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "scope": "all conv implicit-GEMM launches of one step (fwd+dgrad+wgrad), HIP events per launch",
-                "traffic_note": "HBM+MALL bytes per step over the conv launches from rocprofv3 PMC passes (profiles/r01_cfg2_conv_traffic.json); algorithmic ~29 GB",
-                "conv_launches": sum(r["launches"] for r in summ.values()), "conv_ms_per_step": round(tot_ms, 2),
-                "conv_flops_per_step": tot_fl,
                 "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
-                "kernel_achieved": round(top["flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
+                "flops_per_launch": top["flops"] // top["launches"], "algorithmic_bytes_per_launch": top["bytes"] // top["launches"],
+                "scope": "dominant kernel = the conv implicit-GEMM variant with the largest total time in one step; HIP events per launch "
+                         "on the launch stream; traffic = HBM+MALL bytes per launch from the rocprofv3 PMC passes "
+                         "(profiles/r01_cfg2_conv_traffic.json)",
+                "all_conv": {"achieved": round(all_ach, 2), "frac": round(all_ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "launches": sum(r["launches"] for r in summ.values()), "ms_per_step": round(tot_ms, 2),
+                             "flops_per_step": tot_fl, "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
+                             "traffic_bytes_per_step": step_traffic},
                 "step_frac": round(value / world * flops_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                  "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}

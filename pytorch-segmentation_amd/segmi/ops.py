@@ -186,6 +186,11 @@ def _conv_flops(d, C):
     return 2 * d.N * d.P * d.Q * d.K * d.R * d.S * C
 
 
+def _conv_bytes(d, C):
+    """Algorithmic bytes of one conv pass: each of the three tensors (input, filter, output) crosses HBM once, fp32."""
+    return 4 * (d.N * d.H * d.W * C + d.K * d.R * d.S * C + d.N * d.P * d.Q * d.K)
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -202,7 +207,7 @@ class _Conv2dFn(torch.autograd.Function):
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
         nws = lib.segmi_conv2d_fwd_workspace(d) if bias is None else 0
         ws = workspace(nws, x.device) if nws else None
-        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
+        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                        y.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, _stream()), "conv2d_fwd")
         ctx.save_for_backward(x, weight)
@@ -225,14 +230,14 @@ class _Conv2dFn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
             dx = empty_nhwc(N, C, H, W, x.device)
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
-            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, x.device) if nws else None
             dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
             dw = _filter_grad_like(dwb, weight, Ce)
@@ -279,7 +284,7 @@ class _Conv2dSkipFn(torch.autograd.Function):
         wt = torch.empty(Ce * R * S * Kp, device=x.device, dtype=torch.float32)
         check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dskip), ld_of(dy))
-        with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+        with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
             check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dskip.data_ptr(), 1, st), "conv2d_dgrad(+=)")
         dw = None
         if ctx.needs_input_grad[1]:
@@ -287,7 +292,7 @@ class _Conv2dSkipFn(torch.autograd.Function):
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, x.device) if nws else None
             dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
             dw = _filter_grad_like(dwb, weight, Ce)
@@ -371,7 +376,7 @@ class _ConvTranspose2x2Fn(torch.autograd.Function):
         check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), w2.data_ptr(), 1, C, K4, 1, C, st), "convT filter")
         t = empty_nhwc(N, K4, H, W, x.device)
         d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(t))
-        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), detail=lambda: _geom(d)):
+        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
             nws = lib.segmi_conv2d_fwd_workspace(d)
             ws = workspace(nws, x.device) if nws else None
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w2.data_ptr(), None, t.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st),
@@ -399,14 +404,14 @@ class _ConvTranspose2x2Fn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(w2.data_ptr(), wt.data_ptr(), K4, 1, 1, C, K4, st), "krsc_to_crsk")
             dx = empty_nhwc(N, C, H, W, dev)
             d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(dx), ld_of(g))
-            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_dgrad(d, g.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "convT conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(g))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, dev) if nws else None
             dw2 = torch.empty(K4 * C, device=dev, dtype=torch.float32)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), g.data_ptr(), dw2.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "convT conv2d_wgrad")
             dw = torch.empty((C, K, 2, 2), device=dev, dtype=torch.float32)

@@ -22,6 +22,9 @@ def short(n):
     return n.replace("void (anonymous namespace)::", "").split("(")[0]
 
 
+launches = collections.Counter()
+
+
 def load(sub, counter):
     per, total = collections.Counter(), 0.0
     for r in csv.DictReader(open(os.path.join(root, sub, "r_counter_collection.csv"))):
@@ -30,6 +33,8 @@ def load(sub, counter):
         v = float(r["Counter_Value"]) / STEPS
         total += v
         per[short(r["Kernel_Name"])] += v
+        if counter == "FETCH_SIZE":
+            launches[short(r["Kernel_Name"])] += 1.0 / STEPS
     return per, total
 
 
@@ -48,6 +53,9 @@ doc = {
     "traffic_bytes_per_step": 2 * cf + cw,
     "all_kernels_fetch_bytes_raw": fetch_all * 1024.0,
     "all_kernels_write_bytes": write_all * 1024.0,
+    "per_kernel": {k: {"launches_per_step": launches[k], "fetch_bytes_corrected": 2 * fetch[k] * 1024.0, "write_bytes": write[k] * 1024.0,
+                       "traffic_bytes_per_launch": (2 * fetch[k] + write[k]) * 1024.0 / launches[k]}
+                   for k in fetch if k.startswith(CONV) and launches[k] > 0},
     "by_kernel_fetch_kb_raw": {k: int(v) for k, v in fetch.most_common(12) if k.startswith(CONV)},
     "by_kernel_write_kb": {k: int(v) for k, v in write.most_common(12) if k.startswith(CONV)},
     "notes": ["fetch counts Infinity-Cache (MALL) hits as well as HBM reads"],
