@@ -170,3 +170,28 @@ def test_data_prefetcher_refuses_cpu_device():
     from base import DataPrefetcher
     with pytest.raises(ValueError):
         DataPrefetcher([], device="cpu")
+
+
+def test_every_cfg2_conv_layer_dispatches_to_an_lds_dma_kernel():
+    """Host-side dispatch (no launch): each conv geometry of PSPNet-R50 at 8x512x512 runs on the LDS-DMA
+    implicit-GEMM kernels in all three passes — none falls back to the register-staged `conv_gather_kernel`/`conv_wgrad_kernel` —
+    and the tile shapes follow the output width: 128-wide n-tiles above 64 channels, the 32-wide tile for the 21-class heads."""
+    from segmi.ops import conv_out_size, conv_variant
+    from segmi._lib import ConvDesc
+    # (C, K, R, stride, pad, dil, H)  — the distinct layers of the deep-base ResNet-50 (dilated layer3/4), PSP head, aux head
+    layers = [(4, 64, 3, 2, 1, 1, 512), (64, 64, 3, 1, 1, 1, 256), (64, 128, 3, 1, 1, 1, 256),
+              (128, 64, 1, 1, 0, 1, 128), (64, 64, 3, 1, 1, 1, 128), (64, 256, 1, 1, 0, 1, 128), (256, 64, 1, 1, 0, 1, 128),
+              (256, 128, 1, 1, 0, 1, 128), (128, 128, 3, 2, 1, 1, 128), (128, 512, 1, 1, 0, 1, 64), (256, 512, 1, 2, 0, 1, 128),
+              (512, 256, 1, 1, 0, 1, 64), (256, 256, 3, 1, 2, 2, 64), (256, 1024, 1, 1, 0, 1, 64), (1024, 256, 1, 1, 0, 1, 64),
+              (1024, 512, 1, 1, 0, 1, 64), (512, 512, 3, 1, 4, 4, 64), (512, 2048, 1, 1, 0, 1, 64), (2048, 512, 1, 1, 0, 1, 64),
+              (4096, 512, 3, 1, 1, 1, 64), (512, 21, 1, 1, 0, 1, 64), (1024, 512, 3, 1, 1, 1, 64), (2048, 512, 1, 1, 0, 1, 6)]
+    for C, K, R, stride, pad, dil, H in layers:
+        P = conv_out_size(H, R, stride, pad, dil)
+        d = ConvDesc(8, H, H, C, K, R, R, P, P, stride, pad, dil, C, (K + 3) & ~3)
+        names = [conv_variant(d, op) for op in (0, 1, 2)]
+        assert names[0].startswith("conv_dma_kernel<") and names[1].startswith("conv_dma_kernel<"), (C, K, R, names)
+        assert names[2].startswith("conv_wgrad_dma_kernel<"), (C, K, R, names)
+        if K > 64 and 8 * P * P >= 65536:
+            assert names[0].startswith("conv_dma_kernel<128, 128"), names[0]
+        if K <= 32:
+            assert names[0].startswith("conv_dma_kernel<128, 32"), names[0]
