@@ -30,6 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-segmentation_amd"))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: RCCL's cross-process buffer registration fails without this (set before HIP starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
