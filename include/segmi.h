@@ -80,6 +80,16 @@ int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy
 int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
 int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, int S, int C, int Kpad,
                               segmi_stream_t stream);
+/* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
+ *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
+ *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and
+ *                          the six plane products of weight >= 2^-16 run on v_mfma_f32_32x32x16_bf16 with fp32
+ *                          accumulation: per-product error <= 2^-24 (one fp32 rounding), data in HBM stays fp32.
+ * Also selectable at first use with the environment variable SEGMI_CONV_MATH=bf16x3.  aten has no counterpart (the
+ * reference computes in fp32, trainer.py:56); this is the drop-in's throughput knob. */
+enum segmi_conv_math { SEGMI_CONV_MATH_F32 = 0, SEGMI_CONV_MATH_BF16X3 = 1 };
+int segmi_conv_set_math(int math);
+int segmi_conv_get_math(void);
 /* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */
 size_t segmi_colsum_workspace(long rows, int C);
 int segmi_colsum(const float* dy, int ld, long rows, int C, float* out, void* workspace, size_t workspace_bytes,

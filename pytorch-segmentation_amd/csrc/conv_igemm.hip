@@ -20,6 +20,7 @@
 #include "segmi_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -255,10 +256,101 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voffset, unsig
                  :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
+// ------------------------------------------------------------------------------------------------
+// MATH_BF16X3: fp32-accurate products on the bf16 matrix pipe (16x the fp32 MFMA rate per instruction).
+// Each fp32 operand x is split IN REGISTERS, after the fragment read, into three bf16 planes
+//     h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)          (round-to-nearest-even, v_cvt_pk_bf16_f32)
+// Both subtractions are exact in fp32 and the last residual has <= 7 significant bits, so x == h + m + l EXACTLY
+// (8+8+8 = 24 significand bits; exponent range of fp32 kept, unlike an fp16 split).  Of the nine plane products the six
+// of relative weight >= 2^-16 are issued as v_mfma_f32_32x32x16_bf16 into the SAME fp32 accumulator:
+//     x*y ~= l*h' + h*l' + m*m' + m*h' + h*m' + h*h'       dropped: m*l' + l*m' + l*l'  <= 2^-24 |x*y|, signs random
+// i.e. the dropped part is at the level of ONE fp32 rounding of the product, and the accumulator sees 6K/16 roundings
+// instead of the K of the fp32 MFMA chain.  Data in HBM and LDS stay fp32: same DMA, same swizzle, same epilogue;
+// only the fragment reads (8 consecutive k per lane instead of 4) and the matrix instructions differ.
+// Cost model per wave and 32-wide K chunk (64x64 wave tile): 48 MFMAs x 32 cycles = 1536 cycles of matrix pipe against
+// 4096 for fp32 MFMA, plus 64 operand floats per lane x 5.5 VALU to split (the issue-slot budget beside an MFMA is ~5-7
+// VALU: this kernel is VALU-issue/MFMA co-limited, not LDS- or HBM-limited).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3 };
+
+struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+}
+// x - y as ONE v_sub_f32: left to itself the SLP vectoriser fuses neighbouring residuals into v_pk_add_f32, which on gfx950
+// is no faster than two plain fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the costliest filler
+// beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Plain (non-volatile) asm: the
+// scheduler may still move and interleave it.  -DSEGMI_SPLIT_PK=1 restores the compiler's choice for A/B runs.
+__device__ __forceinline__ float sub_f32(float x, float y) {
+#if defined(SEGMI_SPLIT_PK) && SEGMI_SPLIT_PK
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = sub_f32(x0, __builtin_bit_cast(float, h << 16));
+    const float r1 = sub_f32(x1, __builtin_bit_cast(float, h & 0xFFFF0000u));
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = sub_f32(r0, __builtin_bit_cast(float, m << 16));
+    const float s1 = sub_f32(r1, __builtin_bit_cast(float, m & 0xFFFF0000u));
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ Planes split8(const float (&x)[8]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    Planes p;
+    p.h = u32x4_t{h[0], h[1], h[2], h[3]};
+    p.m = u32x4_t{m[0], m[1], m[2], m[3]};
+    p.l = u32x4_t{l[0], l[1], l[2], l[3]};
+    return p;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// acc[i][j] += A_i (x) B_j over 16 k-values, six plane products, smallest terms first; the (i, j) loop is innermost so
+// that consecutive matrix instructions target different accumulators
+template <int TM, int TN>
+__device__ __forceinline__ void mma_bf16x3(f32x16 (&acc)[TM][TN], const Planes (&a)[TM], const Planes (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].l, b[j].h, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].l, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].m, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].h, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].m, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].h, acc[i][j]);
+}
+
 // FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
 // keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
 // an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int MATH>
 __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -430,6 +522,31 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
         const float* Ab = smem + buf * STAGE;
         const float* Bb = Ab + BM * BK;
+        if (MATH == MATH_BF16X3) {
+            // a lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two
+            // swizzled 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair)
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int g0 = ks * 4 + lhalf * 2;
+                const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
+                Planes pa[TM], pb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
+                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                    pa[i] = split8(x);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
+                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                    pb[j] = split8(x);
+                }
+                mma_bf16x3<TM, TN>(acc, pa, pb);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
@@ -664,7 +781,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // ROWQ (Q % 32 == 0): a 32-pixel chunk never straddles an output row, so (n, p, q0) of the chunk are wave-uniform scalars
 // advanced with SALU, and a lane only adds its fixed in-chunk column: ~20 VALU per chunk instead of ~130 (the m -> (n,p,q)
 // bookkeeping per lane and per load is what kept the generic path's waves off the matrix pipe: 125 vs 136 TF/s of fprop).
-template <int BM, int BN, bool ROWQ>
+template <int BM, int BN, bool ROWQ, int MATH>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int BKP = 32, WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -797,6 +914,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
             const float* Ab = smem + buf * STAGE;
             const float* Bb = Ab + BKP * BM;
+            if (MATH == MATH_BF16X3) {
+                // the reduction axis (pixels) is the LDS row index here: a lane gathers its channel's 8 pixels
+                // (ks*16 + lhalf*8 + e) with 8 ds_read_b32 per tile (lanes of a half-wave read consecutive channels of one
+                // pixel: conflict-free as in the fp32 path).  Both 16-pixel steps are fetched before the first split so the
+                // LDS latency of the second hides behind the first step's VALU + matrix work.
+                float ra[BKP / 16][TM][8], rb[BKP / 16][TN][8];
+#pragma unroll
+                for (int ks = 0; ks < BKP / 16; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
+                }
+#pragma unroll
+                for (int ks = 0; ks < BKP / 16; ++ks) {
+                    Planes pa[TM], pb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) pa[i] = split8(ra[ks][i]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) pb[j] = split8(rb[ks][j]);
+                    mma_bf16x3<TM, TN>(acc, pa, pb);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                buf ^= 1;
+                continue;
+            }
             // operand registers are double-buffered by hand: the ds_reads of step kk+2 are in flight while the
             // MFMAs of step kk issue (without it the wave waits out the LDS latency every 4 MFMAs: 115 vs 130 TF/s)
             float a[3][TM], b[3][TN];
@@ -934,6 +1082,18 @@ int conv_bk() {
     return g_bk;
 }
 
+// Matrix arithmetic of the LDS-DMA convolution kernels: MATH_F32 (v_mfma_f32_32x32x2_f32, the default and the parity
+// path) or MATH_BF16X3 (three-plane bf16 split, six products; see the comment above split_pair).  Process-wide, set by
+// segmi_conv_set_math() or, at first use, by SEGMI_CONV_MATH=bf16x3.  The register-staged fallback kernels are fp32 only.
+int g_math = -1;
+int conv_math() {
+    if (g_math < 0) {
+        const char* e = getenv("SEGMI_CONV_MATH");
+        g_math = (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? MATH_BF16X3 : MATH_F32;
+    }
+    return g_math;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
     p.tiles_m = segmi_cdiv(p.M, BM);
@@ -944,8 +1104,14 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
-    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    const bool x3 = conv_math() == MATH_BF16X3;
+    if (fast) {
+        if (x3) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+        else    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_F32>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    } else {
+        if (x3) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+        else    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_F32>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    }
     if (p.ksplit > 1) {
         const long n4 = (long)p.M * p.ldd / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -1091,8 +1257,14 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     unsigned xb, dyb;
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
-        if (p.Q % WG_BKP == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
-        else                   hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
+        const bool x3 = conv_math() == MATH_BF16X3;
+        if (p.Q % WG_BKP == 0) {
+            if (x3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true, MATH_BF16X3>), grid, dim3(256), lds, st, p, xb, dyb);
+            else    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true, MATH_F32>), grid, dim3(256), lds, st, p, xb, dyb);
+        } else {
+            if (x3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, MATH_BF16X3>), grid, dim3(256), lds, st, p, xb, dyb);
+            else    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, MATH_F32>), grid, dim3(256), lds, st, p, xb, dyb);
+        }
     }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();
@@ -1221,7 +1393,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
         const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
-        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", pl.nsplit);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s, %d> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", conv_math(), pl.nsplit);
         else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
@@ -1231,14 +1403,21 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
-                 fast ? "true" : "false");
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %d>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
+                 fast ? "true" : "false", conv_math());
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
     snprintf(buf, len, "conv_gather_kernel<128, %d, %d, %s, %d>", bn, bk, bn == 32 ? "4, 1" : "2, 2", op);
     return SEGMI_OK;
 }
+
+int segmi_conv_set_math(int math) {
+    if (math != SEGMI_CONV_MATH_F32 && math != SEGMI_CONV_MATH_BF16X3) return SEGMI_ERR_BADARG;
+    g_math = math;
+    return SEGMI_OK;
+}
+int segmi_conv_get_math(void) { return conv_math(); }
 
 int segmi_filter_krsc_to_crsk(const float* w, float* wt, int K, int R, int S, int C, int Kpad, segmi_stream_t stream) {
     if (!w || !wt || K <= 0 || R <= 0 || S <= 0 || C <= 0 || Kpad < K) return SEGMI_ERR_BADARG;

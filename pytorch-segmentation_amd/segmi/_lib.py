@@ -37,6 +37,8 @@ SIGNATURES = {
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_conv2d_variant": (i32, [PD, i32, C.c_char_p, sz]),
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "segmi_conv_set_math": (i32, [i32]),
+    "segmi_conv_get_math": (i32, []),
     "segmi_dwconv2d_fwd": (i32, [PD, vp, vp, vp, vp]),
     "segmi_dwconv2d_dgrad": (i32, [PD, vp, vp, vp, vp]),
     "segmi_dwconv2d_wgrad_workspace": (sz, [PD]),

@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4",
+    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math",
 ]
 
 
@@ -168,6 +168,23 @@ def _filter_grad_like(dw_krsc, w, Ce):
 
 def conv_out_size(H, k, stride, pad, dil):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+CONV_MATH = {"f32": 0, "bf16x3": 1}
+
+
+def set_conv_math(name):
+    """Matrix arithmetic of the dense convolution kernels (process-wide; include/segmi.h `segmi_conv_set_math`):
+    "f32" = fp32 MFMA chain (default, the parity path); "bf16x3" = three-plane bf16 split of every fp32 operand, six products
+    on the bf16 matrix pipe, fp32 accumulation (fp32-level accuracy, ~2x the matrix throughput)."""
+    if name not in CONV_MATH:
+        raise SegmiError("segmi.set_conv_math: unknown math %r (choose from %s)" % (name, sorted(CONV_MATH)))
+    check(lib.segmi_conv_set_math(CONV_MATH[name]), "conv_set_math")
+
+
+def get_conv_math():
+    v = lib.segmi_conv_get_math()
+    return next(k for k, x in CONV_MATH.items() if x == v)
 
 
 def conv_variant(d, op):

@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 3
+    assert lib.segmi_abi_version() == 4
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
@@ -67,6 +67,55 @@ def test_status_strings_and_queries():
     assert lib.segmi_conv2d_wgrad_workspace(d) == 0
     assert lib.segmi_bn_stats_workspace(8 * 64 * 64, 2048) >= 3 * 2048 * 4
     assert lib.segmi_ce_workspace(1 << 21) > 0
+
+
+def test_conv_math_switch_and_variant_names():
+    """segmi_conv_set_math / get_math (include/segmi.h): default fp32 MFMA; the variant name reported for profiling carries
+    the arithmetic as its last template argument, exactly as a rocprofv3 kernel trace prints the instantiation."""
+    from segmi import lib, ops
+    from segmi._lib import ConvDesc
+    assert ops.get_conv_math() == "f32" and lib.segmi_conv_get_math() == 0
+    d = ConvDesc(8, 64, 64, 512, 512, 3, 3, 64, 64, 1, 2, 2, 512, 512)
+    assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 0>"
+    assert lib.segmi_conv_set_math(7) == -1 and ops.get_conv_math() == "f32"
+    with pytest.raises(Exception):
+        ops.set_conv_math("tf32")
+    try:
+        ops.set_conv_math("bf16x3")
+        assert lib.segmi_conv_get_math() == 1
+        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>"
+        assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true, 1>"
+        assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true, 1>")
+        # workspace planning does not depend on the arithmetic
+        assert lib.segmi_conv2d_wgrad_workspace(d) % (512 * 9 * 512 * 4) == 0
+    finally:
+        ops.set_conv_math("f32")
+
+
+def test_conv_kernels_are_compiled_without_scratch(tmp_path):
+    """Every LDS-DMA convolution instantiation (both arithmetics) is present in the gfx950 code object, none spills
+    (a spilling matrix loop would silently run at a fraction of the modelled rate) and all leave room for two workgroups
+    per CU (<= 256 VGPRs incl. accumulators)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "pytorch-segmentation_amd", "build", "conv_igemm.o")
+    if not (os.path.exists(os.path.join(llvm, "clang-offload-bundler")) and os.path.exists(obj)):
+        pytest.skip("llvm tools / object file not present")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "conv.co")
+    subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / "unused.o")], check=True)
+    subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    kern = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
+    dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
+    x3 = [n for n in dma if re.search(r"Li1EEEv", n)]          # last template argument MATH = 1
+    f32 = [n for n in dma if re.search(r"Li0EEEv", n)]
+    assert len(x3) == len(f32) == 28, (len(x3), len(f32))
+    for n, v in dma.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
+        assert v["vgpr_count"] <= 256, (n, v)
 
 
 def test_pool_output_sizes_match_torch():
