@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — training images/sec of the MI355X-native segmentation hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--conv-math f32|bf16x3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -37,6 +37,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# --conv-math bf16x3: every fp32 product costs six v_mfma_f32_32x32x16_bf16 plane products (csrc/conv_igemm.hip), so the
+# matrix-pipe ceiling in ALGORITHMIC (fp32) FLOPs is the dense bf16 peak / 6: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz / 6
+PEAK_BF16X3_EQUIV_TFLOPS = round(2516.6 / 6, 1)
 
 # name -> (arch, kwargs, num_classes, per-GPU batch, H, W, train FLOPs/image (conv only), loss, ignore_index)
 # cfg2 is the bench line (BASELINE.json configs[1]); the others are the remaining BASELINE configs, runnable with --config
@@ -112,6 +115,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
     ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
+    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
+                    help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
+                         "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +140,10 @@ def main():
     from segmi.distributed import DistributedModel
     from segmi.profile import KernelTimer
     import utils.losses as losses_mod
+
+    from segmi import ops as segmi_ops
+    segmi_ops.set_conv_math(args.conv_math)
+    peak = PEAK_BF16X3_EQUIV_TFLOPS if args.conv_math == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
 
     arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)
@@ -200,22 +210,29 @@ def main():
         # WRITE_SIZE passes over this same command is reported, per launch of the dominant kernel like `achieved` (cfg2 only)
         traffic = step_traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_cfg2_conv_traffic.json")
-        if args.config == "cfg2" and os.path.exists(tpath):
+        if args.config == "cfg2" and args.conv_math == "f32" and os.path.exists(tpath):
             tj = json.load(open(tpath))
             step_traffic = tj["traffic_bytes_per_step"]
-            traffic = tj.get("per_kernel", {}).get(top_name, {}).get("traffic_bytes_per_launch")
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            # the PMC passes predate the kernels' MATH template argument: "<..., true, 0>" is the kernel profiled as "<..., true>"
+            # (same code); a bf16x3 run has no PMC profile yet -> null
+            legacy = top_name.split(" splitk=")[0]
+            legacy = legacy[:-len(", 0>")] + ">" if legacy.endswith(", 0>") else legacy
+            traffic = tj.get("per_kernel", {}).get(legacy, {}).get("traffic_bytes_per_launch")
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "peak_note": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.conv_math == "f32" else
+                              "fp32-equivalent ceiling of the bf16x3 scheme = dense bf16 MFMA peak 2516.6 / 6 plane products; "
+                              "achieved/frac count ALGORITHMIC fp32 FLOPs (the fp32 MFMA peak is %.1f)" % PEAK_FP32_MFMA_TFLOPS),
                 "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
                 "flops_per_launch": top["flops"] // top["launches"], "algorithmic_bytes_per_launch": top["bytes"] // top["launches"],
                 "scope": "dominant kernel = the conv implicit-GEMM variant with the largest total time in one step; HIP events per launch "
                          "on the launch stream; traffic = HBM+MALL bytes per launch from the rocprofv3 PMC passes "
                          "(profiles/r01_cfg2_conv_traffic.json)",
-                "all_conv": {"achieved": round(all_ach, 2), "frac": round(all_ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "all_conv": {"achieved": round(all_ach, 2), "frac": round(all_ach / peak, 4),
                              "launches": sum(r["launches"] for r in summ.values()), "ms_per_step": round(tot_ms, 2),
                              "flops_per_step": tot_fl, "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
                              "traffic_bytes_per_step": step_traffic},
-                "step_frac": round(value / world * flops_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "step_frac": round(value / world * flops_img / 1e12 / peak, 4),
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                  "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
     if ddp:
@@ -230,12 +247,14 @@ def main():
             "metric": "training images/sec @512x512 (PSPNet-R50)" if args.config == "cfg2" else "training images/sec (%s)" % args.config,
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.conv_math == "f32" else "f32 (HBM/LDS/accumulate fp32; conv products as bf16x3 split on the bf16 matrix pipe)",
+            "data": "synthetic",
             "config": {"workload": "%s: %s%s %dx3x%dx%d per GPU, %d classes, %s%s, SGD(momentum 0.9, wd 1e-4), "
                                    "BN batch stats%s, dropout on" % (args.config, arch, "-" + kw["backbone"] if "backbone" in kw else "", nb, h, w,
                                                                       classes, loss_name, " + 0.4*aux" if psp else "",
                                                                       " (SyncBN)" if args.sync_bn and ddp else ""),
-                       "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)},
+                       "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5),
+                       "conv_math": args.conv_math},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
