@@ -282,26 +282,25 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
 }
-// x - y as ONE v_sub_f32: left to itself the SLP vectoriser fuses neighbouring residuals into v_pk_add_f32, which on gfx950
-// is no faster than two plain fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the costliest filler
-// beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Plain (non-volatile) asm: the
-// scheduler may still move and interleave it.  -DSEGMI_SPLIT_PK=1 restores the compiler's choice for A/B runs.
-__device__ __forceinline__ float sub_f32(float x, float y) {
-#if defined(SEGMI_SPLIT_PK) && SEGMI_SPLIT_PK
-    return x - y;
-#else
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
+// The two residuals of a pair are kept as two plain v_sub_f32: left to itself the SLP vectoriser fuses them into one
+// v_pk_add_f32, which on gfx950 is no faster than two fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the
+// costliest filler beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  The empty asm is
+// an optimisation fence on ONE value of the pair (emits nothing; the subtractions stay ordinary, schedulable VALU).
+// -DSEGMI_SPLIT_PK=1 restores the compiler's choice for A/B runs.
+__device__ __forceinline__ void slp_fence(float& v) {
+#if !(defined(SEGMI_SPLIT_PK) && SEGMI_SPLIT_PK)
+    asm("" : "+v"(v));
 #endif
 }
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     h = cvt_pk_bf16(x0, x1);
-    const float r0 = sub_f32(x0, __builtin_bit_cast(float, h << 16));
-    const float r1 = sub_f32(x1, __builtin_bit_cast(float, h & 0xFFFF0000u));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16);
+    float r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
+    slp_fence(r1);
     m = cvt_pk_bf16(r0, r1);
-    const float s0 = sub_f32(r0, __builtin_bit_cast(float, m << 16));
-    const float s1 = sub_f32(r1, __builtin_bit_cast(float, m & 0xFFFF0000u));
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16);
+    float s1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
+    slp_fence(s1);
     l = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ Planes split8(const float (&x)[8]) {
@@ -518,35 +517,93 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
+    if (MATH == MATH_BF16X3) {
+        // A lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two swizzled
+        // 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair).
+        // Software pipeline over 16-wide k steps, ACROSS chunk boundaries (matrix instructions only need registers, so the
+        // second step of chunk t may issue after the barrier that releases its LDS stage):
+        //     phase A(t): MFMAs of step (t-1, 1)  ||  split of step (t, 0)
+        //     phase B(t): MFMAs of step (t, 0)    ||  split of step (t, 1)
+        // Each phase pairs 6*TM*TN matrix instructions (32 cycles each) with the ~44 VALU per tile row-block of one split
+        // (sched_group_barrier: 1 MFMA + its share of VALU per group), so neither pipe waits for the other inside a wave;
+        // only the very first split of a tile is exposed, and the last step drains after the loop.
+        constexpr int NMMA = TM * TN * 6;
+        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 8 unpack + ... = 44
+        float ra[2][TM][8], rb[2][TN][8];
+        Planes pa[2][TM], pb[2][TN];
+        auto fetch = [&](const float* Ab, const float* Bb, int ks) {
+            const int g0 = ks * 4 + lhalf * 2;
+            const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
+                const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                ra[ks][i][0] = u.x; ra[ks][i][1] = u.y; ra[ks][i][2] = u.z; ra[ks][i][3] = u.w;
+                ra[ks][i][4] = v.x; ra[ks][i][5] = v.y; ra[ks][i][6] = v.z; ra[ks][i][7] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
+                const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                rb[ks][j][0] = u.x; rb[ks][j][1] = u.y; rb[ks][j][2] = u.z; rb[ks][j][3] = u.w;
+                rb[ks][j][4] = v.x; rb[ks][j][5] = v.y; rb[ks][j][6] = v.z; rb[ks][j][7] = v.w;
+            }
+        };
+        auto phase_b = [&]() {                                 // MFMAs of step 0 || split of step 1, then hand over the stage
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
+#pragma unroll
+            for (int q = 0; q < NMMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
+            __syncthreads();                                     // ... for every wave, and this stage is free again
+            buf ^= 1;
+        };
+        if (it0 < T) {                                         // first chunk of the tile: nothing pending, its first split is exposed
+            if (it0 + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
+            const float* Ab = smem + buf * STAGE;
+            const float* Bb = Ab + BM * BK;
+            fetch(Ab, Bb, 0);
+            fetch(Ab, Bb, 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            phase_b();
+        }
+        for (int it = it0 + 1; it < T; ++it) {
+            if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
+            const float* Ab = smem + buf * STAGE;
+            const float* Bb = Ab + BM * BK;
+            fetch(Ab, Bb, 0);
+            fetch(Ab, Bb, 1);                                  // both steps up front: step 1's LDS latency hides behind phase A
+            // phase A: MFMAs of the pending step || split of step 0
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
+#pragma unroll
+            for (int q = 0; q < NMMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+            }
+            phase_b();
+        }
+        if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
+    } else
     for (int it = it0; it < T; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
         const float* Ab = smem + buf * STAGE;
         const float* Bb = Ab + BM * BK;
-        if (MATH == MATH_BF16X3) {
-            // a lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two
-            // swizzled 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair)
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                const int g0 = ks * 4 + lhalf * 2;
-                const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
-                Planes pa[TM], pb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
-                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-                    pa[i] = split8(x);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
-                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-                    pb[j] = split8(x);
-                }
-                mma_bf16x3<TM, TN>(acc, pa, pb);
-            }
-        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
@@ -905,6 +962,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    if (MATH == MATH_BF16X3) {
+        // Same software pipeline as conv_dma_kernel (phase A: pending step's MFMAs || split of step 0; phase B: step 0's
+        // MFMAs || split of step 1; the second step of a chunk issues after the barrier).  The reduction axis (pixels) is the
+        // LDS row index here: a lane gathers its channel's 8 pixels (ks*16 + lhalf*8 + e) with ds_read_b32 (lanes of a
+        // half-wave read consecutive channels of one pixel: conflict-free as in the fp32 path).
+        constexpr int NMMA = TM * TN * 6;
+        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;
+        float ra[2][TM][8], rb[2][TN][8];
+        Planes pa[2][TM], pb[2][TN];
+        int buf = 0;
+        auto fetch = [&](const float* Ab, const float* Bb, int ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
+        };
+        auto phase_b = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
+#pragma unroll
+            for (int q = 0; q < NMMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        };
+        if (mbeg < mend) {
+            issue(mbeg, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (mbeg + BKP < mend) issue(mbeg + BKP, 1);
+            fetch(smem, smem + BKP * BM, 0);
+            fetch(smem, smem + BKP * BM, 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);        // first chunk: exposed split
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            phase_b();
+            for (int mb = mbeg + BKP; mb < mend; mb += BKP) {
+                if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
+                const float* Ab = smem + buf * STAGE;
+                const float* Bb = Ab + BKP * BM;
+                fetch(Ab, Bb, 0);
+                fetch(Ab, Bb, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+                mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
+#pragma unroll
+                for (int q = 0; q < NMMA; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                }
+                phase_b();
+            }
+            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);                            // drain
+        }
+    } else
     if (mbeg < mend) {
         issue(mbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -914,37 +1042,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
             const float* Ab = smem + buf * STAGE;
             const float* Bb = Ab + BKP * BM;
-            if (MATH == MATH_BF16X3) {
-                // the reduction axis (pixels) is the LDS row index here: a lane gathers its channel's 8 pixels
-                // (ks*16 + lhalf*8 + e) with 8 ds_read_b32 per tile (lanes of a half-wave read consecutive channels of one
-                // pixel: conflict-free as in the fp32 path).  Both 16-pixel steps are fetched before the first split so the
-                // LDS latency of the second hides behind the first step's VALU + matrix work.
-                float ra[BKP / 16][TM][8], rb[BKP / 16][TN][8];
-#pragma unroll
-                for (int ks = 0; ks < BKP / 16; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
-                }
-#pragma unroll
-                for (int ks = 0; ks < BKP / 16; ++ks) {
-                    Planes pa[TM], pb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) pa[i] = split8(ra[ks][i]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) pb[j] = split8(rb[ks][j]);
-                    mma_bf16x3<TM, TN>(acc, pa, pb);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                buf ^= 1;
-                continue;
-            }
             // operand registers are double-buffered by hand: the ds_reads of step kk+2 are in flight while the
             // MFMAs of step kk issue (without it the wave waits out the LDS latency every 4 MFMAs: 115 vs 130 TF/s)
             float a[3][TM], b[3][TN];
