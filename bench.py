@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — training images/sec of the MI355X-native segmentation hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--conv-math f32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--conv-math f32|bf16x3] [--graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
     ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
+    ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
+                                                         "one host call per step instead of ~800 launches")
     ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
                     help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
                          "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
@@ -150,7 +152,8 @@ def main():
     if args.sync_bn and ddp:
         from utils.sync_batchnorm import convert_model
         model = convert_model(model)
-    dm = DistributedModel(model, always_reduce=args.force_ddp) if ddp else None
+    # --graph needs gradients at stable addresses: the reducer keeps them as views of flat buckets, also without a process group
+    dm = DistributedModel(model, always_reduce=args.force_ddp) if (ddp or args.graph) else None
     from segmi.optim import SGD          # torch.optim.SGD semantics, one fused launch
     if os.environ.get("SEGMI_BENCH_TORCH_SGD") == "1":
         SGD = torch.optim.SGD            # A/B hook
@@ -180,12 +183,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = step
+    if args.graph:
+        from segmi.graph import GraphedStep
+        run = GraphedStep(step, warmup=3)       # eager warm-up steps + capture; replays below are the timed steps
     for _ in range(args.warmup):
-        loss = step()
+        loss = run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     dt = time.perf_counter() - t0
     if ddp:
@@ -254,7 +261,7 @@ def main():
                                                                       classes, loss_name, " + 0.4*aux" if psp else "",
                                                                       " (SyncBN)" if args.sync_bn and ddp else ""),
                        "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5),
-                       "conv_math": args.conv_math},
+                       "conv_math": args.conv_math, "hip_graph": bool(args.graph)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -201,9 +201,11 @@ int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, in
 
 /* ------------------------------------------------------------------ dropout (K14)
  * nn.Dropout2d(0.1) models/pspnet.py:22,68 (per (n,c) mask) and nn.Dropout models/deeplabv3_plus.py:282,318
- * (per element).  The mask is a counter-based hash of (seed, index): regenerated in backward. */
+ * (per element).  The mask is a counter-based hash of (seed, index): regenerated in backward.
+ * seed_epoch_dev (nullable, device memory): a step counter folded into the seed on the device — a training step captured
+ * once into a hipGraph then draws fresh masks on every replay (the by-value seed is frozen at capture). */
 int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, int C, float p, int channelwise,
-                  uint64_t seed, segmi_stream_t stream);
+                  uint64_t seed, const uint64_t* seed_epoch_dev, segmi_stream_t stream);
 
 /* ------------------------------------------------------------------ per-pixel losses (K10/K11/K12) */
 /* CrossEntropyLoss2d (utils/losses.py:24-31): mean over target != ignore_index of -log_softmax.

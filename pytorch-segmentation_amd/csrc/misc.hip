@@ -69,7 +69,11 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
 }
 template <bool CHANNELWISE>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long HW,
-                                                      long rows, int C, float p, float scale, uint64_t seed) {
+                                                      long rows, int C, float p, float scale, uint64_t seed0,
+                                                      const uint64_t* __restrict__ epoch) {
+    // epoch (optional, device memory): a per-step counter folded into the seed ON THE DEVICE, so that a step captured once
+    // into a hipGraph draws fresh masks on every replay (a by-value seed would be frozen into the graph)
+    const uint64_t seed = epoch ? seed0 + *epoch * 0xD1B54A32D192ED03ull : seed0;
     const int c4n = (C + 3) / 4;
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= c4n) return;
@@ -132,14 +136,14 @@ int segmi_copy_rows(const float* src, int ld_src, float* dst, int ld_dst, long r
 }
 
 int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, int C, float p, int channelwise,
-                  uint64_t seed, segmi_stream_t stream) {
+                  uint64_t seed, const uint64_t* seed_epoch_dev, segmi_stream_t stream) {
     if (!x || !y || N <= 0 || HW <= 0 || C <= 0 || !(p >= 0.f && p < 1.f)) return SEGMI_ERR_BADARG;
     if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C) return SEGMI_ERR_ALIGN;
     const long rows = (long)N * HW;
     RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
     const float scale = 1.f / (1.f - p);
-    if (channelwise) hipLaunchKernelGGL((dropout_kernel<true>), g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, HW, rows, C, p, scale, seed);
-    else             hipLaunchKernelGGL((dropout_kernel<false>), g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, HW, rows, C, p, scale, seed);
+    if (channelwise) hipLaunchKernelGGL((dropout_kernel<true>), g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, HW, rows, C, p, scale, seed, seed_epoch_dev);
+    else             hipLaunchKernelGGL((dropout_kernel<false>), g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, HW, rows, C, p, scale, seed, seed_epoch_dev);
     return segmi_launch_status();
 }
 

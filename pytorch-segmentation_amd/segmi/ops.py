@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math",
+    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_dropout_epoch",
 ]
 
 
@@ -762,25 +762,39 @@ def cat(tensors):
     return _CatFn.apply(*tensors)
 
 
+# Device-side step counter folded into every dropout seed (segmi_dropout's seed_epoch_dev).  None in eager mode (each call
+# draws a fresh host seed); segmi.graph.GraphedStep installs one so that a captured step draws fresh masks per replay.
+_DROPOUT_EPOCH = None
+
+
+def set_dropout_epoch(t):
+    """t: None or a 1-element int64 CUDA tensor that the caller advances once per training step (after backward)."""
+    global _DROPOUT_EPOCH
+    if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise SegmiError("segmi.set_dropout_epoch: expected a 1-element int64 CUDA tensor")
+    _DROPOUT_EPOCH = t
+
+
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, channelwise, seed):
         x = to_nhwc(x, "dropout")
         N, C, H, W = x.shape
         y = empty_nhwc(N, C, H, W, x.device)
+        ep = _DROPOUT_EPOCH
         check(lib.segmi_dropout(x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), N, H * W, C, p, 1 if channelwise else 0, seed,
-                                _stream()), "dropout")
-        ctx.cfg = (p, channelwise, seed)
+                                ep.data_ptr() if ep is not None else None, _stream()), "dropout")
+        ctx.cfg = (p, channelwise, seed, ep)     # backward regenerates the mask: same seed, same (not yet advanced) epoch
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        p, channelwise, seed = ctx.cfg
+        p, channelwise, seed, ep = ctx.cfg
         dy = to_nhwc(dy, "dropout.backward")
         N, C, H, W = dy.shape
         dx = empty_nhwc(N, C, H, W, dy.device)
         check(lib.segmi_dropout(dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx), N, H * W, C, p, 1 if channelwise else 0,
-                                seed, _stream()), "dropout.backward")
+                                seed, ep.data_ptr() if ep is not None else None, _stream()), "dropout.backward")
         return dx, None, None, None
 
 

@@ -56,6 +56,11 @@ class SGD(torch.optim.Optimizer):
                     entries.append((ptrs[0], ptrs[1], ptrs[2], cnt, gi, int(cnt % 4 == 0 and all(q % 16 == 0 for q in ptrs))))
         sig = tuple(sig)
         if sig != self._sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("segmi.optim.SGD: a parameter / gradient / momentum pointer changed while a hipGraph is being "
+                                   "captured; the pointer table is uploaded from host memory and cannot be rebuilt inside a capture. "
+                                   "Keep gradients persistent (segmi.distributed.DistributedModel holds them as bucket views, also in a "
+                                   "single process) and run at least one eager step before capturing (segmi.graph.GraphedStep does).")
             arr = (_Chunk * len(entries))(*[_Chunk(*e) for e in entries])
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._table = host.to(self.param_groups[0]["params"][0].device)

@@ -120,6 +120,17 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         assert v["agpr_count"] <= v["vgpr_count"] <= 256, (n, v)
 
 
+def test_graph_module_refuses_cpu_and_validates_the_dropout_epoch():
+    """segmi.graph.GraphedStep is hipGraph capture: no CPU path; the dropout epoch must be a device int64 scalar."""
+    from segmi import SegmiError, graph, ops
+    with pytest.raises(SegmiError):
+        graph.GraphedStep(lambda: None)
+    with pytest.raises(SegmiError):
+        ops.set_dropout_epoch(torch.zeros(1, dtype=torch.int64))      # CPU tensor
+    ops.set_dropout_epoch(None)
+    assert ops._DROPOUT_EPOCH is None
+
+
 def test_pool_output_sizes_match_torch():
     from segmi.ops import conv_out_size, pool_out_size
     import torch.nn.functional as F

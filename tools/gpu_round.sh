@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, per-layer conv table, rocprof kernel stats.
-# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc] [x3] [x3prof]
+# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc] [x3] [x3prof] [graph]
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -43,5 +43,15 @@ x3prof)
   ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x3prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --conv-math bf16x3 2>&1 | tail -2 ) > gpurun_out/x3prof.log
   find gpurun_out/x3prof -name "*kernel_trace*" -size +30M -delete
   find gpurun_out/x3prof -type f | head ;;
+graph)
+  # first hardware run of hipGraph capture (segmi/graph.py): opt-in tests, then eager vs replayed step on the launch-paced
+  # UNet config and on the bench line
+  ( SEGMI_TEST_GRAPH=1 timeout 900 python -m pytest tests/test_graph_gpu.py -m gpu -q 2>&1 | tail -25 ) > gpurun_out/graph_tests.log
+  cat gpurun_out/graph_tests.log
+  for c in cfg1 cfg2; do
+    ( timeout 600 python bench.py --config $c --no-cpu --no-roofline 2>&1 | tail -1 ) > gpurun_out/graph_${c}_eager.log
+    ( timeout 600 python bench.py --config $c --no-cpu --no-roofline --graph 2>&1 | tail -3 ) > gpurun_out/graph_${c}_graph.log
+    cat gpurun_out/graph_${c}_eager.log gpurun_out/graph_${c}_graph.log
+  done ;;
 esac
 done
