@@ -1,6 +1,6 @@
 """GPU: the MATH_BF16X3 convolution kernels (csrc/conv_igemm.hip; include/segmi.h `segmi_conv_set_math`) against an fp64
 CPU convolution and against the default fp32-MFMA path, for fprop / dgrad / wgrad over the tile shapes the dispatcher
-uses.  Bound asserted: the bf16x3 result is as close to fp64 as the fp32 MFMA chain is (within 3x, plus one fp32 ulp of
+uses.  Bound asserted: the bf16x3 result is as close to fp64 as the fp32 MFMA chain is (within 8x, plus one fp32 ulp of
 the largest output), i.e. fp32-level accuracy — NOT bf16-level (which would be ~1e-2).
 
 OPT-IN until its first run on hardware: the kernels were written in a round whose GPU budget was spent, so the default
@@ -59,7 +59,10 @@ def test_bf16x3_is_fp32_accurate(cuda, case):
     for name, ref, a1, a3 in zip(("fwd", "dgrad", "wgrad"), refs, got["f32"], got["bf16x3"]):
         e1, e3 = _err(a1, ref), _err(a3, ref)
         ulp = ref.abs().max().item() * 2.0 ** -23
-        assert e3 <= 3 * e1 + ulp, "%s %s: bf16x3 err %.3e vs f32-MFMA err %.3e (max|ref| %.3e)" % (name, case, e3, e1, ref.abs().max().item())
+        # 8x: a forgotten plane product would show as >= 64x (m*m' alone is 2^-18 of a product against the chain's 2^-25
+        # rounding noise), while the matrix pipe's internal alignment/rounding of 16-product sums may cost a small factor
+        print("%s %s: bf16x3 err %.3e, f32-MFMA err %.3e, ratio %.2f" % (name, case, e3, e1, e3 / max(e1, 1e-30)))
+        assert e3 <= 8 * e1 + ulp, "%s %s: bf16x3 err %.3e vs f32-MFMA err %.3e (max|ref| %.3e)" % (name, case, e3, e1, ref.abs().max().item())
         assert torch.isfinite(a3).all()
 
 
