@@ -272,6 +272,11 @@ typedef struct segmi_sgd_chunk {
 int segmi_sgd_chunk_elems(void);
 int segmi_sgd_step(const segmi_sgd_chunk* table, int nchunks, const float* lr_host, const float* weight_decay_host,
                    const float* momentum_host, int ngroups, segmi_stream_t stream);
+/* Same update with the hyper-parameters in DEVICE memory: `hyper_dev` holds segmi_sgd_hyper_floats() floats,
+ * lr[8] | weight_decay[8] | momentum[8] indexed by group.  For steps captured into a hipGraph (kernel arguments are frozen
+ * at capture; a captured copy from a pinned host buffer refreshes hyper_dev on every replay). */
+int segmi_sgd_hyper_floats(void);
+int segmi_sgd_step_dev(const segmi_sgd_chunk* table, int nchunks, const float* hyper_dev, segmi_stream_t stream);
 
 #ifdef __cplusplus
 }

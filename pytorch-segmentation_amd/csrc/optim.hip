@@ -18,9 +18,15 @@ struct SgdHyper {
     float lr[MAX_GROUPS], wd[MAX_GROUPS], mom[MAX_GROUPS];
 };
 
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const segmi_sgd_chunk* __restrict__ table, SgdHyper h) {
+// DEVHYPER: the hyper-parameters are read from device memory (layout of SgdHyper) instead of the kernel arguments, so a step
+// captured into a hipGraph follows the lr schedule: the host rewrites a pinned staging buffer and the captured H2D copy node
+// refreshes `hd` on every replay (kernel arguments would be frozen at capture).
+template <bool DEVHYPER>
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const segmi_sgd_chunk* __restrict__ table, SgdHyper h, const SgdHyper* __restrict__ hd) {
     const segmi_sgd_chunk c = table[blockIdx.x];
-    const float lr = h.lr[c.group], wd = h.wd[c.group], mom = h.mom[c.group];
+    const float lr = DEVHYPER ? hd->lr[c.group] : h.lr[c.group];
+    const float wd = DEVHYPER ? hd->wd[c.group] : h.wd[c.group];
+    const float mom = DEVHYPER ? hd->mom[c.group] : h.mom[c.group];
     float* __restrict__ p = c.param;
     const float* __restrict__ g = c.grad;
     float* __restrict__ m = c.momentum;
@@ -61,7 +67,17 @@ int segmi_sgd_step(const segmi_sgd_chunk* table_dev, int nchunks, const float* l
         h.wd[i] = i < ngroups ? weight_decay_host[i] : 0.f;
         h.mom[i] = i < ngroups ? momentum_host[i] : 0.f;
     }
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, table_dev, h);
+    hipLaunchKernelGGL((sgd_multi_kernel<false>), dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, table_dev, h,
+                       (const SgdHyper*)nullptr);
+    return segmi_launch_status();
+}
+
+int segmi_sgd_hyper_floats(void) { return 3 * MAX_GROUPS; }
+
+int segmi_sgd_step_dev(const segmi_sgd_chunk* table_dev, int nchunks, const float* hyper_dev, segmi_stream_t stream) {
+    if (!table_dev || nchunks <= 0 || !hyper_dev) return SEGMI_ERR_BADARG;
+    hipLaunchKernelGGL((sgd_multi_kernel<true>), dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, table_dev, SgdHyper{},
+                       reinterpret_cast<const SgdHyper*>(hyper_dev));
     return segmi_launch_status();
 }
 

@@ -81,6 +81,8 @@ SIGNATURES = {
     "segmi_seg_metrics": (i32, [vp, i32, vp, i64, i32, vp, vp]),
     "segmi_sgd_chunk_elems": (i32, []),
     "segmi_sgd_step": (i32, [vp, i32, vp, vp, vp, i32, vp]),
+    "segmi_sgd_hyper_floats": (i32, []),
+    "segmi_sgd_step_dev": (i32, [vp, i32, vp, vp]),
     "segmi_pyramid_pool_workspace": (sz, [i32, i32, i32, i32, i32, vp]),
     "segmi_pyramid_pool_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "segmi_pyramid_pool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -15,8 +15,9 @@ What makes a step capturable here
   * stable gradient addresses: the fused SGD walks a device table of (param, grad, momentum) pointers that is built on
     the host.  Keep `.grad` persistent — `segmi.distributed.DistributedModel` / `GradAllReducer` hold gradients as views
     of flat buckets also in a single process — otherwise `segmi.optim.SGD.step` refuses to rebuild its table mid-capture;
-  * hyper-parameters passed by value (lr, momentum, weight decay) are frozen: re-capture when the schedule changes them
-    (constant-lr benchmarking, or one graph per lr plateau).
+  * hyper-parameters passed by value are frozen at capture: `segmi.optim.SGD(capturable=True)` keeps lr / momentum /
+    weight decay in device memory and refreshes them with a stream-ordered copy issued BEFORE each replay
+    (`GraphedStep(step_fn, pre_replay=optimizer.push_hyper)`), so schedulers keep working.
 """
 import torch
 
@@ -29,24 +30,29 @@ class GraphedStep:
 
     `step_fn()` performs one complete training step on static (pre-allocated, device-resident) inputs and returns a
     tensor or a tuple of tensors (e.g. the loss); the returned tensors are overwritten in place by every replay.
-    Refill the static inputs with `copy_` between calls to feed new batches."""
+    Refill the static inputs with `copy_` between calls to feed new batches.  Construction runs `warmup` eager steps (real
+    training steps) and then captures; the capture itself executes nothing, so `outputs` is defined only after the first
+    replay."""
 
-    def __init__(self, step_fn, warmup=3, device=None):
+    def __init__(self, step_fn, warmup=3, device=None, pre_replay=None):
         if not torch.cuda.is_available():
             raise SegmiError("segmi.graph.GraphedStep needs the MI355X (hipGraph capture; there is no CPU path)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.epoch = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._step_fn = step_fn
+        self._pre_replay = pre_replay     # eager stream work ordered before each replay (e.g. optimizer.push_hyper, input copy_)
         self.replays = 0
         ops.set_dropout_epoch(self.epoch)
         # warm-up on a side stream (lazy allocations, workspace growth, SGD pointer table, hipFuncSetAttribute calls and the
         # SyncBN count exchange all happen here, outside the capture)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(max(1, int(warmup))):
-                self._body()
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        # warmup=0: the caller has already run the step eagerly at least once (a trainer that must not take an extra step)
+        if int(warmup) > 0:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(int(warmup)):
+                    self._body()
+            torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -58,6 +64,8 @@ class GraphedStep:
         return out
 
     def __call__(self):
+        if self._pre_replay is not None:
+            self._pre_replay()
         self.graph.replay()
         self.replays += 1
         return self.outputs

@@ -24,7 +24,15 @@ def _same_layout(a, b):
 
 
 class SGD(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
+    """capturable=True keeps lr / weight decay / momentum in DEVICE memory so that a step captured into a hipGraph
+    (segmi.graph.GraphedStep) follows the lr schedule — kernel arguments would be frozen at capture.  `push_hyper()` sends the
+    current `param_groups` values through a ring of pinned staging slots with an ordinary stream-ordered copy (each slot is
+    reused only after the event of its previous copy has completed, so a host running several replays ahead cannot overwrite
+    values still in flight).  Eager `step()` pushes by itself; around a captured step call `push_hyper()` before each replay."""
+
+    _RING = 8
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False, capturable=False):
         if dampening != 0 or nesterov:
             raise NotImplementedError("segmi.optim.SGD implements dampening=0, nesterov=False (the reference's configuration)")
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False))
@@ -32,6 +40,33 @@ class SGD(torch.optim.Optimizer):
             raise ValueError("segmi.optim.SGD supports up to 8 parameter groups")
         self._table = None
         self._sig = None
+        self.capturable = bool(capturable)
+        self._ring = self._ring_events = self._hyper_dev = None
+        self._ring_pos = 0
+
+    def push_hyper(self):
+        """Stream-ordered refresh of the device-resident hyper-parameters from `param_groups` (capturable=True only)."""
+        if not self.capturable:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("segmi.optim.SGD.push_hyper must stay outside the captured region (call it before graph replay)")
+        if self._ring is None:
+            n = lib.segmi_sgd_hyper_floats()
+            dev = self.param_groups[0]["params"][0].device
+            self._ring = torch.zeros(self._RING, n, dtype=torch.float32).pin_memory()
+            self._ring_events = [None] * self._RING
+            self._hyper_dev = torch.zeros(n, dtype=torch.float32, device=dev)
+        i = self._ring_pos
+        self._ring_pos = (i + 1) % self._RING
+        if self._ring_events[i] is not None:
+            self._ring_events[i].synchronize()          # the copy that last read this slot has executed
+        h = self._ring[i]
+        for gi, g in enumerate(self.param_groups):
+            h[gi], h[8 + gi], h[16 + gi] = float(g["lr"]), float(g["weight_decay"]), float(g["momentum"])
+        self._hyper_dev.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_events[i] = ev
 
     def _build(self):
         """Chunk table on the device; rebuilt only if a gradient / parameter / buffer pointer changed."""
@@ -75,6 +110,14 @@ class SGD(torch.optim.Optimizer):
                 loss = closure()
         self._build()
         if not self._n:
+            return loss
+        if self.capturable:
+            if not torch.cuda.is_current_stream_capturing():
+                self.push_hyper()                  # eager step: always current.  Captured step: the caller pushes before each replay
+            elif self._hyper_dev is None:
+                raise RuntimeError("segmi.optim.SGD(capturable=True): run one eager step (or push_hyper()) before capturing")
+            check(lib.segmi_sgd_step_dev(self._table.data_ptr(), self._n, self._hyper_dev.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "sgd_step_dev")
             return loss
         ng = len(self.param_groups)
         f = (C.c_float * ng)

@@ -27,6 +27,7 @@ class Trainer(BaseTrainer):
         self.metrics = SegMetrics(self.num_classes, self.device)
         self.psp = self.config["arch"]["type"][:3] == "PSP"
         self.iteration_losses = []
+        self._graphed = None             # (GraphedStep, static data, static target) once captured (trainer.hip_graph)
         # side-stream H2D staging of the next batch (reference trainer.py:30-33); loaders that already yield device tensors pass through
         if prefetch and self.device.type == "cuda":
             self.train_loader = DataPrefetcher(self.train_loader, device=self.device)
@@ -46,6 +47,35 @@ class Trainer(BaseTrainer):
             loss = self.loss(output, target)
         return output, loss
 
+    def _graph_step(self, data, target):
+        """trainer.hip_graph: the step of `_train_epoch` replayed from a hipGraph on static input buffers.  Batches whose shape
+        differs from the captured one (a ragged last batch) run eagerly.  The outputs of a replay live in the graph's static
+        buffers and are overwritten by the next replay, so the values handed back are clones (the loss; the logits only feed
+        the device-side metric counters of this iteration)."""
+        from segmi.graph import GraphedStep
+
+        def eager(d, t):
+            self.model.zero_grad()
+            output, loss = self._forward_loss(d, t)
+            loss.backward()
+            self.model.finish_gradients()
+            self.optimizer.step()
+            return output, loss
+
+        if self._graphed is None:
+            out = eager(data, target)          # this iteration's real step, eagerly (allocations, SGD table, hyper-parameters)
+            sd, st = data.clone(), target.clone()
+            gs = GraphedStep(lambda: eager(sd, st), warmup=0, pre_replay=self.optimizer.push_hyper)   # capture only: executes nothing
+            self._graphed = (gs, sd, st)
+            return out
+        gs, sd, st = self._graphed
+        if data.shape != sd.shape or target.shape != st.shape:
+            return eager(data, target)
+        sd.copy_(data, non_blocking=True)
+        st.copy_(target, non_blocking=True)
+        output, loss = gs()
+        return output, loss.detach().clone()
+
     def _train_epoch(self, epoch):
         self.model.train()
         if self.config["arch"]["args"].get("freeze_bn"):
@@ -61,11 +91,14 @@ class Trainer(BaseTrainer):
             data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
             self.lr_scheduler.step(epoch=epoch - 1)
 
-            self.model.zero_grad()
-            output, loss = self._forward_loss(data, target)
-            loss.backward()
-            self.model.finish_gradients()
-            self.optimizer.step()
+            if self.use_graph:
+                output, loss = self._graph_step(data, target)
+            else:
+                self.model.zero_grad()
+                output, loss = self._forward_loss(data, target)
+                loss.backward()
+                self.model.finish_gradients()
+                self.optimizer.step()
 
             loss_d = loss.detach()
             loss_sum += loss_d

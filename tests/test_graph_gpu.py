@@ -94,3 +94,73 @@ def test_graph_with_dropout_draws_fresh_masks(cuda):
         assert all(torch.isfinite(torch.tensor(ls)))
     finally:
         gs.close()
+
+
+def test_capturable_sgd_follows_the_lr_schedule_inside_a_graph(cuda):
+    """lr changes every iteration (the reference's Poly schedule does, trainer.py:52): a graph captured once must apply the
+    lr of each replay — device-resident hyper-parameters pushed before the replay — and match eager steps bit for bit."""
+    from segmi.graph import GraphedStep
+    from segmi.optim import SGD
+    torch.manual_seed(1)
+    w0 = torch.randn(1000, device=cuda)
+    grads = [torch.randn(1000, device=cuda) for _ in range(6)]
+    lrs = [0.1 * (1 - i / 6.0) ** 0.9 for i in range(6)]
+
+    def run(capturable, graphed):
+        w = torch.nn.Parameter(w0.clone())
+        w.grad = torch.zeros_like(w)
+        opt = SGD([w], lr=lrs[0], momentum=0.9, weight_decay=1e-4, capturable=capturable)
+        src = torch.zeros_like(w)
+
+        def step():
+            w.grad.copy_(src)
+            opt.step()
+            return w
+
+        gs = None
+        for i in range(6):
+            opt.param_groups[0]["lr"] = lrs[i]
+            src.copy_(grads[i])
+            (gs() if gs is not None else step())
+            if graphed and i == 2:                      # three eager steps, then capture (warmup=0: capture executes nothing)
+                gs = GraphedStep(step, warmup=0, pre_replay=opt.push_hyper)
+        torch.cuda.synchronize()
+        if gs is not None:
+            gs.close()
+        return w.detach().clone()
+
+    ref = run(False, False)
+    assert torch.equal(run(True, False), ref)           # device-resident hyper-parameters, eager
+    got = run(True, True)                                # ... and replayed from a graph
+    assert torch.equal(got, ref), (got - ref).abs().max().item()
+
+
+def test_trainer_with_hip_graph_matches_the_eager_trainer(cuda, tmp_path):
+    """config trainer.hip_graph = true: same 4-iteration UNet trajectory (Poly lr changes every iteration) as the eager
+    re-hosted Trainer, bit for bit (UNet has no dropout; every kernel is deterministic)."""
+    import json
+    import dataloaders
+    import models
+    from oracle.weights import synth_state_dict
+    from trainer import Trainer
+    from utils.losses import CrossEntropyLoss2d
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = torch.load(os.path.join(ROOT, "tests", "golden", "trainer_unet.pt"), weights_only=False)
+
+    def run(graph):
+        config = json.loads(json.dumps(rec["config"]))
+        config["trainer"].update(save_dir=str(tmp_path / ("g" if graph else "e")), log_dir=str(tmp_path), save_period=10, hip_graph=graph)
+        loader = dataloaders.Synth(**config["train_loader"]["args"])
+        model = models.UNet(loader.dataset.num_classes, **config["arch"]["args"])
+        model.load_state_dict(synth_state_dict(rec["manifest"], seed=11))
+        tr = Trainer(model=model, loss=CrossEntropyLoss2d(ignore_index=config["ignore_index"]), resume=None, config=config,
+                     train_loader=loader, val_loader=None)
+        tr.train()
+        return [float(v) for v in tr.iteration_losses], tr.metrics.counts(), {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+
+    le, ce, se = run(False)
+    lg, cg, sg = run(True)
+    assert le == lg, (le, lg)
+    assert float(ce[0]) == float(cg[0]) and float(ce[1]) == float(cg[1])
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
