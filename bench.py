@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
                                                          "one host call per step instead of ~800 launches")
-    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
+    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3", "bf16x3_simple", "bf16x3_pk"],
                     help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
                          "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
     args = ap.parse_args()
@@ -145,7 +145,7 @@ def main():
 
     from segmi import ops as segmi_ops
     segmi_ops.set_conv_math(args.conv_math)
-    peak = PEAK_BF16X3_EQUIV_TFLOPS if args.conv_math == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_BF16X3_EQUIV_TFLOPS if args.conv_math != "f32" else PEAK_FP32_MFMA_TFLOPS
 
     arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)

@@ -87,7 +87,14 @@ int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, 
  *                          accumulation: per-product error <= 2^-24 (one fp32 rounding), data in HBM stays fp32.
  * Also selectable at first use with the environment variable SEGMI_CONV_MATH=bf16x3.  aten has no counterpart (the
  * reference computes in fp32, trainer.py:56); this is the drop-in's throughput knob. */
-enum segmi_conv_math { SEGMI_CONV_MATH_F32 = 0, SEGMI_CONV_MATH_BF16X3 = 1 };
+enum segmi_conv_math {
+    SEGMI_CONV_MATH_F32 = 0,
+    SEGMI_CONV_MATH_BF16X3 = 1,
+    /* the same bf16x3 arithmetic with a different loop structure, kept for A/B measurements (SEGMI_CONV_MATH=bf16x3_simple /
+     * bf16x3_pk): per-chunk loop scheduled by the compiler; pipelined loop with packed residual subtractions */
+    SEGMI_CONV_MATH_BF16X3_SIMPLE = 2,
+    SEGMI_CONV_MATH_BF16X3_PK = 3
+};
 int segmi_conv_set_math(int math);
 int segmi_conv_get_math(void);
 /* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */

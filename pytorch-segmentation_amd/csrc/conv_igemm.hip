@@ -274,7 +274,11 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3 };
+// MATH_BF16X3 is the scheme as described; the other two are the same arithmetic kept for A/B measurements of the loop structure:
+// _SIMPLE = per-chunk loop left to the compiler's scheduler (no cross-chunk pipeline, fewer registers), _PK = pipelined loop
+// with the SLP fence off (residual pairs as v_pk_add_f32).
+enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3, MATH_BF16X3_SIMPLE = SEGMI_CONV_MATH_BF16X3_SIMPLE,
+       MATH_BF16X3_PK = SEGMI_CONV_MATH_BF16X3_PK };
 
 struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
 
@@ -286,27 +290,28 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 // v_pk_add_f32, which on gfx950 is no faster than two fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the
 // costliest filler beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  The empty asm is
 // an optimisation fence on ONE value of the pair (emits nothing; the subtractions stay ordinary, schedulable VALU).
-// -DSEGMI_SPLIT_PK=1 restores the compiler's choice for A/B runs.
+// PK = true (MATH_BF16X3_PK) leaves the choice to the compiler, for A/B runs.
+template <bool PK>
 __device__ __forceinline__ void slp_fence(float& v) {
-#if !(defined(SEGMI_SPLIT_PK) && SEGMI_SPLIT_PK)
-    asm("" : "+v"(v));
-#endif
+    if (!PK) asm("" : "+v"(v));
 }
+template <bool PK>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     h = cvt_pk_bf16(x0, x1);
     const float r0 = x0 - __builtin_bit_cast(float, h << 16);
     float r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
-    slp_fence(r1);
+    slp_fence<PK>(r1);
     m = cvt_pk_bf16(r0, r1);
     const float s0 = r0 - __builtin_bit_cast(float, m << 16);
     float s1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
-    slp_fence(s1);
+    slp_fence<PK>(s1);
     l = cvt_pk_bf16(s0, s1);
 }
+template <bool PK = false>
 __device__ __forceinline__ Planes split8(const float (&x)[8]) {
     unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    for (int i = 0; i < 4; ++i) split_pair<PK>(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
     Planes p;
     p.h = u32x4_t{h[0], h[1], h[2], h[3]};
     p.m = u32x4_t{m[0], m[1], m[2], m[3]};
@@ -517,7 +522,39 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
-    if (MATH == MATH_BF16X3) {
+    constexpr bool PK = MATH == MATH_BF16X3_PK;
+    if (MATH == MATH_BF16X3_SIMPLE) {
+        // same fragments and products, one chunk at a time, instruction order left to the compiler (A/B baseline of the pipeline)
+        for (int it = it0; it < T; ++it) {
+            if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
+            const float* Ab = smem + buf * STAGE;
+            const float* Bb = Ab + BM * BK;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int g0 = ks * 4 + lhalf * 2;
+                const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
+                Planes qa[TM], qb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
+                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                    qa[i] = split8<PK>(x);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
+                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                    qb[j] = split8<PK>(x);
+                }
+                mma_bf16x3<TM, TN>(acc, qa, qb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else if (MATH != MATH_F32) {
         // A lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two swizzled
         // 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair).
         // Software pipeline over 16-wide k steps, ACROSS chunk boundaries (matrix instructions only need registers, so the
@@ -552,9 +589,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         auto phase_b = [&]() {                                 // MFMAs of step 0 || split of step 1, then hand over the stage
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
             mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
@@ -573,9 +610,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             fetch(Ab, Bb, 0);
             fetch(Ab, Bb, 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
             phase_b();
         }
         for (int it = it0 + 1; it < T; ++it) {
@@ -587,9 +624,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             // phase A: MFMAs of the pending step || split of step 0
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
             mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
@@ -962,7 +999,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (MATH == MATH_BF16X3) {
+    constexpr bool PK = MATH == MATH_BF16X3_PK;
+    if (MATH == MATH_BF16X3_SIMPLE) {
+        if (mbeg < mend) {
+            issue(mbeg, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int buf = 0;
+            for (int mb = mbeg; mb < mend; mb += BKP) {
+                if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
+                const float* Ab = smem + buf * STAGE;
+                const float* Bb = Ab + BKP * BM;
+                float ra[BKP / 16][TM][8], rb[BKP / 16][TN][8];
+#pragma unroll
+                for (int ks = 0; ks < BKP / 16; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
+                }
+#pragma unroll
+                for (int ks = 0; ks < BKP / 16; ++ks) {
+                    Planes qa[TM], qb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) qa[i] = split8<PK>(ra[ks][i]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) qb[j] = split8<PK>(rb[ks][j]);
+                    mma_bf16x3<TM, TN>(acc, qa, qb);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    } else if (MATH != MATH_F32) {
         // Same software pipeline as conv_dma_kernel (phase A: pending step's MFMAs || split of step 0; phase B: step 0's
         // MFMAs || split of step 1; the second step of a chunk issues after the barrier).  The reduction axis (pixels) is the
         // LDS row index here: a lane gathers its channel's 8 pixels (ks*16 + lhalf*8 + e) with ds_read_b32 (lanes of a
@@ -985,9 +1059,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         auto phase_b = [&]() {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
             mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
@@ -1007,9 +1081,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             fetch(smem, smem + BKP * BM, 0);
             fetch(smem, smem + BKP * BM, 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);        // first chunk: exposed split
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);        // first chunk: exposed split
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
             phase_b();
             for (int mb = mbeg + BKP; mb < mend; mb += BKP) {
                 if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
@@ -1019,9 +1093,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 fetch(Ab, Bb, 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
+                for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+                for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
                 mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
 #pragma unroll
                 for (int q = 0; q < NMMA; ++q) {
@@ -1186,7 +1260,10 @@ int g_math = -1;
 int conv_math() {
     if (g_math < 0) {
         const char* e = getenv("SEGMI_CONV_MATH");
-        g_math = (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? MATH_BF16X3 : MATH_F32;
+        g_math = MATH_F32;
+        if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_math = MATH_BF16X3;
+        else if (e && !strcmp(e, "bf16x3_simple")) g_math = MATH_BF16X3_SIMPLE;
+        else if (e && !strcmp(e, "bf16x3_pk")) g_math = MATH_BF16X3_PK;
     }
     return g_math;
 }
@@ -1201,14 +1278,19 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
-    const bool x3 = conv_math() == MATH_BF16X3;
-    if (fast) {
-        if (x3) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-        else    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_F32>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    } else {
-        if (x3) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-        else    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_F32>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+#define SEGMI_LAUNCH_DMA(FASTV, MATHV) \
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, FASTV, MATHV>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes)
+    switch (conv_math() * 2 + (fast ? 1 : 0)) {
+        case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_DMA(true, MATH_F32); break;
+        case MATH_F32 * 2:               SEGMI_LAUNCH_DMA(false, MATH_F32); break;
+        case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_DMA(true, MATH_BF16X3); break;
+        case MATH_BF16X3 * 2:            SEGMI_LAUNCH_DMA(false, MATH_BF16X3); break;
+        case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_DMA(true, MATH_BF16X3_SIMPLE); break;
+        case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_DMA(false, MATH_BF16X3_SIMPLE); break;
+        case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_DMA(true, MATH_BF16X3_PK); break;
+        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X3_PK); break;
     }
+#undef SEGMI_LAUNCH_DMA
     if (p.ksplit > 1) {
         const long n4 = (long)p.M * p.ldd / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -1354,14 +1436,19 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     unsigned xb, dyb;
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
-        const bool x3 = conv_math() == MATH_BF16X3;
-        if (p.Q % WG_BKP == 0) {
-            if (x3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true, MATH_BF16X3>), grid, dim3(256), lds, st, p, xb, dyb);
-            else    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true, MATH_F32>), grid, dim3(256), lds, st, p, xb, dyb);
-        } else {
-            if (x3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, MATH_BF16X3>), grid, dim3(256), lds, st, p, xb, dyb);
-            else    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, MATH_F32>), grid, dim3(256), lds, st, p, xb, dyb);
+#define SEGMI_LAUNCH_WGRAD(ROWQV, MATHV) \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, ROWQV, MATHV>), grid, dim3(256), lds, st, p, xb, dyb)
+        switch (conv_math() * 2 + (p.Q % WG_BKP == 0 ? 1 : 0)) {
+            case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_WGRAD(true, MATH_F32); break;
+            case MATH_F32 * 2:               SEGMI_LAUNCH_WGRAD(false, MATH_F32); break;
+            case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3); break;
+            case MATH_BF16X3 * 2:            SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3); break;
+            case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_SIMPLE); break;
+            case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_SIMPLE); break;
+            case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_PK); break;
+            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_PK); break;
         }
+#undef SEGMI_LAUNCH_WGRAD
     }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();
@@ -1510,7 +1597,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
 }
 
 int segmi_conv_set_math(int math) {
-    if (math != SEGMI_CONV_MATH_F32 && math != SEGMI_CONV_MATH_BF16X3) return SEGMI_ERR_BADARG;
+    if (math < SEGMI_CONV_MATH_F32 || math > SEGMI_CONV_MATH_BF16X3_PK) return SEGMI_ERR_BADARG;
     g_math = math;
     return SEGMI_OK;
 }

@@ -31,8 +31,9 @@ def _err(a, ref):
     return (a.detach().cpu().double() - ref).abs().max().item()
 
 
+@pytest.mark.parametrize("variant", ["bf16x3", "bf16x3_simple", "bf16x3_pk"])
 @pytest.mark.parametrize("case", CASES)
-def test_bf16x3_is_fp32_accurate(cuda, case):
+def test_bf16x3_is_fp32_accurate(cuda, case, variant):
     from segmi import ops
     N, C, H, W, K, R, stride, pad, dil = case
     g = torch.Generator().manual_seed(11)
@@ -46,7 +47,7 @@ def test_bf16x3_is_fp32_accurate(cuda, case):
 
     got = {}
     try:
-        for math in ("f32", "bf16x3"):
+        for math in ("f32", variant):
             ops.set_conv_math(math)
             assert ops.get_conv_math() == math
             xd = x.to(cuda).requires_grad_(True)
@@ -56,12 +57,12 @@ def test_bf16x3_is_fp32_accurate(cuda, case):
             got[math] = (yd, xd.grad, wd.grad)
     finally:
         ops.set_conv_math("f32")
-    for name, ref, a1, a3 in zip(("fwd", "dgrad", "wgrad"), refs, got["f32"], got["bf16x3"]):
+    for name, ref, a1, a3 in zip(("fwd", "dgrad", "wgrad"), refs, got["f32"], got[variant]):
         e1, e3 = _err(a1, ref), _err(a3, ref)
         ulp = ref.abs().max().item() * 2.0 ** -23
         # 8x: a forgotten plane product would show as >= 64x (m*m' alone is 2^-18 of a product against the chain's 2^-25
         # rounding noise), while the matrix pipe's internal alignment/rounding of 16-product sums may cost a small factor
-        print("%s %s: bf16x3 err %.3e, f32-MFMA err %.3e, ratio %.2f" % (name, case, e3, e1, e3 / max(e1, 1e-30)))
+        print("%s %s %s: bf16x3 err %.3e, f32-MFMA err %.3e, ratio %.2f" % (variant, name, case, e3, e1, e3 / max(e1, 1e-30)))
         assert e3 <= 8 * e1 + ulp, "%s %s: bf16x3 err %.3e vs f32-MFMA err %.3e (max|ref| %.3e)" % (name, case, e3, e1, ref.abs().max().item())
         assert torch.isfinite(a3).all()
 
