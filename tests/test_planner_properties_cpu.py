@@ -4,7 +4,9 @@ randomly drawn convolution descriptors (hypothesis), plus the BASELINE configs' 
 import re
 
 import pytest
-from hypothesis import given, settings, strategies as st
+
+hypothesis = pytest.importorskip("hypothesis")          # a missing optional package must not break collection of the suite
+from hypothesis import given, settings, strategies as st  # noqa: E402
 
 
 def _desc(N, H, W, C, K, R, stride, dil):
