@@ -91,7 +91,8 @@ class BaseTrainer:
         #   "conv_math": "f32" | "bf16x3"   matrix arithmetic of the convolutions (include/segmi.h segmi_conv_set_math)
         #   "hip_graph": true               replay the training step from a hipGraph (segmi.graph.GraphedStep); needs the fused SGD
         from segmi import ops as segmi_ops
-        segmi_ops.set_conv_math(cfg_trainer.get("conv_math", "f32"))
+        if "conv_math" in cfg_trainer:            # absent: leave the process-wide setting (SEGMI_CONV_MATH or fp32) alone
+            segmi_ops.set_conv_math(cfg_trainer["conv_math"])
         self.use_graph = bool(cfg_trainer.get("hip_graph", False))
         if self.use_graph and not fused:
             raise ValueError("trainer.hip_graph needs an optimizer with device-resident hyper-parameters (segmi.optim.SGD)")
