@@ -56,3 +56,50 @@ def test_dot_products_match_fp64_as_well_as_the_fp32_chain_does():
     e3 = np.abs(M.dot_bf16x3(a, b) - ref) / ref
     e1 = np.abs(M.dot_f32_chain(a, b) - ref) / ref
     assert e3.max() <= 2 * e1.max() and abs(np.mean((M.dot_bf16x3(a, b) - ref) / ref)) <= 2.0 ** -22, (e3.max(), e1.max())
+
+
+def test_pspnet_logits_under_the_bf16x3_model_are_as_close_to_fp64_as_fp32_is(monkeypatch):
+    """Network-scale evidence without a GPU: PSPNet-R50 forward (oracle/pspnet_ref.py) with every convolution computed the
+    bf16x3 way — operands split into three bf16 planes (torch's RNE conversion, as v_cvt_pk_bf16_f32), the six kept plane
+    products summed exactly (fp64), the result rounded to fp32 — against the same network in fp64 and in plain fp32.
+    The dropped plane products must not move the logits more than fp32 rounding already does."""
+    import torch
+    import torch.nn.functional as F
+    import models
+    from oracle import pspnet_ref
+
+    torch.manual_seed(0)
+    sd32 = {k: v.detach().clone().contiguous() for k, v in models.PSPNet(5, backbone="resnet50", pretrained=False).state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+
+    def split3(t):
+        h = t.to(torch.bfloat16).to(torch.float32)
+        r = t - h
+        m = r.to(torch.bfloat16).to(torch.float32)
+        l = (r - m).to(torch.bfloat16).to(torch.float32)
+        assert torch.equal((h.double() + m.double()) + l.double(), t.double())
+        return h, m, l
+
+    def conv_x3(sd, key, inp, stride=1, pad=0, dil=1):
+        w, b = sd[key + ".weight"], sd.get(key + ".bias")
+        (xh, xm, xl), (wh, wm, wl) = split3(inp), split3(w)
+        acc = None
+        for pa, pb in ((xl, wh), (xh, wl), (xm, wm), (xm, wh), (xh, wm), (xh, wh)):
+            y = F.conv2d(pa.double(), pb.double(), None, stride, pad, dil)
+            acc = y if acc is None else acc + y
+        y = acc.to(torch.float32)
+        return y if b is None else y + b.view(1, -1, 1, 1)
+
+    with torch.no_grad():
+        ref = pspnet_ref.pspnet_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}, x.double(),
+                                        training=False)
+        f32 = pspnet_ref.pspnet_forward(sd32, x, training=False)
+        monkeypatch.setattr(pspnet_ref, "_conv", conv_x3)
+        x3 = pspnet_ref.pspnet_forward(sd32, x, training=False)
+    scale = ref.abs().max().item()
+    e32 = (f32.double() - ref).abs().max().item() / scale
+    ex3 = (x3.double() - ref).abs().max().item() / scale
+    assert e32 < 1e-4 and ex3 < 1e-4, (e32, ex3)                # both at fp32 level through 50+ layers ...
+    assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)                  # ... and the split costs nothing beyond fp32 rounding
+    assert int((x3.argmax(1) != f32.argmax(1)).sum()) <= 2      # masks agree (flips only possible at exact near-ties)
