@@ -93,7 +93,10 @@ enum segmi_conv_math {
     /* the same bf16x3 arithmetic with a different loop structure, kept for A/B measurements (SEGMI_CONV_MATH=bf16x3_simple /
      * bf16x3_pk): per-chunk loop scheduled by the compiler; pipelined loop with packed residual subtractions */
     SEGMI_CONV_MATH_BF16X3_SIMPLE = 2,
-    SEGMI_CONV_MATH_BF16X3_PK = 3
+    SEGMI_CONV_MATH_BF16X3_PK = 3,
+    /* REDUCED precision, never the parity path: two bf16 planes per operand, three products (16 significand bits per
+     * operand, per-product error <= 2^-15, ~2^-18 typical — between TF32 and fp32); half the work of bf16x3 (SEGMI_CONV_MATH=bf16x2) */
+    SEGMI_CONV_MATH_BF16X2 = 4
 };
 int segmi_conv_set_math(int math);
 int segmi_conv_get_math(void);

@@ -278,7 +278,11 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // _SIMPLE = per-chunk loop left to the compiler's scheduler (no cross-chunk pipeline, fewer registers), _PK = pipelined loop
 // with the SLP fence off (residual pairs as v_pk_add_f32).
 enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3, MATH_BF16X3_SIMPLE = SEGMI_CONV_MATH_BF16X3_SIMPLE,
-       MATH_BF16X3_PK = SEGMI_CONV_MATH_BF16X3_PK };
+       MATH_BF16X3_PK = SEGMI_CONV_MATH_BF16X3_PK,
+       // REDUCED precision (not fp32-equivalent, never the parity or headline path): two planes (h, m) per operand, three
+       // products (m*h', h*m', h*h'): 16 significand bits per operand, per-product error <= 2^-15 (typically 2^-18); half the split work and
+       // half the matrix instructions of bf16x3.  Network-scale effect measured on the CPU model: DESIGN §4.1b.
+       MATH_BF16X2 = SEGMI_CONV_MATH_BF16X2 };
 
 struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
 
@@ -323,20 +327,22 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const u32x4_t& b, 
 }
 // acc[i][j] += A_i (x) B_j over 16 k-values, six plane products, smallest terms first; the (i, j) loop is innermost so
 // that consecutive matrix instructions target different accumulators
-template <int TM, int TN>
+template <int TM, int TN, int NP = 3>
 __device__ __forceinline__ void mma_bf16x3(f32x16 (&acc)[TM][TN], const Planes (&a)[TM], const Planes (&b)[TN]) {
+    if (NP == 3) {      // NP == 2 (MATH_BF16X2): the l planes and the m*m' product are not used (and their computation is dead code)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].l, b[j].h, acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].l, b[j].h, acc[i][j]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].l, acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].l, acc[i][j]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].m, acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].m, acc[i][j]);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -523,6 +529,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
     constexpr bool PK = MATH == MATH_BF16X3_PK;
+    constexpr int NP = MATH == MATH_BF16X2 ? 2 : 3;      // bf16 planes per operand
     if (MATH == MATH_BF16X3_SIMPLE) {
         // same fragments and products, one chunk at a time, instruction order left to the compiler (A/B baseline of the pipeline)
         for (int it = it0; it < T; ++it) {
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
                     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
                     qb[j] = split8<PK>(x);
                 }
-                mma_bf16x3<TM, TN>(acc, qa, qb);
+                mma_bf16x3<TM, TN, NP>(acc, qa, qb);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -564,8 +571,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         // Each phase pairs 6*TM*TN matrix instructions (32 cycles each) with the ~44 VALU per tile row-block of one split
         // (sched_group_barrier: 1 MFMA + its share of VALU per group), so neither pipe waits for the other inside a wave;
         // only the very first split of a tile is exposed, and the last step drains after the loop.
-        constexpr int NMMA = TM * TN * 6;
-        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 8 unpack + ... = 44
+        constexpr int NMMA = TM * TN * (NP == 3 ? 6 : 3);
+        constexpr int VPG = ((TM + TN) * (NP == 3 ? 44 : 24) + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub (44), or 8 + 8 + 8
         float ra[2][TM][8], rb[2][TN][8];
         Planes pa[2][TM], pb[2][TN];
         auto fetch = [&](const float* Ab, const float* Bb, int ks) {
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
-            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
+            mma_bf16x3<TM, TN, NP>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
-            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
+            mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             }
             phase_b();
         }
-        if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
+        if (it0 < T) mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
     } else
     for (int it = it0; it < T; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
@@ -1000,6 +1007,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     constexpr bool PK = MATH == MATH_BF16X3_PK;
+    constexpr int NP = MATH == MATH_BF16X2 ? 2 : 3;      // bf16 planes per operand
     if (MATH == MATH_BF16X3_SIMPLE) {
         if (mbeg < mend) {
             issue(mbeg, 0);
@@ -1029,7 +1037,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                     for (int i = 0; i < TM; ++i) qa[i] = split8<PK>(ra[ks][i]);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) qb[j] = split8<PK>(rb[ks][j]);
-                    mma_bf16x3<TM, TN>(acc, qa, qb);
+                    mma_bf16x3<TM, TN, NP>(acc, qa, qb);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -1041,8 +1049,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         // MFMAs || split of step 1; the second step of a chunk issues after the barrier).  The reduction axis (pixels) is the
         // LDS row index here: a lane gathers its channel's 8 pixels (ks*16 + lhalf*8 + e) with ds_read_b32 (lanes of a
         // half-wave read consecutive channels of one pixel: conflict-free as in the fp32 path).
-        constexpr int NMMA = TM * TN * 6;
-        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;
+        constexpr int NMMA = TM * TN * (NP == 3 ? 6 : 3);
+        constexpr int VPG = ((TM + TN) * (NP == 3 ? 44 : 24) + NMMA - 1) / NMMA;
         float ra[2][TM][8], rb[2][TN][8];
         Planes pa[2][TM], pb[2][TN];
         int buf = 0;
@@ -1062,7 +1070,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
-            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
+            mma_bf16x3<TM, TN, NP>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1096,7 +1104,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
-                mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
+                mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);
 #pragma unroll
                 for (int q = 0; q < NMMA; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1104,7 +1112,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 }
                 phase_b();
             }
-            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);                            // drain
+            mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);                            // drain
         }
     } else
     if (mbeg < mend) {
@@ -1264,6 +1272,7 @@ int conv_math() {
         if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_math = MATH_BF16X3;
         else if (e && !strcmp(e, "bf16x3_simple")) g_math = MATH_BF16X3_SIMPLE;
         else if (e && !strcmp(e, "bf16x3_pk")) g_math = MATH_BF16X3_PK;
+        else if (e && !strcmp(e, "bf16x2")) g_math = MATH_BF16X2;
     }
     return g_math;
 }
@@ -1288,7 +1297,9 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
         case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_DMA(true, MATH_BF16X3_SIMPLE); break;
         case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_DMA(false, MATH_BF16X3_SIMPLE); break;
         case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_DMA(true, MATH_BF16X3_PK); break;
-        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X3_PK); break;
+        case MATH_BF16X3_PK * 2:         SEGMI_LAUNCH_DMA(false, MATH_BF16X3_PK); break;
+        case MATH_BF16X2 * 2 + 1:        SEGMI_LAUNCH_DMA(true, MATH_BF16X2); break;
+        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X2); break;
     }
 #undef SEGMI_LAUNCH_DMA
     if (p.ksplit > 1) {
@@ -1446,7 +1457,9 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
             case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_SIMPLE); break;
             case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_SIMPLE); break;
             case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_PK); break;
-            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_PK); break;
+            case MATH_BF16X3_PK * 2:         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_PK); break;
+            case MATH_BF16X2 * 2 + 1:        SEGMI_LAUNCH_WGRAD(true, MATH_BF16X2); break;
+            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X2); break;
         }
 #undef SEGMI_LAUNCH_WGRAD
     }
@@ -1597,7 +1610,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
 }
 
 int segmi_conv_set_math(int math) {
-    if (math < SEGMI_CONV_MATH_F32 || math > SEGMI_CONV_MATH_BF16X3_PK) return SEGMI_ERR_BADARG;
+    if (math < SEGMI_CONV_MATH_F32 || math > SEGMI_CONV_MATH_BF16X2) return SEGMI_ERR_BADARG;
     g_math = math;
     return SEGMI_OK;
 }

@@ -170,7 +170,8 @@ def conv_out_size(H, k, stride, pad, dil):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-CONV_MATH = {"f32": 0, "bf16x3": 1, "bf16x3_simple": 2, "bf16x3_pk": 3}   # 2, 3: loop-structure variants of bf16x3 for A/B runs
+CONV_MATH = {"f32": 0, "bf16x3": 1, "bf16x3_simple": 2, "bf16x3_pk": 3,   # 2, 3: loop-structure variants of bf16x3 for A/B runs
+             "bf16x2": 4}                                                    # reduced precision (16 significand bits per operand)
 
 
 def set_conv_math(name):

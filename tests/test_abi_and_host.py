@@ -78,7 +78,7 @@ def test_conv_math_switch_and_variant_names():
     d = ConvDesc(8, 64, 64, 512, 512, 3, 3, 64, 64, 1, 2, 2, 512, 512)
     assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 0>"
     assert lib.segmi_conv_set_math(7) == -1 and lib.segmi_conv_set_math(-1) == -1 and ops.get_conv_math() == "f32"
-    for name, code in (("bf16x3_simple", 2), ("bf16x3_pk", 3)):               # A/B loop variants of the same arithmetic
+    for name, code in (("bf16x3_simple", 2), ("bf16x3_pk", 3), ("bf16x2", 4)):   # A/B loop variants; reduced-precision mode
         ops.set_conv_math(name)
         assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, %d>" % code
     ops.set_conv_math("f32")
@@ -115,8 +115,8 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
         kern[name]["agpr_count"] = int(blk.split()[0])
     dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
-    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(4)]   # last template argument = MATH
-    assert per_math == [28, 28, 28, 28], per_math
+    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]   # last template argument = MATH
+    assert per_math == [28, 28, 28, 28, 28], per_math
     for n, v in dma.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
         # .vgpr_count is the unified total (arch VGPRs up to the accumulator offset + AGPRs); 2 x 256 = one SIMD's file

@@ -114,3 +114,31 @@ def test_bf16x3_training_step_matches_f32_path(cuda):
     assert (o1 - o3).abs().max().item() <= 1e-3 * o1.abs().max().item()
     assert abs(l1 - l3) <= 1e-4
     assert ((g1 - g3).norm() / g1.norm()).item() <= 1e-3
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16x2_reduced_precision_mode_is_what_it_says(cuda, case):
+    """SEGMI_CONV_MATH_BF16X2 (two planes, three products) is NOT fp32-equivalent: 16 significand bits per operand.  It must
+    still meet the per-op convolution tolerance of the parity suite (1e-4 * max|ref|, tests/test_ops_gpu.py) and be far
+    better than plain bf16 (~4e-3)."""
+    from segmi import ops
+    N, C, H, W, K, R, stride, pad, dil = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad, dilation=dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    try:
+        ops.set_conv_math("bf16x2")
+        xd = x.to(cuda).requires_grad_(True)
+        wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        yd = ops.conv2d(xd, wd, None, stride, pad, dil)
+        yd.backward(gy.to(cuda))
+    finally:
+        ops.set_conv_math("f32")
+    for name, ref, a in zip(("fwd", "dgrad", "wgrad"), (yr.detach(), xr.grad, wr.grad), (yd, xd.grad, wd.grad)):
+        e = _err(a, ref) / ref.abs().max().item()
+        print("bf16x2 %s %s: rel err %.3e" % (name, case, e))
+        assert e <= 1e-4, (name, case, e)

@@ -33,7 +33,7 @@ x3)
   # of the whole training step (SEGMI_CONV_MATH is read at the first convolution of the process)
   ( SEGMI_TEST_BF16X3=1 timeout 900 python -m pytest tests/test_conv_bf16x3_gpu.py -m gpu -q -s 2>&1 | tail -60 ) > gpurun_out/x3_tests.log
   cat gpurun_out/x3_tests.log
-  for m in f32 bf16x3 bf16x3_simple bf16x3_pk; do
+  for m in f32 bf16x3 bf16x3_simple bf16x3_pk bf16x2; do
     ( SEGMI_CONV_MATH=$m timeout 300 python tools/conv_bench.py psp_bottleneck l4_3x3_d4 l4_1x1_up l3_1x1_down l1_1x1 stem3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/x3_convbench_$m.txt
     ( timeout 600 python bench.py --no-cpu --conv-math $m 2>&1 | tail -1 ) > gpurun_out/x3_bench_$m.log
   done
