@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, per-layer conv table, rocprof kernel stats.
-# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc] [x3] [x3prof] [graph]
+# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc] [x3] [x3prof] [x3pmc] [graph]
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -44,6 +44,18 @@ x3prof)
   ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x3prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --conv-math bf16x3 2>&1 | tail -2 ) > gpurun_out/x3prof.log
   find gpurun_out/x3prof -name "*kernel_trace*" -size +30M -delete
   find gpurun_out/x3prof -type f | head ;;
+x3pmc)
+  # matrix-pipe / issue counters of ONE layer in isolation under both arithmetics (same counter set as profiles/r01_psp_bottleneck_pmc.txt;
+  # --pmc with --kernel-trace only), then an LDS/L2 pass: is the bf16x3 loop VALU-issue bound as modelled, or waiting on operand DMA?
+  rm -rf gpurun_out/x3pmc
+  for m in f32 bf16x3; do
+    ( SEGMI_CONV_MATH=$m timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+        --output-format csv -d gpurun_out/x3pmc/sq_$m -o r -- python tools/conv_bench.py psp_bottleneck l4_1x1_up --iters 5 2>&1 | tail -8 ) > gpurun_out/x3pmc_sq_$m.log
+    ( SEGMI_CONV_MATH=$m timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS TCC_HIT_sum TCC_MISS_sum \
+        --output-format csv -d gpurun_out/x3pmc/mem_$m -o r -- python tools/conv_bench.py psp_bottleneck l4_1x1_up --iters 5 2>&1 | tail -8 ) > gpurun_out/x3pmc_mem_$m.log
+  done
+  find gpurun_out/x3pmc -name "*kernel_trace*" -size +30M -delete
+  for d in gpurun_out/x3pmc/*/; do echo "== $d"; python tools/pmc_summary.py $d r 2>&1 | head -40; done ;;
 graph)
   # first hardware run of hipGraph capture (segmi/graph.py): opt-in tests, then eager vs replayed step on the launch-paced
   # UNet config and on the bench line
