@@ -24,6 +24,8 @@ Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -105,6 +107,20 @@ def cpu_baseline(name, seconds_cap=40.0):
                       % (len(times), nb, h, w, best)}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(argv, n, port):
+    """The per-GPU launcher `python bench.py --gpus N ...` re-executes itself under (the driver's own form for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,22 +138,33 @@ def main():
                          "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: one command drives all GPUs, like the reference (base/base_trainer.py:33-38, train.py:46-53)
+        # — by re-executing itself as one rank per GPU under torch.distributed.run
+        cmd = launch_command(sys.argv[1:], args.gpus, free_port())
+        print("[bench] " + " ".join(cmd), file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    oversubscribed = world > ndev      # more ranks than GPUs (launcher smoke on a 1-GPU box): ranks share devices, RCCL cannot
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     ddp = world > 1 or args.force_ddp
+    backend = None
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = "gloo" if oversubscribed else "nccl"           # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from segmi.distributed import DistributedModel
     from segmi.profile import KernelTimer
@@ -263,7 +290,9 @@ def main():
                                    "BN batch stats%s, dropout on" % (args.config, arch, "-" + kw["backbone"] if "backbone" in kw else "", nb, h, w,
                                                                       classes, loss_name, " + 0.4*aux" if psp else "",
                                                                       " (SyncBN)" if args.sync_bn and ddp else ""),
-                       "global_batch": nb * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5),
+                       "global_batch": nb * world, "parallelism": "dp%d" % world,
+                       "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
+                       "rccl_ranks": (dist.get_world_size() if ddp and backend == "nccl" else 0), "final_loss": round(final_loss, 5),
                        "conv_math": args.conv_math, "hip_graph": bool(args.graph)},
             "roofline": roof, "cpu_baseline": cpu,
         }

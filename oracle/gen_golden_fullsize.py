@@ -1,0 +1,96 @@
+"""Generate tests/golden/full_*.pt: the REAL reference (/root/reference) run on torch CPU at the BASELINE.json shapes.
+
+    python oracle/gen_golden_fullsize.py [cfg2 cfg3 cfg4 cfg5]      (build container only; ~5 min, peak RSS ~13 GB)
+
+One training step per config (dropout neutralised, BN batch statistics, weights from oracle.weights.synth_state_dict,
+inputs from oracle.weights.synth_batch) with exactly the loss expression of the reference's hot loop
+(trainer.py:56-66: CE + 0.4*CE(aux) for PSP*, the configured loss otherwise).  Full-resolution logits are too large to commit
+(cfg2: 176 MB), so each fixture keeps what the north-star acceptance sentence needs:
+
+  mask     uint8  [N,H,W]   argmax of the main head            -> mismatch COUNT of the HIP path's masks, bit for bit
+  margin   fp16   [N,H,W]   top-1 minus top-2 logit            -> "0 mismatches among pixels whose margin > 2*max|dlogit|"
+  logits   fp32   [N,C,H/s,W/s]  main head at pixel stride s   -> max|dlogit| (and aux head at stride 2s for PSP)
+  loss, per-tensor gradient digests (norm / absmax / 64 samples), a few running statistics.
+
+cfg2 = PSPNet-R50 8x3x512x512 21 classes (the bench line); cfg3 = DeepLabV3+ R101 OS16 513x513 19 classes at batch 2 (of 16);
+cfg4 = one SyncBN shard's shape, PSPNet-R50 4x3x769x769 19 classes (97x97 maps), local BN; cfg5 = DeepLabV3+ Xception 512x512
+150 classes + LovaszSoftmax at batch 2 (of 8), ignore_index -1.
+"""
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import reference_harness  # noqa: E402
+from oracle.gen_golden import _grad_digest  # noqa: E402
+from oracle.weights import manifest_of, synth_batch, synth_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name: (arch, kwargs, classes, N, H, W, loss, ignore_index, logits stride, weight seed, batch seed, running-stat keys)
+FULL = {
+    "cfg2": ("PSPNet", dict(backbone="resnet50"), 21, 8, 512, 512, "CrossEntropyLoss2d", 255, 8, 0, 1234,
+             ("initial.0.1.running_mean", "layer4.2.bn3.running_var", "master_branch.0.bottleneck.1.running_mean")),
+    "cfg3": ("DeepLab", dict(backbone="resnet101", output_stride=16), 19, 2, 513, 513, "CrossEntropyLoss2d", 255, 8, 2, 555,
+             ("backbone.layer4.2.bn3.running_var", "decoder.bn1.running_mean")),
+    "cfg4": ("PSPNet", dict(backbone="resnet50"), 19, 4, 769, 769, "CrossEntropyLoss2d", 255, 12, 0, 4321,
+             ("initial.0.1.running_mean", "layer4.2.bn3.running_var", "master_branch.0.bottleneck.1.running_mean")),
+    "cfg5": ("DeepLab", dict(backbone="xception", output_stride=16), 150, 2, 512, 512, "LovaszSoftmax", -1, 16, 2, 777,
+             ("ASSP.aspp4.1.running_var", "decoder.bn1.running_mean")),
+}
+
+
+def gen(name, models, losses):
+    arch, kw, C, N, H, W, loss_name, ign, stride, wseed, bseed, run_keys = FULL[name]
+    torch.manual_seed(0)
+    model = getattr(models, arch)(C, pretrained=False, **kw)
+    if kw.get("backbone") == "xception":
+        model.backbone.block2.relu.inplace = False          # numerically neutral autograd workaround
+    man = manifest_of(model.state_dict())
+    model.load_state_dict(synth_state_dict(man, seed=wseed))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.eval()
+    crit = getattr(losses, loss_name)(ignore_index=ign)
+    x, t = synth_batch(N, 3, H, W, C, ignore_index=ign, seed=bseed)
+    t0 = time.time()
+    out = model(x)
+    aux = None
+    if arch[:3] == "PSP":                       # trainer.py:57-62
+        out, aux = out
+        loss = crit(out, t) + 0.4 * crit(aux, t)
+    else:
+        loss = crit(out, t)
+    t1 = time.time()
+    loss.backward()
+    t2 = time.time()
+    o = out.detach()
+    top2 = o.topk(2, dim=1).values
+    sd_after = model.state_dict()
+    rec = {"name": name, "arch": arch, "kwargs": kw, "num_classes": C, "input_shape": (N, 3, H, W), "loss_name": loss_name,
+           "ignore_index": ign, "weight_seed": wseed, "batch_seed": bseed, "stride": stride, "manifest": man,
+           "mask": o.argmax(1).to(torch.uint8), "margin": (top2[:, 0] - top2[:, 1]).to(torch.float16),
+           "logits": o[:, :, ::stride, ::stride].clone(), "logit_absmax": o.abs().max().item(),
+           "loss": loss.detach().clone(), "grads": _grad_digest(model.named_parameters()),
+           "running": {k: sd_after[k].clone() for k in run_keys},
+           "cpu_seconds": {"forward_loss": t1 - t0, "backward": t2 - t1, "threads": torch.get_num_threads()}}
+    if aux is not None:
+        rec["aux"] = aux.detach()[:, :, ::2 * stride, ::2 * stride].clone()
+    path = os.path.join(GOLD, "full_%s.pt" % name)
+    torch.save(rec, path)
+    print("%s: loss %.6f |logit| max %.3f, margin<1e-4 on %d px, fwd %.1fs bwd %.1fs -> %s (%.1f MB)"
+          % (name, loss.item(), rec["logit_absmax"], int((rec["margin"].float() < 1e-4).sum()), t1 - t0, t2 - t1, path,
+             os.path.getsize(path) / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    models, losses = reference_harness.load()
+    for name in (sys.argv[1:] or list(FULL)):
+        gen(name, models, losses)
