@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
                                                          "one host call per step instead of ~800 launches")
-    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3", "bf16x3_simple", "bf16x3_pk", "bf16x2"],
+    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
                     help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
                          "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
     args = ap.parse_args()
@@ -172,7 +172,7 @@ def main():
 
     from segmi import ops as segmi_ops
     segmi_ops.set_conv_math(args.conv_math)
-    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16x2": round(2516.6 / 3, 1)}.get(args.conv_math, PEAK_BF16X3_EQUIV_TFLOPS)
+    peak = PEAK_FP32_MFMA_TFLOPS if args.conv_math == "f32" else PEAK_BF16X3_EQUIV_TFLOPS
 
     arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)
@@ -282,8 +282,6 @@ def main():
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.conv_math == "f32" else
-                      "REDUCED: conv operands cut to 16 significand bits (bf16x2 split), fp32 storage/accumulate — not comparable with the fp32 line"
-                      if args.conv_math == "bf16x2" else
                       "f32 (HBM/LDS/accumulate fp32; conv products as bf16x3 split on the bf16 matrix pipe)"),
             "data": "synthetic",
             "config": {"workload": "%s: %s%s %dx3x%dx%d per GPU, %d classes, %s%s, SGD(momentum 0.9, wd 1e-4), "

@@ -89,14 +89,7 @@ int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, 
  * reference computes in fp32, trainer.py:56); this is the drop-in's throughput knob. */
 enum segmi_conv_math {
     SEGMI_CONV_MATH_F32 = 0,
-    SEGMI_CONV_MATH_BF16X3 = 1,
-    /* the same bf16x3 arithmetic with a different loop structure, kept for A/B measurements (SEGMI_CONV_MATH=bf16x3_simple /
-     * bf16x3_pk): per-chunk loop scheduled by the compiler; pipelined loop with packed residual subtractions */
-    SEGMI_CONV_MATH_BF16X3_SIMPLE = 2,
-    SEGMI_CONV_MATH_BF16X3_PK = 3,
-    /* REDUCED precision, never the parity path: two bf16 planes per operand, three products (16 significand bits per
-     * operand, per-product error <= 2^-15, ~2^-18 typical — between TF32 and fp32); half the work of bf16x3 (SEGMI_CONV_MATH=bf16x2) */
-    SEGMI_CONV_MATH_BF16X2 = 4
+    SEGMI_CONV_MATH_BF16X3 = 1
 };
 int segmi_conv_set_math(int math);
 int segmi_conv_get_math(void);
@@ -143,7 +136,7 @@ int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, voi
 int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
                       float momentum, int clamp_mode, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
-                      segmi_stream_t stream);
+                      float* count_out, segmi_stream_t stream);
 /* Single-device batch statistics in one call: segmi_bn_stats followed by segmi_bn_finalize(nparts = 1) with the merge
  * and the finalize fused into one launch (bit-identical to the two-call sequence; workspace as segmi_bn_stats). */
 int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* gamma, const float* beta, float eps,
@@ -166,11 +159,13 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
                         float* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* dgamma = sums[C:2C], dbeta = sums[0:C];
  * training: dx = scale*(dy' - sums0/count - xhat*sums1/count); eval (frozen): dx = scale*dy'.
- * d_residual (optional) = dy'.  `count` is the (global) element count per channel. */
+ * d_residual (optional) = dy'.  `count` is the (global) element count per channel; when count_dev != NULL it is read
+ * from device memory instead (SyncBN: the count segmi_bn_finalize summed from the all-gathered partials — no host-side
+ * exchange, valid for ragged shards). */
 int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                        const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
-                       float count, int relu, int training, float* dx, int lddx, float* dres, int lddres,
-                       segmi_stream_t stream);
+                       float count, const float* count_dev, int relu, int training, float* dx, int lddx, float* dres,
+                       int lddres, segmi_stream_t stream);
 /* standalone ReLU (models/deeplabv3_plus.py:99-101,210) */
 int segmi_relu_fwd(const float* x, int ldx, float* y, int ldy, long rows, int C, segmi_stream_t stream);
 int segmi_relu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, long rows, int C,
@@ -218,15 +213,20 @@ int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, in
                   uint64_t seed, const uint64_t* seed_epoch_dev, segmi_stream_t stream);
 
 /* ------------------------------------------------------------------ per-pixel losses (K10/K11/K12) */
-/* CrossEntropyLoss2d (utils/losses.py:24-31): mean over target != ignore_index of -log_softmax.
- * fwd writes lse[rows] and loss_out = {loss, n_valid}; bwd recomputes softmax from (logits, lse):
- * dlogits = (softmax - onehot) * (*grad_out) / n_valid, 0 at ignored pixels. */
+/* CrossEntropyLoss2d (utils/losses.py:24-31): nn.CrossEntropyLoss(weight, ignore_index, reduction='mean'):
+ * sum_i w[t_i] * (-log_softmax_i[t_i]) / sum_i w[t_i] over pixels with target != ignore_index; class_weight (C floats,
+ * device) may be NULL (w = 1: the plain mean over valid pixels).
+ * fwd writes lse[rows] and loss_out[3] = {loss, denominator = sum of w (= n_valid without weights), numerator};
+ * bwd recomputes softmax from (logits, lse): dlogits = w[t] * (softmax - onehot) * (*grad_out) / loss_out[1], 0 at ignored
+ * pixels.  A caller that wants another normalisation (reduction='sum'; the global-batch mean of a data-parallel job, where
+ * the denominators of all ranks are all-reduced first) hands bwd its own loss_out[1]. */
 size_t segmi_ce_workspace(long rows);
-int segmi_ce_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
-                 float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
-int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
-                 long ignore_index, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
+int segmi_ce_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index,
+                 const float* class_weight, float* lse, float* loss_out, void* workspace, size_t workspace_bytes,
                  segmi_stream_t stream);
+int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
+                 long ignore_index, const float* class_weight, const float* loss_out, const float* grad_out, float* dlogits,
+                 int lddl, segmi_stream_t stream);
 
 /* DiceLoss (utils/losses.py:33-50): softmax, one-hot, whole-batch 1 - (2*sum(p*y)+s)/(sum(p)+sum(y)+s).
  * Reproduces the reference's in-place rewrite of ignored pixels to target.min() (target is mutated when
@@ -238,13 +238,26 @@ int segmi_dice_fwd(const float* logits, int ld, int64_t* target, long rows, int 
                    segmi_stream_t stream);
 int segmi_dice_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
                    const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream);
-/* FocalLoss (utils/losses.py:52-65, alpha=None): mean over ALL pixels of (1-exp(-ce))^gamma * ce with
- * ce = 0 at ignored pixels.  Workspace: segmi_ce_workspace(rows).  loss_out[2] = {loss, rows}. */
+/* The three stages of segmi_dice_fwd as separate calls, for data-parallel training: the reference evaluates DiceLoss on the
+ * GATHERED global batch (trainer.py:56-66 under nn.DataParallel), so target.min()/max()/ignored-count and the three sums are
+ * whole-job quantities.  A rank runs segmi_target_stats, all-reduces {min, max, count} (and re-derives stats[3]), runs
+ * segmi_dice_sums with those global stats (performs the in-place target rewrite, writes lse and this rank's
+ * sums[3] = {sum p*y, sum p, sum y} as doubles), all-reduces sums, and calls segmi_dice_finalize.  Workspaces as
+ * segmi_dice_workspace(rows). */
+int segmi_target_stats(const int64_t* target, long rows, long ignore_index, int64_t* stats, void* workspace,
+                       size_t workspace_bytes, segmi_stream_t stream);
+int segmi_dice_sums(const float* logits, int ld, int64_t* target, long rows, int C, long ignore_index, const int64_t* stats,
+                    float* lse, double* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_dice_finalize(const double* sums, float smooth, float* loss_out, segmi_stream_t stream);
+/* FocalLoss (utils/losses.py:52-65): mean over ALL pixels of (1-exp(-ce))^gamma * ce with ce = alpha[t] * (-log p_t)
+ * (alpha: C class weights of the inner nn.CrossEntropyLoss(reduce=False, weight=alpha), NULL = 1) and ce = 0 at ignored
+ * pixels.  Workspace: segmi_ce_workspace(rows).  loss_out[3] = {loss, rows, sum}; bwd divides by loss_out[1]. */
 int segmi_focal_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float gamma,
-                    float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
-int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
-                    long ignore_index, float gamma, const float* grad_out, float* dlogits, int lddl,
+                    const float* alpha, float* lse, float* loss_out, void* workspace, size_t workspace_bytes,
                     segmi_stream_t stream);
+int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
+                    long ignore_index, float gamma, const float* alpha, const float* loss_out, const float* grad_out,
+                    float* dlogits, int lddl, segmi_stream_t stream);
 
 /* LovaszSoftmax (utils/losses.py:79-89 -> utils/lovasz_losses.py:153-218, lovasz_grad :19-31), classes='present',
  * per_image=False: softmax; ignored pixels dropped; per present class sort |fg - p_c| descending, Jaccard-gradient dot;

@@ -160,9 +160,14 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int Cp, const float* gamma,
                                    const float* beta, float eps, float momentum, int clamp_mode, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
-                                   float* scale, float* shift) {
+                                   float* scale, float* shift, float* count_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c == 0 && count_out) {       // elements per channel over all partials (the global batch of a SyncBN layer)
+        float tot = 0.f;
+        for (int i = 0; i < nparts; ++i) tot += part[(long)i * 3 * Cp];
+        *count_out = tot;
+    }
     if (c >= C) return;
     float n = 0.f, m = 0.f, q = 0.f;
     for (int i = 0; i < nparts; ++i) {
@@ -306,10 +311,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ sums,
-                                                           float inv_count, float* __restrict__ dx, int lddx,
+                                                           float inv_count, const float* __restrict__ count_dev,
+                                                           float* __restrict__ dx, int lddx,
                                                            float* __restrict__ dres, int lddres) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= c4n) return;
+    if (TRAIN && count_dev) inv_count = 1.f / count_dev[0];
     const int Cp = c4n * 4;
     const float4 sc = ld4(scale + c4 * 4);
     float4 sh = zero4();
@@ -430,11 +437,12 @@ int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const floa
 int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
                       float momentum, int clamp_mode, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
-                      segmi_stream_t stream) {
+                      float* count_out, segmi_stream_t stream) {
     if (!partials || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return SEGMI_ERR_BADARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SEGMI_ERR_BADARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, C,
-                       gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift);
+                       gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift,
+                       count_out);
     return segmi_launch_status();
 }
 
@@ -494,18 +502,18 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
 
 int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                        const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
-                       float count, int relu, int training, float* dx, int lddx, float* dres, int lddres,
-                       segmi_stream_t stream) {
+                       float count, const float* count_dev, int relu, int training, float* dx, int lddx, float* dres,
+                       int lddres, segmi_stream_t stream) {
     if (!dy || !scale || !dx || rows <= 0 || C <= 0 || (relu && !y && (!x || !shift))) return SEGMI_ERR_BADARG;
-    if (training && (!x || !mean || !invstd || !sums || count <= 0.f)) return SEGMI_ERR_BADARG;
+    if (training && (!x || !mean || !invstd || !sums || (!count_dev && count <= 0.f))) return SEGMI_ERR_BADARG;
     const bool need_x = training || (relu && !y);
     if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(lddx, C) || (need_x && !ld_ok(ldx, C)) || (relu && y && !ld_ok(ldy, C)) ||
         (dres && !ld_ok(lddres, C)))
         return SEGMI_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
-    const float inv = training ? 1.f / count : 0.f;
-#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, sums, inv, dx, lddx, dres, lddres)
+    const float inv = (training && !count_dev) ? 1.f / count : 0.f;
+#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, sums, inv, count_dev, dx, lddx, dres, lddres)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH_BA(false, false, false); break;

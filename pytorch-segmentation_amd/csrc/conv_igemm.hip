@@ -274,15 +274,10 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// MATH_BF16X3 is the scheme as described; the other two are the same arithmetic kept for A/B measurements of the loop structure:
-// _SIMPLE = per-chunk loop left to the compiler's scheduler (no cross-chunk pipeline, fewer registers), _PK = pipelined loop
-// with the SLP fence off (residual pairs as v_pk_add_f32).
-enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3, MATH_BF16X3_SIMPLE = SEGMI_CONV_MATH_BF16X3_SIMPLE,
-       MATH_BF16X3_PK = SEGMI_CONV_MATH_BF16X3_PK,
-       // REDUCED precision (not fp32-equivalent, never the parity or headline path): two planes (h, m) per operand, three
-       // products (m*h', h*m', h*h'): 16 significand bits per operand, per-product error <= 2^-15 (typically 2^-18); half the split work and
-       // half the matrix instructions of bf16x3.  Network-scale effect measured on the CPU model: DESIGN §4.1b.
-       MATH_BF16X2 = SEGMI_CONV_MATH_BF16X2 };
+// The loop is software-pipelined over 16-wide k steps across chunk boundaries; two other loop structures (compiler-scheduled
+// per-chunk loop, packed residual subtractions) and a two-plane reduced-precision variant were measured on hardware in round 2
+// (profiles/r02_bf16x3_*) and removed: this one was the fastest (197 vs 182/186 TF/s on the PSP bottleneck).
+enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3 };
 
 struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
 
@@ -294,28 +289,22 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 // v_pk_add_f32, which on gfx950 is no faster than two fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the
 // costliest filler beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  The empty asm is
 // an optimisation fence on ONE value of the pair (emits nothing; the subtractions stay ordinary, schedulable VALU).
-// PK = true (MATH_BF16X3_PK) leaves the choice to the compiler, for A/B runs.
-template <bool PK>
-__device__ __forceinline__ void slp_fence(float& v) {
-    if (!PK) asm("" : "+v"(v));
-}
-template <bool PK>
+__device__ __forceinline__ void slp_fence(float& v) { asm("" : "+v"(v)); }
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     h = cvt_pk_bf16(x0, x1);
     const float r0 = x0 - __builtin_bit_cast(float, h << 16);
     float r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
-    slp_fence<PK>(r1);
+    slp_fence(r1);
     m = cvt_pk_bf16(r0, r1);
     const float s0 = r0 - __builtin_bit_cast(float, m << 16);
     float s1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
-    slp_fence<PK>(s1);
+    slp_fence(s1);
     l = cvt_pk_bf16(s0, s1);
 }
-template <bool PK = false>
 __device__ __forceinline__ Planes split8(const float (&x)[8]) {
     unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair<PK>(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
     Planes p;
     p.h = u32x4_t{h[0], h[1], h[2], h[3]};
     p.m = u32x4_t{m[0], m[1], m[2], m[3]};
@@ -327,34 +316,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const u32x4_t& b, 
 }
 // acc[i][j] += A_i (x) B_j over 16 k-values, six plane products, smallest terms first; the (i, j) loop is innermost so
 // that consecutive matrix instructions target different accumulators
-template <int TM, int TN, int NP = 3>
+template <int TM, int TN>
 __device__ __forceinline__ void mma_bf16x3(f32x16 (&acc)[TM][TN], const Planes (&a)[TM], const Planes (&b)[TN]) {
-    if (NP == 3) {      // NP == 2 (MATH_BF16X2): the l planes and the m*m' product are not used (and their computation is dead code)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].l, b[j].h, acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].l, acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].m, acc[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].m, b[j].h, acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].m, acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].h, b[j].h, acc[i][j]);
+#define SEGMI_PLANE_PRODUCT(PA, PB)                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].PA, b[j].PB, acc[i][j]);
+    SEGMI_PLANE_PRODUCT(l, h)
+    SEGMI_PLANE_PRODUCT(h, l)
+    SEGMI_PLANE_PRODUCT(m, m)
+    SEGMI_PLANE_PRODUCT(m, h)
+    SEGMI_PLANE_PRODUCT(h, m)
+    SEGMI_PLANE_PRODUCT(h, h)
+#undef SEGMI_PLANE_PRODUCT
 }
 
 // FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
@@ -528,40 +501,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
-    constexpr bool PK = MATH == MATH_BF16X3_PK;
-    constexpr int NP = MATH == MATH_BF16X2 ? 2 : 3;      // bf16 planes per operand
-    if (MATH == MATH_BF16X3_SIMPLE) {
-        // same fragments and products, one chunk at a time, instruction order left to the compiler (A/B baseline of the pipeline)
-        for (int it = it0; it < T; ++it) {
-            if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
-            const float* Ab = smem + buf * STAGE;
-            const float* Bb = Ab + BM * BK;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                const int g0 = ks * 4 + lhalf * 2;
-                const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
-                Planes qa[TM], qb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
-                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-                    qa[i] = split8<PK>(x);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
-                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-                    qb[j] = split8<PK>(x);
-                }
-                mma_bf16x3<TM, TN, NP>(acc, qa, qb);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            buf ^= 1;
-        }
-    } else if (MATH != MATH_F32) {
+    if (MATH != MATH_F32) {
         // A lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two swizzled
         // 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair).
         // Software pipeline over 16-wide k steps, ACROSS chunk boundaries (matrix instructions only need registers, so the
@@ -571,8 +511,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         // Each phase pairs 6*TM*TN matrix instructions (32 cycles each) with the ~44 VALU per tile row-block of one split
         // (sched_group_barrier: 1 MFMA + its share of VALU per group), so neither pipe waits for the other inside a wave;
         // only the very first split of a tile is exposed, and the last step drains after the loop.
-        constexpr int NMMA = TM * TN * (NP == 3 ? 6 : 3);
-        constexpr int VPG = ((TM + TN) * (NP == 3 ? 44 : 24) + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub (44), or 8 + 8 + 8
+        constexpr int NMMA = TM * TN * 6;
+        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub = 44
         float ra[2][TM][8], rb[2][TN][8];
         Planes pa[2][TM], pb[2][TN];
         auto fetch = [&](const float* Ab, const float* Bb, int ks) {
@@ -596,10 +536,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         auto phase_b = [&]() {                                 // MFMAs of step 0 || split of step 1, then hand over the stage
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
-            mma_bf16x3<TM, TN, NP>(acc, pa[0], pb[0]);
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -617,9 +557,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             fetch(Ab, Bb, 0);
             fetch(Ab, Bb, 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
             phase_b();
         }
         for (int it = it0 + 1; it < T; ++it) {
@@ -631,10 +571,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             // phase A: MFMAs of the pending step || split of step 0
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
-            mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -642,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             }
             phase_b();
         }
-        if (it0 < T) mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
+        if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
     } else
     for (int it = it0; it < T; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
@@ -1006,51 +946,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    constexpr bool PK = MATH == MATH_BF16X3_PK;
-    constexpr int NP = MATH == MATH_BF16X2 ? 2 : 3;      // bf16 planes per operand
-    if (MATH == MATH_BF16X3_SIMPLE) {
-        if (mbeg < mend) {
-            issue(mbeg, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int buf = 0;
-            for (int mb = mbeg; mb < mend; mb += BKP) {
-                if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
-                const float* Ab = smem + buf * STAGE;
-                const float* Bb = Ab + BKP * BM;
-                float ra[BKP / 16][TM][8], rb[BKP / 16][TN][8];
-#pragma unroll
-                for (int ks = 0; ks < BKP / 16; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
-                }
-#pragma unroll
-                for (int ks = 0; ks < BKP / 16; ++ks) {
-                    Planes qa[TM], qb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) qa[i] = split8<PK>(ra[ks][i]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) qb[j] = split8<PK>(rb[ks][j]);
-                    mma_bf16x3<TM, TN, NP>(acc, qa, qb);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-    } else if (MATH != MATH_F32) {
+    if (MATH != MATH_F32) {
         // Same software pipeline as conv_dma_kernel (phase A: pending step's MFMAs || split of step 0; phase B: step 0's
         // MFMAs || split of step 1; the second step of a chunk issues after the barrier).  The reduction axis (pixels) is the
         // LDS row index here: a lane gathers its channel's 8 pixels (ks*16 + lhalf*8 + e) with ds_read_b32 (lanes of a
         // half-wave read consecutive channels of one pixel: conflict-free as in the fp32 path).
-        constexpr int NMMA = TM * TN * (NP == 3 ? 6 : 3);
-        constexpr int VPG = ((TM + TN) * (NP == 3 ? 44 : 24) + NMMA - 1) / NMMA;
+        constexpr int NMMA = TM * TN * 6;
+        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;
         float ra[2][TM][8], rb[2][TN][8];
         Planes pa[2][TM], pb[2][TN];
         int buf = 0;
@@ -1067,10 +969,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         auto phase_b = [&]() {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8<PK>(ra[1][i]);
+            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8<PK>(rb[1][j]);
-            mma_bf16x3<TM, TN, NP>(acc, pa[0], pb[0]);
+            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1089,9 +991,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             fetch(smem, smem + BKP * BM, 0);
             fetch(smem, smem + BKP * BM, 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);        // first chunk: exposed split
+            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);        // first chunk: exposed split
 #pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
+            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
             phase_b();
             for (int mb = mbeg + BKP; mb < mend; mb += BKP) {
                 if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
@@ -1101,10 +1003,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 fetch(Ab, Bb, 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) pa[0][i] = split8<PK>(ra[0][i]);
+                for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) pb[0][j] = split8<PK>(rb[0][j]);
-                mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);
+                for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+                mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
 #pragma unroll
                 for (int q = 0; q < NMMA; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1112,7 +1014,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
                 }
                 phase_b();
             }
-            mma_bf16x3<TM, TN, NP>(acc, pa[1], pb[1]);                            // drain
+            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);                            // drain
         }
     } else
     if (mbeg < mend) {
@@ -1270,9 +1172,6 @@ int conv_math() {
         const char* e = getenv("SEGMI_CONV_MATH");
         g_math = MATH_F32;
         if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_math = MATH_BF16X3;
-        else if (e && !strcmp(e, "bf16x3_simple")) g_math = MATH_BF16X3_SIMPLE;
-        else if (e && !strcmp(e, "bf16x3_pk")) g_math = MATH_BF16X3_PK;
-        else if (e && !strcmp(e, "bf16x2")) g_math = MATH_BF16X2;
     }
     return g_math;
 }
@@ -1293,13 +1192,7 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
         case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_DMA(true, MATH_F32); break;
         case MATH_F32 * 2:               SEGMI_LAUNCH_DMA(false, MATH_F32); break;
         case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_DMA(true, MATH_BF16X3); break;
-        case MATH_BF16X3 * 2:            SEGMI_LAUNCH_DMA(false, MATH_BF16X3); break;
-        case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_DMA(true, MATH_BF16X3_SIMPLE); break;
-        case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_DMA(false, MATH_BF16X3_SIMPLE); break;
-        case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_DMA(true, MATH_BF16X3_PK); break;
-        case MATH_BF16X3_PK * 2:         SEGMI_LAUNCH_DMA(false, MATH_BF16X3_PK); break;
-        case MATH_BF16X2 * 2 + 1:        SEGMI_LAUNCH_DMA(true, MATH_BF16X2); break;
-        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X2); break;
+        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X3); break;
     }
 #undef SEGMI_LAUNCH_DMA
     if (p.ksplit > 1) {
@@ -1453,13 +1346,7 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
             case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_WGRAD(true, MATH_F32); break;
             case MATH_F32 * 2:               SEGMI_LAUNCH_WGRAD(false, MATH_F32); break;
             case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3); break;
-            case MATH_BF16X3 * 2:            SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3); break;
-            case MATH_BF16X3_SIMPLE * 2 + 1: SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_SIMPLE); break;
-            case MATH_BF16X3_SIMPLE * 2:     SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_SIMPLE); break;
-            case MATH_BF16X3_PK * 2 + 1:     SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3_PK); break;
-            case MATH_BF16X3_PK * 2:         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3_PK); break;
-            case MATH_BF16X2 * 2 + 1:        SEGMI_LAUNCH_WGRAD(true, MATH_BF16X2); break;
-            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X2); break;
+            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3); break;
         }
 #undef SEGMI_LAUNCH_WGRAD
     }
@@ -1610,7 +1497,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
 }
 
 int segmi_conv_set_math(int math) {
-    if (math < SEGMI_CONV_MATH_F32 || math > SEGMI_CONV_MATH_BF16X2) return SEGMI_ERR_BADARG;
+    if (math != SEGMI_CONV_MATH_F32 && math != SEGMI_CONV_MATH_BF16X3) return SEGMI_ERR_BADARG;
     g_math = math;
     return SEGMI_OK;
 }

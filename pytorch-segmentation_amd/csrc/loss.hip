@@ -48,10 +48,11 @@ __device__ __forceinline__ float pixel_lse(const float* row, int C, int g, long 
     return m + logf(s);
 }
 
-// part[block] = {sum of -log p_t over valid pixels, number of valid pixels}
+// part[block] = {sum of -w_t log p_t over valid pixels, sum of w_t over valid pixels}   (w = 1 without class weights:
+// the pixel count).  nn.CrossEntropyLoss(weight=w, reduction='mean') = the quotient of the two (utils/losses.py:24-28).
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
-                                                     long rows, int C, long ignore, float* __restrict__ lse_out,
-                                                     double* __restrict__ part) {
+                                                     long rows, int C, long ignore, const float* __restrict__ cw,
+                                                     float* __restrict__ lse_out, double* __restrict__ part) {
     const int g = threadIdx.x & (LPP - 1);
     const long ppb = 256 / LPP;
     float lsum = 0.f, lcnt = 0.f;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         const float lse = pixel_lse(logits + r * ld, C, g, valid ? t : -1, xt);
         if (g == 0) {
             lse_out[r] = lse;
-            if (valid) { lsum += lse - xt; lcnt += 1.f; }
+            if (valid) { const float w = cw ? cw[t] : 1.f; lsum += w * (lse - xt); lcnt += w; }
         }
     }
     lsum = wave_sum(lsum); lcnt = wave_sum(lcnt);
@@ -76,22 +77,24 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
 }
 
+// out = {mean = s / c, c, s}: reduction 'mean' reads out[0]; 'sum' and the data-parallel global-batch mean (the caller
+// all-reduces c and rescales, segmi/distributed.py) start from the raw sum out[2]
 __global__ void ce_finalize_kernel(const double* __restrict__ part, int nparts, float* __restrict__ out) {
     // single wave; nparts <= SEGMI_MAX_GRID
     double s = 0.0, c = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 64) { s += part[2 * i]; c += part[2 * i + 1]; }
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
-    if (threadIdx.x == 0) { out[0] = (float)(s / c); out[1] = (float)c; }
+    if (threadIdx.x == 0) { out[0] = (float)(s / c); out[1] = (float)c; out[2] = (float)s; }
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                      const float* __restrict__ lse, long rows, int C, long ignore,
-                                                     const float* __restrict__ loss_out, const float* __restrict__ grad_out,
-                                                     float* __restrict__ dl, int lddl) {
+                                                     const float* __restrict__ cw, const float* __restrict__ loss_out,
+                                                     const float* __restrict__ grad_out, float* __restrict__ dl, int lddl) {
     const int g = threadIdx.x & (LPP - 1);
     const long ppb = 256 / LPP;
     const int c4n = (C + 3) >> 2;
-    const float gs = grad_out[0] / loss_out[1];
+    const float gs0 = grad_out[0] / loss_out[1];
     for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
         const long t = target[r];
         const bool valid = t != ignore && t >= 0 && t < C;
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
         for (int q = g; q < c4n; q += LPP) {
             float4 d = zero4();
             if (valid) {
+                const float gs = cw ? gs0 * cw[t] : gs0;
                 const float4 v = ld4(row + q * 4);
                 const int c = q * 4;
                 d.x = (expf(v.x - l) - (t == c ? 1.f : 0.f)) * gs;
@@ -203,6 +207,13 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
         part[3 * blockIdx.x + 2] = (double)sm[8] + sm[9] + sm[10] + sm[11];
     }
 }
+// sums[3] = {sum p_t, sum_c p_c, sum onehot} of this rank (the data-parallel path all-reduces them before dice_finalize)
+__global__ void dice_sum_kernel(const double* __restrict__ part, int nparts, double* __restrict__ sums) {
+    double i = 0.0, p = 0.0, t = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 64) { i += part[3 * k]; p += part[3 * k + 1]; t += part[3 * k + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { i += __shfl_xor(i, o, 64); p += __shfl_xor(p, o, 64); t += __shfl_xor(t, o, 64); }
+    if (threadIdx.x == 0) { sums[0] = i; sums[1] = p; sums[2] = t; }
+}
 __global__ void dice_finalize_kernel(const double* __restrict__ part, int nparts, float smooth, float* __restrict__ out) {
     double i = 0.0, p = 0.0, t = 0.0;
     for (int k = threadIdx.x; k < nparts; k += 64) { i += part[3 * k]; p += part[3 * k + 1]; t += part[3 * k + 2]; }
@@ -245,9 +256,10 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // FocalLoss  utils/losses.py:52-65 (alpha=None): ce = per-pixel cross entropy (0 at ignored pixels),
 // loss = mean over ALL pixels of (1 - exp(-ce))^gamma * ce.
+// alpha (class weights of the inner nn.CrossEntropyLoss(reduce=False, weight=alpha)): ce = alpha_t * (-log p_t).
 __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
-                                                        long rows, int C, long ignore, float gamma, float* __restrict__ lse_out,
-                                                        double* __restrict__ part) {
+                                                        long rows, int C, long ignore, float gamma, const float* __restrict__ cw,
+                                                        float* __restrict__ lse_out, double* __restrict__ part) {
     const int g = threadIdx.x & (LPP - 1);
     const long ppb = 256 / LPP;
     float lsum = 0.f;
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
         if (g == 0) {
             lse_out[r] = lse;
             if (valid) {
-                const float ce = lse - xt;
+                const float ce = (cw ? cw[t] : 1.f) * (lse - xt);
                 lsum += powf(1.f - expf(-ce), gamma) * ce;
             }
         }
@@ -275,16 +287,17 @@ __global__ void focal_finalize_kernel(const double* __restrict__ part, int npart
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 64) s += part[2 * i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) { out[0] = (float)(s / rows); out[1] = (float)rows; }
+    if (threadIdx.x == 0) { out[0] = (float)(s / rows); out[1] = (float)rows; out[2] = (float)s; }
 }
-// d loss / d z_c = g/rows * [ gamma (1-pt)^(gamma-1) pt ce + (1-pt)^gamma ] * (p_c - delta_ct)
+// d loss / d z_c = g/denom * [ gamma (1-pt)^(gamma-1) pt ce + (1-pt)^gamma ] * alpha_t * (p_c - delta_ct),  pt = exp(-ce)
 __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                         const float* __restrict__ lse, long rows, int C, long ignore, float gamma,
+                                                        const float* __restrict__ cw, const float* __restrict__ loss_out,
                                                         const float* __restrict__ grad_out, float* __restrict__ dl, int lddl) {
     const int g = threadIdx.x & (LPP - 1);
     const long ppb = 256 / LPP;
     const int c4n = (C + 3) >> 2;
-    const float gs = grad_out[0] / (float)rows;
+    const float gs = grad_out[0] / loss_out[1];
     for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
         const long t = target[r];
         const bool valid = t != ignore && t >= 0 && t < C;
@@ -292,10 +305,11 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
         const float* row = logits + r * ld;
         float k = 0.f;
         if (valid) {
-            const float ce = l - row[t];
+            const float a = cw ? cw[t] : 1.f;
+            const float ce = a * (l - row[t]);
             const float pt = expf(-ce), om = 1.f - pt;
             const float dce = (gamma == 0.f ? 0.f : gamma * powf(om, gamma - 1.f) * pt * ce) + powf(om, gamma);
-            k = gs * dce;
+            k = gs * dce * a;
         }
         for (int q = g; q < c4n; q += LPP) {
             float4 d = zero4();
@@ -373,30 +387,63 @@ extern "C" {
 
 size_t segmi_ce_workspace(long rows) { return (size_t)ce_blocks(rows) * 2 * sizeof(double); }
 
-int segmi_ce_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
-                 float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+int segmi_ce_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index,
+                 const float* class_weight, float* lse, float* loss_out, void* workspace, size_t workspace_bytes,
+                 segmi_stream_t stream) {
     if (!logits || !target || !lse || !loss_out || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_ce_workspace(rows)) return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nb = ce_blocks(rows);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, lse, (double*)workspace);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, class_weight, lse,
+                       (double*)workspace);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, loss_out);
     return segmi_launch_status();
 }
 
 int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C,
-                 long ignore_index, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
-                 segmi_stream_t stream) {
+                 long ignore_index, const float* class_weight, const float* loss_out, const float* grad_out, float* dlogits,
+                 int lddl, segmi_stream_t stream) {
     if (!logits || !target || !lse || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
-                       ignore_index, loss_out, grad_out, dlogits, lddl);
+                       ignore_index, class_weight, loss_out, grad_out, dlogits, lddl);
     return segmi_launch_status();
 }
 
 /* workspace: 3 doubles per block (dice partials) + 3 int64 per block (target statistics) */
 size_t segmi_dice_workspace(long rows) { return (size_t)ce_blocks(rows) * 3 * (sizeof(double) + sizeof(long long)); }
+
+int segmi_target_stats(const int64_t* target, long rows, long ignore_index, int64_t* stats, void* workspace, size_t workspace_bytes,
+                       segmi_stream_t stream) {
+    if (!target || !stats || rows <= 0) return SEGMI_ERR_BADARG;
+    if (!workspace || workspace_bytes < segmi_dice_workspace(rows)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_blocks(rows);
+    long long* ipart = (long long*)((double*)workspace + 3 * (size_t)nb);
+    hipLaunchKernelGGL(target_stats_partial_kernel, dim3(nb), dim3(256), 0, st, target, rows, ignore_index, ipart);
+    hipLaunchKernelGGL(target_stats_final_kernel, dim3(1), dim3(64), 0, st, (const long long*)ipart, nb, ignore_index, stats);
+    return segmi_launch_status();
+}
+
+int segmi_dice_sums(const float* logits, int ld, int64_t* target, long rows, int C, long ignore_index, const int64_t* stats,
+                    float* lse, double* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits || !target || !stats || !lse || !sums || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_dice_workspace(rows)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_blocks(rows);
+    double* dpart = (double*)workspace;
+    hipLaunchKernelGGL(dice_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, stats, lse, dpart);
+    hipLaunchKernelGGL(dice_sum_kernel, dim3(1), dim3(64), 0, st, (const double*)dpart, nb, sums);
+    return segmi_launch_status();
+}
+
+int segmi_dice_finalize(const double* sums, float smooth, float* loss_out, segmi_stream_t stream) {
+    if (!sums || !loss_out) return SEGMI_ERR_BADARG;
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, 1, smooth, loss_out);
+    return segmi_launch_status();
+}
 
 int segmi_dice_fwd(const float* logits, int ld, int64_t* target, long rows, int C, long ignore_index, float smooth,
                    int64_t* stats, float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
@@ -406,9 +453,8 @@ int segmi_dice_fwd(const float* logits, int ld, int64_t* target, long rows, int 
     hipStream_t st = (hipStream_t)stream;
     const int nb = ce_blocks(rows);
     double* dpart = (double*)workspace;
-    long long* ipart = (long long*)(dpart + 3 * (size_t)nb);
-    hipLaunchKernelGGL(target_stats_partial_kernel, dim3(nb), dim3(256), 0, st, (const int64_t*)target, rows, ignore_index, ipart);
-    hipLaunchKernelGGL(target_stats_final_kernel, dim3(1), dim3(64), 0, st, (const long long*)ipart, nb, ignore_index, stats);
+    int rc = segmi_target_stats(target, rows, ignore_index, stats, workspace, workspace_bytes, stream);
+    if (rc) return rc;
     hipLaunchKernelGGL(dice_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, (const int64_t*)stats, lse, dpart);
     hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)dpart, nb, smooth, loss_out);
     return segmi_launch_status();
@@ -424,23 +470,26 @@ int segmi_dice_bwd(const float* logits, int ld, const int64_t* target, const flo
 }
 
 int segmi_focal_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float gamma,
-                    float* lse, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+                    const float* alpha, float* lse, float* loss_out, void* workspace, size_t workspace_bytes,
+                    segmi_stream_t stream) {
     if (!logits || !target || !lse || !loss_out || rows <= 0 || C <= 0 || !(gamma >= 0.f)) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_ce_workspace(rows)) return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nb = ce_blocks(rows);
-    hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, gamma, lse, (double*)workspace);
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, ld, target, rows, C, ignore_index, gamma, alpha, lse,
+                       (double*)workspace);
     hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, (double)rows, loss_out);
     return segmi_launch_status();
 }
 
 int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const float* lse, long rows, int C, long ignore_index,
-                    float gamma, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
-    if (!logits || !target || !lse || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+                    float gamma, const float* alpha, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
+                    segmi_stream_t stream) {
+    if (!logits || !target || !lse || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
-                       ignore_index, gamma, grad_out, dlogits, lddl);
+                       ignore_index, gamma, alpha, loss_out, grad_out, dlogits, lddl);
     return segmi_launch_status();
 }
 

@@ -49,13 +49,13 @@ SIGNATURES = {
     "segmi_colsum": (i32, [vp, i32, i64, i32, vp, vp, sz, vp]),
     "segmi_bn_stats_workspace": (sz, [i64, i32]),
     "segmi_bn_stats": (i32, [vp, i32, i64, i32, vp, vp, sz, vp]),
-    "segmi_bn_finalize": (i32, [vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "segmi_bn_finalize": (i32, [vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "segmi_bn_stats_finalize": (i32, [vp, i32, i64, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),
     "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
-    "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp, i32, vp]),
+    "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "segmi_relu_fwd": (i32, [vp, i32, vp, i32, i64, i32, vp]),
     "segmi_relu_bwd": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "segmi_add": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),
@@ -68,13 +68,16 @@ SIGNATURES = {
     "segmi_bilinear_bwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "segmi_dropout": (i32, [vp, i32, vp, i32, i32, i64, i32, f32, i32, u64, vp, vp]),
     "segmi_ce_workspace": (sz, [i64]),
-    "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, sz, vp]),
-    "segmi_ce_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, i32, vp]),
+    "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "segmi_ce_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, vp, i32, vp]),
     "segmi_dice_workspace": (sz, [i64]),
     "segmi_dice_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, vp, sz, vp]),
     "segmi_dice_bwd": (i32, [vp, i32, vp, vp, i64, i32, vp, vp, vp, i32, vp]),
-    "segmi_focal_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, sz, vp]),
-    "segmi_focal_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, f32, vp, vp, i32, vp]),
+    "segmi_target_stats": (i32, [vp, i64, i64, vp, vp, sz, vp]),
+    "segmi_dice_sums": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "segmi_dice_finalize": (i32, [vp, f32, vp, vp]),
+    "segmi_focal_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, vp, sz, vp]),
+    "segmi_focal_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, f32, vp, vp, vp, vp, i32, vp]),
     "segmi_lovasz_workspace": (sz, [i64, i32]),
     "segmi_lovasz_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, i32, vp, vp, sz, vp]),
     "segmi_lovasz_bwd": (i32, [vp, i32, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),

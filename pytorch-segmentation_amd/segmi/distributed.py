@@ -26,6 +26,26 @@ def _is_dist():
     return dist.is_available() and dist.is_initialized()
 
 
+def global_batch_mean(local_sum, local_den, group=None):
+    """Per-rank terms of a GLOBAL-batch mean under gradient averaging.
+
+    The reference computes its loss on the gathered global batch (nn.DataParallel, trainer.py:56-66): for CrossEntropy that is
+    sum over ALL shards of the per-pixel losses / number of valid pixels of ALL shards (utils/losses.py:29-31).  One process per
+    GPU back-propagates a per-rank loss and AVERAGES gradients; with `W * local_sum / global_den` as the per-rank loss both the
+    average of the losses and the average of the gradients equal the global-batch value, also when shards hold different numbers
+    of valid pixels (equal shards reduce it to the local mean).  One all-reduce of a single float.
+
+    local_sum, local_den: 0-d tensors (device-agnostic).  Returns (loss term of this rank, denominator to divide the local
+    per-pixel gradients by = global_den / W)."""
+    world = dist.get_world_size(group) if _is_dist() else 1
+    if world == 1:
+        return local_sum / local_den, local_den
+    den = local_den.detach().clone().reshape(1)
+    dist.all_reduce(den, group=group)
+    den = den[0] / world
+    return local_sum / den, den
+
+
 class GradAllReducer:
     """Bucketed, overlapped gradient averaging for the parameters of one model replica.
 
@@ -156,34 +176,24 @@ class SyncBNContext:
     def __init__(self, process_group=None, clamp_mode=0):
         self.group = process_group
         self.clamp_mode = clamp_mode
-        self._count_cache = {}
+        self.collectives = 0          # issued by this layer so far (bench.py --sync-bn reports the per-step total)
 
     @property
     def world(self):
         return dist.get_world_size(self.group) if _is_dist() else 1
 
-    def global_count(self, rows):
-        """Sum of per-rank element counts per channel.  Exchanged once per distinct local `rows`
-        (host-side, synchronising) and cached: shards keep their shapes from step to step."""
-        if self.world == 1:
-            return float(rows)
-        c = self._count_cache.get(rows)
-        if c is None:
-            t = torch.tensor([float(rows)], dtype=torch.float64)
-            if dist.get_backend(self.group) == "nccl":
-                t = t.cuda()
-            dist.all_reduce(t, group=self.group)
-            c = self._count_cache[rows] = float(t.item())
-        return c
-
-    def gather_stats(self, part, rows):
-        """part: [3*C] local partial -> ([world*3*C] all partials, world, global count)."""
+    def gather_stats(self, part):
+        """part: [3*C] local partial {count, mean, M2} -> ([world*3*C] all partials, world).  The global element count is NOT
+        exchanged separately: every partial carries its own count, the merge kernel (segmi_bn_finalize) sums them on the device
+        and hands the total to the backward pass through device memory — correct for ragged shards and for shard sizes that
+        change from step to step, and no collective ever depends on rank-local state."""
         w = self.world
         if w == 1:
-            return part, 1, float(rows)
+            return part, 1
         out = torch.empty(w * part.numel(), dtype=part.dtype, device=part.device)
         dist.all_gather_into_tensor(out, part.contiguous(), group=self.group)
-        return out, w, self.global_count(rows)
+        self.collectives += 1
+        return out, w
 
     def reduce_sums(self, sums):
         """[2*C] local {sum dy, sum dy*xhat} -> global sums (new tensor; the local ones remain the
@@ -192,6 +202,7 @@ class SyncBNContext:
             return sums
         g = sums.clone()
         dist.all_reduce(g, group=self.group)
+        self.collectives += 1
         return g
 
 

@@ -170,8 +170,7 @@ def conv_out_size(H, k, stride, pad, dil):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-CONV_MATH = {"f32": 0, "bf16x3": 1, "bf16x3_simple": 2, "bf16x3_pk": 3,   # 2, 3: loop-structure variants of bf16x3 for A/B runs
-             "bf16x2": 4}                                                    # reduced precision (16 significand bits per operand)
+CONV_MATH = {"f32": 0, "bf16x3": 1}
 
 
 def set_conv_math(name):
@@ -461,7 +460,7 @@ class _BatchNormActFn(torch.autograd.Function):
         dev, st = x.device, _stream()
         if residual is not None:
             residual = to_nhwc(residual, "batch_norm.residual")
-        coef = torch.empty(4 * C, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift
+        coef = torch.empty(4 * C + 4, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift | global count (SyncBN)
         mean, invstd, scale, shift = (coef[i * C:(i + 1) * C] for i in range(4))
         gp = gamma.data_ptr() if gamma is not None else None
         bp = beta.data_ptr() if beta is not None else None
@@ -482,12 +481,13 @@ class _BatchNormActFn(torch.autograd.Function):
             ws = workspace(nws, dev)
             part = torch.empty(3 * C, device=dev, dtype=torch.float32)
             check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st), "bn_stats")
-            part, nparts, count = sync.gather_stats(part, rows)
-            if count <= 1:
-                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            # one all-gather; the global element count is summed from the gathered partials ON THE DEVICE (coef[4C]) — no host-side
+            # count exchange, so ragged / changing shard sizes cannot desynchronise the ranks' collectives
+            part, nparts = sync.gather_stats(part)
+            count = None
             check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
-                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
-                  "bn_finalize")
+                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                        coef.data_ptr() + 16 * C, st), "bn_finalize")
         else:
             check(lib.segmi_bn_eval_coeffs(running_mean.data_ptr(), running_var.data_ptr(), gp, bp, eps, C,
                                            mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
@@ -531,7 +531,8 @@ class _BatchNormActFn(torch.autograd.Function):
                 dres = empty_nhwc(N, C, H, W, dev)
             check(lib.segmi_bn_bwd_apply(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
                                          mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gsums.data_ptr(),
-                                         count, 1 if relu else 0, 1 if training else 0, dx.data_ptr(), ld_of(dx),
+                                         count if count is not None else 0.0, coef.data_ptr() + 16 * C if count is None else None,
+                                         1 if relu else 0, 1 if training else 0, dx.data_ptr(), ld_of(dx),
                                          dres.data_ptr() if dres is not None else None,
                                          ld_of(dres) if dres is not None else 0, st), "bn_bwd_apply")
         if want_res and not relu:
@@ -808,10 +809,34 @@ def dropout(x, p, training=True, channelwise=False):
     return _DropoutFn.apply(x, float(p), bool(channelwise), seed)
 
 
-# --------------------------------------------------------------------------- cross entropy
+# --------------------------------------------------------------------------- per-pixel losses
+# Data-parallel semantics (`group`): the reference evaluates its loss on the GATHERED global batch (trainer.py:56-66 under
+# nn.DataParallel), i.e. CE is the mean over the valid pixels of ALL shards and Dice's sums run over the whole batch.  One
+# process per GPU averages gradients instead, so each rank's loss is rescaled such that the AVERAGE over ranks of the
+# per-rank losses — and of their gradients — equals the global-batch value: CE/Focal: W * local_sum / global_denominator
+# (one all-reduce of the denominator), Dice: global sums (all-reduce of 3 doubles) with the upstream gradient times W.
+# `group` is a torch.distributed process group (or True = the default group); None / world size 1 = single-device maths.
+def _dist_world(group):
+    import torch.distributed as dist
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return None, 1
+    g = None if group is True else group
+    w = dist.get_world_size(g)
+    return g, w
+
+
+def _class_weight(weight, C, dev, what):
+    if weight is None:
+        return None
+    w = torch.as_tensor(weight, dtype=torch.float32).to(dev).contiguous()
+    if w.numel() != C:
+        raise SegmiError("%s: weight has %d entries, logits have %d classes" % (what, w.numel(), C))
+    return w
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index):
+    def forward(ctx, logits, target, ignore_index, weight, reduction, group):
         logits = to_nhwc(logits, "cross_entropy")
         N, C, H, W = logits.shape
         if target.dtype != torch.int64 or not target.is_cuda:
@@ -820,30 +845,47 @@ class _CrossEntropyFn(torch.autograd.Function):
             raise SegmiError("cross_entropy: target shape %s does not match logits %s" % (tuple(target.shape), tuple(logits.shape)))
         target = target.contiguous()
         rows, dev, st = N * H * W, logits.device, _stream()
+        cw = _class_weight(weight, C, dev, "cross_entropy")
         lse = torch.empty(rows, device=dev, dtype=torch.float32)
-        out = torch.empty(2, device=dev, dtype=torch.float32)  # {loss, n_valid}
+        out = torch.empty(3, device=dev, dtype=torch.float32)  # {mean, denominator, numerator}
         nws = lib.segmi_ce_workspace(rows)
         ws = workspace(nws, dev)
-        check(lib.segmi_ce_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
-                               out.data_ptr(), ws.data_ptr(), nws, st), "ce_fwd")
-        ctx.save_for_backward(logits, target, lse, out)
+        check(lib.segmi_ce_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index,
+                               cw.data_ptr() if cw is not None else None, lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "ce_fwd")
+        pg, world = _dist_world(group)
+        if reduction == "sum":
+            norm = torch.ones(3, device=dev, dtype=torch.float32)     # bwd divides by norm[1] = 1
+            value = out[2]
+            if world > 1:
+                norm = norm / world      # gradients are averaged over ranks: the sum over the global batch needs W * local
+                value = out[2] * world
+        elif world > 1:
+            from .distributed import global_batch_mean
+            value, den = global_batch_mean(out[2], out[1], pg)       # one all-reduce: valid pixels / weight sum of all shards
+            norm = torch.stack([out[0], den, out[2]])
+        else:
+            norm, value = out, out[0]
+        ctx.save_for_backward(logits, target, lse, norm, cw)
         ctx.ignore_index = ignore_index
-        return out[0]
+        return value
 
     @staticmethod
     def backward(ctx, g):
-        logits, target, lse, out = ctx.saved_tensors
+        logits, target, lse, norm, cw = ctx.saved_tensors
         N, C, H, W = logits.shape
         g = g.contiguous().float()
         dl = empty_nhwc(N, C, H, W, logits.device)
         check(lib.segmi_ce_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C,
-                               ctx.ignore_index, out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "ce_bwd")
-        return dl, None, None
+                               ctx.ignore_index, cw.data_ptr() if cw is not None else None, norm.data_ptr(), g.data_ptr(),
+                               dl.data_ptr(), ld_of(dl), _stream()), "ce_bwd")
+        return dl, None, None, None, None, None
 
 
-def cross_entropy(logits, target, ignore_index=255):
-    """nn.CrossEntropyLoss(ignore_index=..., reduction='mean') on [N,C,H,W] logits / [N,H,W] int64 target."""
-    return _CrossEntropyFn.apply(logits, target, int(ignore_index))
+def cross_entropy(logits, target, ignore_index=255, weight=None, reduction="mean", group=None):
+    """nn.CrossEntropyLoss(weight=..., ignore_index=..., reduction='mean'|'sum') on [N,C,H,W] logits / [N,H,W] int64 target."""
+    if reduction not in ("mean", "sum"):
+        raise SegmiError("cross_entropy: reduction must be 'mean' or 'sum' (got %r)" % (reduction,))
+    return _CrossEntropyFn.apply(logits, target, int(ignore_index), weight, reduction, group)
 
 
 def _loss_inputs(logits, target, what):
@@ -858,7 +900,7 @@ def _loss_inputs(logits, target, what):
 
 class _DiceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index, smooth):
+    def forward(ctx, logits, target, ignore_index, smooth, group):
         logits, rows, C = _loss_inputs(logits, target, "dice_loss")
         if not target.is_contiguous():
             raise SegmiError("dice_loss: target must be contiguous (it is rewritten in place like the reference does)")
@@ -868,10 +910,29 @@ class _DiceFn(torch.autograd.Function):
         stats = torch.empty(4, device=dev, dtype=torch.int64)
         nws = lib.segmi_dice_workspace(rows)
         ws = workspace(nws, dev)
-        check(lib.segmi_dice_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, smooth,
-                                 stats.data_ptr(), lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "dice_fwd")
+        pg, world = _dist_world(group)
+        if world == 1:
+            check(lib.segmi_dice_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, smooth,
+                                     stats.data_ptr(), lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "dice_fwd")
+        else:
+            import torch.distributed as dist
+            # the reference's target.min()/max()/(target == ignore).sum() are taken over the gathered global target (utils/losses.py:40-42)
+            check(lib.segmi_target_stats(target.data_ptr(), rows, ignore_index, stats.data_ptr(), ws.data_ptr(), nws, st), "target_stats")
+            ext = torch.stack([stats[0], -stats[1]])
+            dist.all_reduce(ext, op=dist.ReduceOp.MIN, group=pg)
+            cnt = stats[2:3].clone()
+            dist.all_reduce(cnt, group=pg)
+            tmin, tmax = ext[0], -ext[1]
+            in_range = (tmin <= ignore_index) & (tmax > ignore_index)
+            stats = torch.stack([tmin, tmax, cnt[0], ((~in_range) & (cnt[0] > 0)).to(torch.int64)]).contiguous()
+            sums = torch.empty(3, device=dev, dtype=torch.float64)
+            check(lib.segmi_dice_sums(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, stats.data_ptr(),
+                                      lse.data_ptr(), sums.data_ptr(), ws.data_ptr(), nws, st), "dice_sums")
+            dist.all_reduce(sums, group=pg)
+            check(lib.segmi_dice_finalize(sums.data_ptr(), smooth, out.data_ptr(), st), "dice_finalize")
         ctx.save_for_backward(logits, lse, out)
         ctx.target = target     # int64, no autograd involvement; kept by reference (its rewritten content is what backward needs)
+        ctx.world = world
         return out[0]
 
     @staticmethod
@@ -879,48 +940,63 @@ class _DiceFn(torch.autograd.Function):
         logits, lse, out = ctx.saved_tensors
         N, C, H, W = logits.shape
         g = g.contiguous().float()
+        if ctx.world > 1:
+            g = g * ctx.world       # this rank's share of the GLOBAL loss' gradient; the gradient all-reduce averages over ranks
         dl = empty_nhwc(N, C, H, W, logits.device)
         check(lib.segmi_dice_bwd(logits.data_ptr(), ld_of(logits), ctx.target.data_ptr(), lse.data_ptr(), N * H * W, C,
                                  out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "dice_bwd")
-        return dl, None, None, None
+        return dl, None, None, None, None
 
 
-def dice_loss(logits, target, ignore_index=255, smooth=1.0):
+def dice_loss(logits, target, ignore_index=255, smooth=1.0, group=None):
     """DiceLoss.forward of the reference (utils/losses.py:39-50), including its in-place rewrite of ignored target pixels."""
-    return _DiceFn.apply(logits, target, int(ignore_index), float(smooth))
+    return _DiceFn.apply(logits, target, int(ignore_index), float(smooth), group)
 
 
 class _FocalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index, gamma):
+    def forward(ctx, logits, target, ignore_index, gamma, alpha, size_average, group):
         logits, rows, C = _loss_inputs(logits, target, "focal_loss")
         target = target.contiguous()
         dev, st = logits.device, _stream()
+        cw = _class_weight(alpha, C, dev, "focal_loss")
         lse = torch.empty(rows, device=dev, dtype=torch.float32)
-        out = torch.empty(2, device=dev, dtype=torch.float32)
+        out = torch.empty(3, device=dev, dtype=torch.float32)      # {mean over all pixels, rows, sum}
         nws = lib.segmi_ce_workspace(rows)
         ws = workspace(nws, dev)
-        check(lib.segmi_focal_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, gamma, lse.data_ptr(),
-                                  out.data_ptr(), ws.data_ptr(), nws, st), "focal_fwd")
-        ctx.save_for_backward(logits, target, lse)
+        check(lib.segmi_focal_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, gamma,
+                                  cw.data_ptr() if cw is not None else None, lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "focal_fwd")
+        pg, world = _dist_world(group)
+        if not size_average:                                        # reference: loss.sum()
+            norm = torch.ones(3, device=dev, dtype=torch.float32) / world
+            value = out[2] * world
+        elif world > 1:
+            from .distributed import global_batch_mean
+            value, den = global_batch_mean(out[2], out[1], pg)     # pixels of all shards (ragged shards weigh by their size)
+            norm = torch.stack([out[0], den, out[2]])
+        else:
+            norm, value = out, out[0]
+        ctx.save_for_backward(logits, target, lse, norm, cw)
         ctx.cfg = (ignore_index, gamma)
-        return out[0]
+        return value
 
     @staticmethod
     def backward(ctx, g):
-        logits, target, lse = ctx.saved_tensors
+        logits, target, lse, norm, cw = ctx.saved_tensors
         ignore_index, gamma = ctx.cfg
         N, C, H, W = logits.shape
         g = g.contiguous().float()
         dl = empty_nhwc(N, C, H, W, logits.device)
         check(lib.segmi_focal_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C, ignore_index,
-                                  gamma, g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "focal_bwd")
-        return dl, None, None, None
+                                  gamma, cw.data_ptr() if cw is not None else None, norm.data_ptr(), g.data_ptr(), dl.data_ptr(),
+                                  ld_of(dl), _stream()), "focal_bwd")
+        return dl, None, None, None, None, None, None
 
 
-def focal_loss(logits, target, ignore_index=255, gamma=2.0):
-    """FocalLoss.forward of the reference (utils/losses.py:59-65), alpha=None, size_average=True."""
-    return _FocalFn.apply(logits, target, int(ignore_index), float(gamma))
+def focal_loss(logits, target, ignore_index=255, gamma=2.0, alpha=None, size_average=True, group=None):
+    """FocalLoss.forward of the reference (utils/losses.py:52-65): ce = alpha_t * (-log p_t) (0 where ignored),
+    ((1 - exp(-ce))^gamma * ce).mean() over ALL pixels (or .sum() with size_average=False)."""
+    return _FocalFn.apply(logits, target, int(ignore_index), float(gamma), alpha, bool(size_average), group)
 
 
 class _LovaszFn(torch.autograd.Function):

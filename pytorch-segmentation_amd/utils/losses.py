@@ -7,65 +7,75 @@ import torch.nn as nn
 
 from segmi import ops
 
+# Data parallelism: the reference computes every loss on the gathered global batch (nn.DataParallel, trainer.py:56-66).  With one
+# process per GPU the losses below reproduce that when `process_group` is "auto" (default: the default torch.distributed group
+# once it is initialised with more than one rank), a group object, or None (strictly per-rank maths).  See segmi.ops.
+
+
+def _group(pg):
+    return True if pg == "auto" else pg
+
 
 class CrossEntropyLoss2d(nn.Module):
-    """nn.CrossEntropyLoss(ignore_index, reduction='mean') (reference utils/losses.py:24-31) as one
-    fused log-softmax + NLL pass; backward recomputes softmax from the saved log-sum-exp."""
+    """nn.CrossEntropyLoss(weight, ignore_index, reduction) (reference utils/losses.py:24-31) as one
+    fused log-softmax + NLL pass; backward recomputes softmax from the saved log-sum-exp.
+    weight: per-class rescaling (weighted mean = sum w_t l / sum w_t over valid pixels); reduction 'mean' | 'sum'."""
 
-    def __init__(self, weight=None, ignore_index=255, reduction="mean"):
+    def __init__(self, weight=None, ignore_index=255, reduction="mean", process_group="auto"):
         super().__init__()
-        if weight is not None:
-            raise NotImplementedError("class weights are not supported by the fused CE kernel yet")
-        if reduction != "mean":
-            raise NotImplementedError("only reduction='mean' is on the hot path (reference default)")
+        if reduction not in ("mean", "sum"):
+            raise NotImplementedError("reduction=%r: the fused CE kernel reduces on the device ('mean' | 'sum'); the reference's "
+                                      "trainer needs a scalar (trainer.py:66-70)" % (reduction,))
+        self.register_buffer("weight", None if weight is None else weight.detach().clone().float())
+        self.reduction = reduction
         self.ignore_index = ignore_index
+        self.process_group = process_group
 
     def forward(self, output, target):
-        return ops.cross_entropy(output, target, self.ignore_index)
+        return ops.cross_entropy(output, target, self.ignore_index, self.weight, self.reduction, _group(self.process_group))
 
 
 class DiceLoss(nn.Module):
     """Reference utils/losses.py:33-50: softmax -> one-hot -> whole-batch Dice with smooth=1.  Like the reference it
     rewrites ignored pixels of the caller's `target` to target.min() in place."""
 
-    def __init__(self, smooth=1., ignore_index=255):
+    def __init__(self, smooth=1., ignore_index=255, process_group="auto"):
         super().__init__()
         self.ignore_index = ignore_index
         self.smooth = smooth
+        self.process_group = process_group
 
     def forward(self, output, target):
-        return ops.dice_loss(output, target, self.ignore_index, self.smooth)
+        return ops.dice_loss(output, target, self.ignore_index, self.smooth, _group(self.process_group))
 
 
 class FocalLoss(nn.Module):
-    """Reference utils/losses.py:52-65: ((1 - exp(-ce))^gamma * ce).mean() over all pixels, ce = 0 where ignored."""
+    """Reference utils/losses.py:52-65: ce = CrossEntropy(reduce=False, weight=alpha) (0 where ignored);
+    ((1 - exp(-ce))^gamma * ce).mean() over all pixels, or .sum() with size_average=False."""
 
-    def __init__(self, gamma=2, alpha=None, ignore_index=255, size_average=True):
+    def __init__(self, gamma=2, alpha=None, ignore_index=255, size_average=True, process_group="auto"):
         super().__init__()
-        if alpha is not None:
-            raise NotImplementedError("class weights (alpha) are not supported by the fused focal kernel")
+        self.register_buffer("alpha", None if alpha is None else alpha.detach().clone().float())
         self.gamma = gamma
         self.size_average = size_average
         self.ignore_index = ignore_index
+        self.process_group = process_group
 
     def forward(self, output, target):
-        loss = ops.focal_loss(output, target, self.ignore_index, self.gamma)
-        if self.size_average:
-            return loss
-        return loss * float(target.numel())      # reference: loss.sum()
+        return ops.focal_loss(output, target, self.ignore_index, self.gamma, self.alpha, self.size_average, _group(self.process_group))
 
 
 class CE_DiceLoss(nn.Module):
-    """Reference utils/losses.py:67-77: CrossEntropy(ignore_index) + DiceLoss() — the Dice term is built with its DEFAULT
-    ignore_index (255) whatever this module was given, and CE is evaluated first (on the not-yet-rewritten target).
+    """Reference utils/losses.py:67-77: CrossEntropy(weight, reduction, ignore_index) + DiceLoss() — the Dice term is built with
+    its DEFAULT ignore_index (255) whatever this module was given, and CE is evaluated first (on the not-yet-rewritten target).
     Unlike the reference, backward works when ignored pixels exist (there the in-place rewrite invalidates the
     tensor autograd saved for the CE term)."""
 
-    def __init__(self, smooth=1, reduction="mean", ignore_index=255, weight=None):
+    def __init__(self, smooth=1, reduction="mean", ignore_index=255, weight=None, process_group="auto"):
         super().__init__()
         self.smooth = smooth
-        self.dice = DiceLoss()
-        self.cross_entropy = CrossEntropyLoss2d(weight=weight, ignore_index=ignore_index, reduction=reduction)
+        self.dice = DiceLoss(process_group=process_group)
+        self.cross_entropy = CrossEntropyLoss2d(weight=weight, ignore_index=ignore_index, reduction=reduction, process_group=process_group)
 
     def forward(self, output, target):
         ce = self.cross_entropy(output, target.clone())     # CE keeps its own copy of the un-rewritten target for backward
@@ -74,7 +84,8 @@ class CE_DiceLoss(nn.Module):
 
 class LovaszSoftmax(nn.Module):
     """Reference utils/losses.py:79-89: softmax + Lovasz-Softmax over the whole batch, classes present in the labels.
-    (`classes` is stored in an attribute the reference never reads — utils/losses.py:82 — so 'present' is what runs.)"""
+    (`classes` is stored in an attribute the reference never reads — utils/losses.py:82 — so 'present' is what runs.)
+    Data parallel: the batch-level sort is not shard-decomposable, so each rank evaluates its own shard."""
 
     def __init__(self, classes="present", per_image=False, ignore_index=255):
         super().__init__()

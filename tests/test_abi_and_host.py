@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 4
+    assert lib.segmi_abi_version() == 5
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
@@ -70,21 +70,23 @@ def test_status_strings_and_queries():
 
 
 def test_conv_math_switch_and_variant_names():
-    """segmi_conv_set_math / get_math (include/segmi.h): default fp32 MFMA; the variant name reported for profiling carries
-    the arithmetic as its last template argument, exactly as a rocprofv3 kernel trace prints the instantiation."""
+    """segmi_conv_set_math / get_math (include/segmi.h): two arithmetics, f32 (fp32 MFMA chain) and bf16x3; the variant name
+    reported for profiling carries the arithmetic as its last template argument, exactly as a rocprofv3 kernel trace prints
+    the instantiation.  The process default comes from SEGMI_CONV_MATH (library default otherwise) and is restored."""
     from segmi import lib, ops
     from segmi._lib import ConvDesc
-    assert ops.get_conv_math() == "f32" and lib.segmi_conv_get_math() == 0
+    prev = ops.get_conv_math()
+    assert prev in ("f32", "bf16x3")
     d = ConvDesc(8, 64, 64, 512, 512, 3, 3, 64, 64, 1, 2, 2, 512, 512)
-    assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 0>"
-    assert lib.segmi_conv_set_math(7) == -1 and lib.segmi_conv_set_math(-1) == -1 and ops.get_conv_math() == "f32"
-    for name, code in (("bf16x3_simple", 2), ("bf16x3_pk", 3), ("bf16x2", 4)):   # A/B loop variants; reduced-precision mode
-        ops.set_conv_math(name)
-        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, %d>" % code
-    ops.set_conv_math("f32")
-    with pytest.raises(Exception):
-        ops.set_conv_math("tf32")
     try:
+        ops.set_conv_math("f32")
+        assert lib.segmi_conv_get_math() == 0
+        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 0>"
+        for bad in (7, -1, 2, 3, 4):                      # 2-4 were round-1 A/B variants, removed after their hardware run
+            assert lib.segmi_conv_set_math(bad) == -1 and ops.get_conv_math() == "f32"
+        for name in ("tf32", "bf16x2", "bf16x3_simple"):
+            with pytest.raises(Exception):
+                ops.set_conv_math(name)
         ops.set_conv_math("bf16x3")
         assert lib.segmi_conv_get_math() == 1
         assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>"
@@ -93,7 +95,7 @@ def test_conv_math_switch_and_variant_names():
         # workspace planning does not depend on the arithmetic
         assert lib.segmi_conv2d_wgrad_workspace(d) % (512 * 9 * 512 * 4) == 0
     finally:
-        ops.set_conv_math("f32")
+        ops.set_conv_math(prev)
 
 
 def test_conv_kernels_are_compiled_without_scratch(tmp_path):
@@ -115,8 +117,8 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
         kern[name]["agpr_count"] = int(blk.split()[0])
     dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
-    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]   # last template argument = MATH
-    assert per_math == [28, 28, 28, 28, 28], per_math
+    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]   # last template argument = MATH (0 f32, 1 bf16x3)
+    assert per_math == [28, 28, 0, 0, 0], per_math
     for n, v in dma.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
         # .vgpr_count is the unified total (arch VGPRs up to the accumulator offset + AGPRs); 2 x 256 = one SIMD's file

@@ -103,14 +103,3 @@ def test_pspnet_logits_under_the_bf16x3_model_are_as_close_to_fp64_as_fp32_is(mo
     assert e32 < 1e-4 and ex3 < 1e-4, (e32, ex3)                # both at fp32 level through 50+ layers ...
     assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)                  # ... and the split costs nothing beyond fp32 rounding
     assert int((x3.argmax(1) != f32.argmax(1)).sum()) <= 2      # masks agree (flips only possible at exact near-ties)
-
-
-def test_two_plane_mode_is_reduced_precision_by_the_stated_amount():
-    """SEGMI_CONV_MATH_BF16X2 keeps h*h' + h*m' + m*h': what it drops (m*m' <= 2^-16, l*h' + h*l' <= 2^-16) is <= 2^-15 of a
-    product in the worst case, ~2^-18 on average."""
-    a, b = _samples(100000, 4), _samples(100000, 5)
-    ah, am, _ = M.split3(a)
-    bh, bm, _ = M.split3(b)
-    kept = ah.astype(np.float64) * bh + am.astype(np.float64) * bh + ah.astype(np.float64) * bm
-    rel = np.abs(kept - a.astype(np.float64) * b) / np.abs(a.astype(np.float64) * b)
-    assert rel.max() <= 2.0 ** -15 and rel.mean() <= 2.0 ** -18

@@ -3,16 +3,13 @@ CPU convolution and against the default fp32-MFMA path, for fprop / dgrad / wgra
 uses.  Bound asserted: the bf16x3 result is as close to fp64 as the fp32 MFMA chain is (within 8x, plus one fp32 ulp of
 the largest output), i.e. fp32-level accuracy — NOT bf16-level (which would be ~1e-2).
 
-OPT-IN until its first run on hardware: the kernels were written in a round whose GPU budget was spent, so the default
-(parity, round-end) GPU suite must not depend on them.  Enable with SEGMI_TEST_BF16X3=1."""
-import os
-
+First run on hardware: round 2 (gpurun_out -> profiles/r02_bf16x3_*): error ratios 0.5-1.2 against the fp32 MFMA chain on every
+case below, so the tests are part of the default GPU suite.  Every test restores the arithmetic the process was running with."""
 import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SEGMI_TEST_BF16X3", "0") != "1", reason="opt-in: SEGMI_TEST_BF16X3=1")]
+pytestmark = pytest.mark.gpu
 
 CASES = [
     # N, C, H, W, K, R, stride, pad, dil          tile shape exercised
@@ -31,10 +28,10 @@ def _err(a, ref):
     return (a.detach().cpu().double() - ref).abs().max().item()
 
 
-@pytest.mark.parametrize("variant", ["bf16x3", "bf16x3_simple", "bf16x3_pk"])
 @pytest.mark.parametrize("case", CASES)
-def test_bf16x3_is_fp32_accurate(cuda, case, variant):
+def test_bf16x3_is_fp32_accurate(cuda, case):
     from segmi import ops
+    variant, prev = "bf16x3", ops.get_conv_math()
     N, C, H, W, K, R, stride, pad, dil = case
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, C, H, W, generator=g)
@@ -56,7 +53,7 @@ def test_bf16x3_is_fp32_accurate(cuda, case, variant):
             yd.backward(gy.to(cuda))
             got[math] = (yd, xd.grad, wd.grad)
     finally:
-        ops.set_conv_math("f32")
+        ops.set_conv_math(prev)
     for name, ref, a1, a3 in zip(("fwd", "dgrad", "wgrad"), refs, got["f32"], got[variant]):
         e1, e3 = _err(a1, ref), _err(a3, ref)
         ulp = ref.abs().max().item() * 2.0 ** -23
@@ -74,11 +71,12 @@ def test_bf16x3_wide_dynamic_range(cuda):
     x = torch.randn(2, 64, 16, 16, generator=g) * 1e2
     w = torch.randn(128, 64, 3, 3, generator=g) * 1e-6
     ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    prev = ops.get_conv_math()
     try:
         ops.set_conv_math("bf16x3")
         y = ops.conv2d(x.to(cuda), w.to(cuda).contiguous(memory_format=torch.channels_last), None, 1, 1, 1)
     finally:
-        ops.set_conv_math("f32")
+        ops.set_conv_math(prev)
     assert _err(y, ref) <= 1e-5 * ref.abs().max().item()
 
 
@@ -99,6 +97,7 @@ def test_bf16x3_training_step_matches_f32_path(cuda):
     t = torch.randint(0, 5, (2, 64, 64), generator=g).to(cuda)
     crit = CrossEntropyLoss2d(ignore_index=255)
     res = {}
+    prev = ops.get_conv_math()
     try:
         for math in ("f32", "bf16x3"):
             ops.set_conv_math(math)
@@ -108,37 +107,9 @@ def test_bf16x3_training_step_matches_f32_path(cuda):
             loss.backward()
             res[math] = (out.detach().clone(), loss.item(), m.master_branch[1].weight.grad.detach().clone())
     finally:
-        ops.set_conv_math("f32")
+        ops.set_conv_math(prev)
     o1, l1, g1 = res["f32"]
     o3, l3, g3 = res["bf16x3"]
     assert (o1 - o3).abs().max().item() <= 1e-3 * o1.abs().max().item()
     assert abs(l1 - l3) <= 1e-4
     assert ((g1 - g3).norm() / g1.norm()).item() <= 1e-3
-
-
-@pytest.mark.parametrize("case", CASES)
-def test_bf16x2_reduced_precision_mode_is_what_it_says(cuda, case):
-    """SEGMI_CONV_MATH_BF16X2 (two planes, three products) is NOT fp32-equivalent: 16 significand bits per operand.  It must
-    still meet the per-op convolution tolerance of the parity suite (1e-4 * max|ref|, tests/test_ops_gpu.py) and be far
-    better than plain bf16 (~4e-3)."""
-    from segmi import ops
-    N, C, H, W, K, R, stride, pad, dil = case
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(N, C, H, W, generator=g)
-    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
-    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
-    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad, dilation=dil)
-    gy = torch.randn(yr.shape, generator=g)
-    yr.backward(gy.double())
-    try:
-        ops.set_conv_math("bf16x2")
-        xd = x.to(cuda).requires_grad_(True)
-        wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-        yd = ops.conv2d(xd, wd, None, stride, pad, dil)
-        yd.backward(gy.to(cuda))
-    finally:
-        ops.set_conv_math("f32")
-    for name, ref, a in zip(("fwd", "dgrad", "wgrad"), (yr.detach(), xr.grad, wr.grad), (yd, xd.grad, wd.grad)):
-        e = _err(a, ref) / ref.abs().max().item()
-        print("bf16x2 %s %s: rel err %.3e" % (name, case, e))
-        assert e <= 1e-4, (name, case, e)

@@ -100,6 +100,53 @@ def test_bucketed_gradient_allreduce_equals_global_batch_gradient():
             assert e < 1e-6, (z, e)
 
 
+def _loss_worker(rank, world):
+    """Global-batch loss semantics: shards with DIFFERENT numbers of valid pixels.  Per-rank loss =
+    segmi.distributed.global_batch_mean(local sum, local count) -> averaged gradients == gradient of the single-process
+    CrossEntropy over the concatenated batch (reference trainer.py:56-66, utils/losses.py:29-31)."""
+    import torch.nn.functional as F
+    from segmi.distributed import DistributedModel, global_batch_mean
+    g = torch.Generator().manual_seed(17)
+    sizes = (3, 2)                                           # ragged shards too
+    X = torch.randn(sum(sizes), 3, 8, 8, generator=g)
+    T = torch.randint(0, 5, (sum(sizes), 8, 8), generator=g)
+    T[0, :6] = 255                                           # rank 0's shard: 3/4 of its first image ignored
+    T[4, :1] = 255                                           # rank 1's shard: one row
+    off = sum(sizes[:rank])
+    xs, ts = X[off:off + sizes[rank]], T[off:off + sizes[rank]]
+    torch.manual_seed(3)
+    net = torch.nn.Conv2d(3, 5, 3, padding=1)
+    dm = DistributedModel(net)
+    out = {}
+    for mode in ("global", "naive"):
+        dm.zero_grad()
+        logits = dm(xs)
+        lsum = F.cross_entropy(logits, ts, ignore_index=255, reduction="sum")
+        cnt = (ts != 255).sum().float()
+        if mode == "global":
+            loss, den = global_batch_mean(lsum, cnt)
+        else:
+            loss = lsum / cnt                                # what round 1 did: the mean of per-rank means
+        loss.backward()
+        dm.finish_gradients()
+        lavg = loss.detach().clone()
+        dist.all_reduce(lavg)
+        out[mode] = (lavg.item() / world, {k: p.grad.clone() for k, p in net.named_parameters()})
+    torch.manual_seed(3)
+    ref = torch.nn.Conv2d(3, 5, 3, padding=1)
+    rl = F.cross_entropy(ref(X), T, ignore_index=255)
+    rl.backward()
+    err = {m: max((out[m][1][k] - p.grad).abs().max().item() for k, p in ref.named_parameters()) for m in out}
+    return {"loss": {m: abs(out[m][0] - rl.item()) for m in out}, "err": err, "den": float(den), "valid": float((T != 255).sum())}
+
+
+def test_global_batch_loss_semantics_with_unequal_ignore_regions():
+    for r in _spawn(_loss_worker):
+        assert r["den"] == r["valid"] / 2                     # global valid count / world
+        assert r["loss"]["global"] < 1e-6 and r["err"]["global"] < 1e-6, r
+        assert r["err"]["naive"] > 1e-4, r                    # the per-rank mean is NOT the reference's semantics here
+
+
 def _welford_partial(x):
     """[3*C] packed partial exactly as segmi_bn_stats emits it: count (replicated), mean, M2 per channel."""
     C = x.shape[1]
@@ -132,21 +179,24 @@ def _syncbn_worker(rank, world):
     off = sum(rows[:rank])
     x = X[off:off + rows[rank]]
     ctx = SyncBNContext()
-    parts, nparts, count = ctx.gather_stats(_welford_partial(x), x.shape[0] * 16)
-    count2 = ctx.global_count(x.shape[0] * 16)       # cached second time
+    parts, nparts = ctx.gather_stats(_welford_partial(x))
     n, mean, m2 = _chan_merge(parts, nparts, 6)
+    # the global count is never exchanged on its own: it is the sum of the counts the partials carry (what segmi_bn_finalize
+    # sums on the device), so ragged shards cannot leave a rank with a stale cached value
+    count = float(parts.view(nparts, 3, 6)[:, 0, 0].sum())
     ref_mean = X.double().mean((0, 2, 3))
     ref_var = X.double().var((0, 2, 3), unbiased=False)
     sums = torch.arange(12.0) * (rank + 1)
     gs = ctx.reduce_sums(sums)
-    return {"nparts": nparts, "count": count, "count2": count2, "n": float(n[0]),
+    return {"nparts": nparts, "count": count, "collectives": ctx.collectives, "n": float(n[0]),
             "mean_err": (mean - ref_mean).abs().max().item(), "var_err": (m2 / n - ref_var).abs().max().item(),
             "sums_ok": torch.equal(gs, torch.arange(12.0) * 3), "local_untouched": torch.equal(sums, torch.arange(12.0) * (rank + 1))}
 
 
 def test_syncbn_statistic_exchange_matches_global_batch():
     for r in _spawn(_syncbn_worker):
-        assert r["nparts"] == 2 and r["count"] == r["count2"] == r["n"] == 8 * 16
+        assert r["nparts"] == 2 and r["count"] == r["n"] == 8 * 16
+        assert r["collectives"] == 2          # one all-gather forward, one all-reduce backward — no count exchange
         assert r["mean_err"] < 1e-6 and r["var_err"] < 1e-5
         assert r["sums_ok"] and r["local_untouched"]
 
@@ -161,7 +211,7 @@ def test_single_process_paths_need_no_process_group():
     assert torch.allclose(lin.weight.grad, torch.full((2, 3), 4.0))
     ctx = SyncBNContext()
     p = torch.ones(6)
-    assert ctx.gather_stats(p, 10) == (p, 1, 10.0) and ctx.reduce_sums(p) is p
+    assert ctx.gather_stats(p) == (p, 1) and ctx.reduce_sums(p) is p
 
 
 def test_syncbn_plugin_surface():

@@ -10,6 +10,11 @@ numbers of SURVEY.md §7 (pytest -s, or the captured stdout of a failure):
 
 and asserts
   * logits:  max|dlogit| <= 1e-3 * max|logit|          (strided sample of the main head; aux head for PSPNet)
+             — or, where the fp32 reference ITSELF is further than 5e-4 * max|logit| from the fp64 oracle (cfg3: DeepLab-R101 with
+             batch statistics at batch 2 amplifies fp32 rounding to 8.4e-4; two independent fp32 evaluations then differ by
+             ~sqrt(2) of that and no second fp32 implementation can meet 1e-3), the noise-floor criterion of
+             tests/test_pspnet_gpu.py: the HIP logits are at most 2x as far from the fp64 oracle as the reference's own are.
+             Both distances are printed for every config.
   * masks :  0 mismatches among pixels whose oracle top-2 margin exceeds 2*max|dlogit| — bit-identity on EVERY pixel is not
              attainable between two fp32 summation orders (torch-CPU NCHW vs channels_last already differ on 341 of 1 M
              pixels); every remaining mismatch is a numerical tie, and the count is printed
@@ -57,7 +62,8 @@ def run_fullsize_audit(name, device):
     assert tuple(out.shape) == (N, C, H, W)
     o = out.detach()
     mask = o.argmax(1).to(torch.uint8).cpu()
-    d = (o[:, :, ::s, ::s].cpu() - rec["logits"]).abs().max().item()
+    osub = o[:, :, ::s, ::s].cpu()
+    d = (osub - rec["logits"]).abs().max().item()
     margin = rec["margin"].float()
     mism = mask != rec["mask"]
     n_mis = int(mism.sum())
@@ -65,6 +71,7 @@ def run_fullsize_audit(name, device):
     bad = int((mism & (margin > 2 * d)).sum())
     res = {"config": name, "pixels": mask.numel(), "mismatches": n_mis, "max_margin_among_mismatches": max_margin_mis,
            "max_abs_dlogit": d, "logit_absmax": rec["logit_absmax"], "mismatches_outside_margin": bad,
+           "hip_err_f64": (osub.double() - rec["logits_f64"].double()).abs().max().item(), "ref_err_f64": rec["ref_err_f64"],
            "near_ties_in_oracle(margin<2d)": int((margin <= 2 * d).sum()),
            "loss": loss.item(), "loss_ref": rec["loss"].item()}
     if aux is not None:
@@ -88,12 +95,16 @@ def test_fullsize_step_matches_reference_golden(cuda, name):
     from segmi import ops
     r = run_fullsize_audit(name, cuda)
     print("\n[fullsize %s, conv math %s] pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
-          "(max|logit| %.3f) | mismatches outside 2*max|dlogit| %d | oracle pixels within that margin %d | loss %.6f (ref %.6f) | "
-          "grad-norm rel err median %.2e max %.2e (%s)"
+          "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
+          "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s)"
           % (name, ops.get_conv_math(), r["pixels"], r["mismatches"], r["max_margin_among_mismatches"], r["max_abs_dlogit"],
-             r["logit_absmax"], r["mismatches_outside_margin"], r["near_ties_in_oracle(margin<2d)"], r["loss"], r["loss_ref"],
+             r["logit_absmax"], r["hip_err_f64"], r["ref_err_f64"], r["mismatches_outside_margin"], r["near_ties_in_oracle(margin<2d)"],
+             r["loss"], r["loss_ref"],
              r["grad_norm_rel_err_median"], r["grad_norm_rel_err_max"], r["grad_norm_worst"]))
-    assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
+    if r["ref_err_f64"] <= 5e-4 * r["logit_absmax"]:
+        assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
+    else:                                     # the reference's own fp32 rounding noise is already ~1e-3 of the logit scale here
+        assert r["hip_err_f64"] <= 2.0 * r["ref_err_f64"] and r["max_abs_dlogit"] <= 3.0 * r["ref_err_f64"], r
     assert r["mismatches_outside_margin"] == 0, r
     if "max_abs_daux" in r:
         assert r["max_abs_daux"] <= 1e-3 * r["aux_absmax"], r

@@ -33,7 +33,7 @@ x3)
   # of the whole training step (SEGMI_CONV_MATH is read at the first convolution of the process)
   ( SEGMI_TEST_BF16X3=1 timeout 900 python -m pytest tests/test_conv_bf16x3_gpu.py -m gpu -q -s 2>&1 | tail -60 ) > gpurun_out/x3_tests.log
   cat gpurun_out/x3_tests.log
-  for m in f32 bf16x3 bf16x3_simple bf16x3_pk; do
+  for m in f32 bf16x3; do
     ( SEGMI_CONV_MATH=$m timeout 300 python tools/conv_bench.py psp_bottleneck l4_3x3_d4 l4_1x1_up l3_1x1_down l1_1x1 stem3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/x3_convbench_$m.txt
     ( timeout 600 python bench.py --no-cpu --conv-math $m 2>&1 | tail -1 ) > gpurun_out/x3_bench_$m.log
   done
@@ -76,6 +76,12 @@ testsf32)
 graphdbg)
   ( SEGMI_TEST_GRAPH=1 timeout 600 python -X faulthandler -m pytest tests/test_graph_gpu.py -m gpu -x -q -s 2>&1 | grep -v "^  File" | head -80 ) > gpurun_out/graph_tests_dbg.log
   cat gpurun_out/graph_tests_dbg.log ;;
+x3exp)
+  # where does the bf16x3 loop's time go?  fprop only: full arithmetic vs no split (planes = raw bits) vs no matrix instructions
+  for m in f32 bf16x3; do
+    ( SEGMI_CONV_MATH=$m timeout 300 python tools/conv_bench.py psp_bottleneck l4_3x3_d4 l4_1x1_up --op fwd 2>&1 | grep -v amdgpu.ids ) > gpurun_out/x3exp_$m.txt
+    echo "== $m"; cat gpurun_out/x3exp_$m.txt
+  done ;;
 spawn)
   # the self-launching multi-GPU bench on a 1-GPU box: two ranks share cuda:0 (gloo on device tensors; RCCL needs one GPU per rank)
   ( timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -4 ) > gpurun_out/spawn.log; cat gpurun_out/spawn.log ;;
