@@ -228,6 +228,21 @@ int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float
                  long ignore_index, const float* class_weight, const float* loss_out, const float* grad_out, float* dlogits,
                  int lddl, segmi_stream_t stream);
 
+/* CrossEntropyLoss2d applied to bilinearly upsampled logits — F.interpolate(logits_lo, size=(OH, OW), mode='bilinear',
+ * align_corners) followed by the loss (models/pspnet.py:85-91 / models/deeplabv3_plus.py:361 + trainer.py:56-66) — WITHOUT
+ * materialising the [N, C, OH, OW] tensor: fwd interpolates each output pixel's four low-resolution neighbours on the fly and
+ * keeps only lse[N*OH*OW]; bwd recomputes the softmax the same way while reducing along the width, so the gradient is produced
+ * directly for logits_lo [N, H, W, C] (pixel stride ld / lddl).  loss_out, class_weight, grad_out as segmi_ce_fwd / _bwd.
+ * Workspace: segmi_upsample_ce_workspace (16-byte aligned). */
+size_t segmi_upsample_ce_workspace(int N, int H, int W, int C, int OH, int OW);
+int segmi_upsample_ce_fwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                          const int64_t* target, long ignore_index, const float* class_weight, float* lse, float* loss_out,
+                          void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_upsample_ce_bwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                          const int64_t* target, const float* lse, long ignore_index, const float* class_weight,
+                          const float* loss_out, const float* grad_out, float* dlogits_lo, int lddl, void* workspace,
+                          size_t workspace_bytes, segmi_stream_t stream);
+
 /* DiceLoss (utils/losses.py:33-50): softmax, one-hot, whole-batch 1 - (2*sum(p*y)+s)/(sum(p)+sum(y)+s).
  * Reproduces the reference's in-place rewrite of ignored pixels to target.min() (target is mutated when
  * ignore_index is not in range(target.min(), target.max()) and an ignored pixel exists); stats[4] =

@@ -87,19 +87,14 @@ class BaseTrainer:
         otype = config["optimizer"]["type"]
         oargs = config["optimizer"]["args"]
         fused = hasattr(segmi_optim, otype) and not oargs.get("nesterov") and not oargs.get("dampening")
-        # segmi extensions of the `trainer` section (both default off = the reference's behaviour):
+        # segmi extension of the `trainer` section (absent = the process-wide setting, SEGMI_CONV_MATH or the library default):
         #   "conv_math": "f32" | "bf16x3"   matrix arithmetic of the convolutions (include/segmi.h segmi_conv_set_math)
-        #   "hip_graph": true               replay the training step from a hipGraph (segmi.graph.GraphedStep); needs the fused SGD
         from segmi import ops as segmi_ops
-        if "conv_math" in cfg_trainer:            # absent: leave the process-wide setting (SEGMI_CONV_MATH or fp32) alone
+        if "conv_math" in cfg_trainer:
             segmi_ops.set_conv_math(cfg_trainer["conv_math"])
-        self.use_graph = bool(cfg_trainer.get("hip_graph", False))
-        if self.use_graph and not fused:
-            raise ValueError("trainer.hip_graph needs an optimizer with device-resident hyper-parameters (segmi.optim.SGD)")
-        if self.use_graph:
-            self.optimizer = getattr(segmi_optim, otype)(trainable_params, capturable=True, **oargs)
-        else:
-            self.optimizer = get_instance(segmi_optim if fused else torch.optim, "optimizer", config, trainable_params)
+        self.optimizer = get_instance(segmi_optim if fused else torch.optim, "optimizer", config, trainable_params)
+        # data parallel + fused SGD: the update of a gradient bucket is launched right after ITS all-reduce (segmi.distributed)
+        self.bucket_step = bool(self.model.reducer.collective and fused and self.model.attach_optimizer(self.optimizer))
         self.lr_scheduler = getattr(utils.lr_scheduler, config["lr_scheduler"]["type"])(self.optimizer, self.epochs, len(train_loader))
 
         # MONITORING

@@ -6,6 +6,12 @@
 // CrossEntropyLoss2d  utils/losses.py:24-31  (aten::log_softmax + aten::nll_loss2d, ignore_index,
 //                      reduction='mean' over non-ignored pixels; all-ignored -> NaN like torch)
 #include "segmi_common.h"
+#include "bilinear.h"
+#include "rowgeom.h"
+
+// height pass of the separable bilinear backward (pool_resize.hip; C++ linkage, internal)
+int segmi_internal_bilinear_bwd_height(const float* tmp, int ldt, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                                       int ac, hipStream_t st);
 
 namespace {
 
@@ -113,6 +119,173 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
             }
             st4(dl + r * lddl + q * 4, d);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CrossEntropy on bilinearly UPSAMPLED logits, without materialising them  (SURVEY §8 f2).
+// The reference upsamples its stride-8 (PSPNet, models/pspnet.py:85-91) or stride-4 (DeepLab decoder, models/deeplabv3_plus.py:361)
+// logits to the input size and feeds the full-resolution tensor to the loss (trainer.py:56-66): at cfg2 that is a 201 MB tensor
+// per head written, read twice by log_softmax / nll_loss forward + backward, a 201 MB gradient written and read again by the
+// bilinear backward.  Here the loss kernel interpolates the four low-resolution neighbours of each output pixel on the fly
+// (they stay in L2: the low-resolution logits are 2.7 MB) — the only full-resolution array is the per-pixel log-sum-exp
+// (4 B/pixel) — and the backward recomputes softmax the same way while reducing along the width (pass W of the separable
+// bilinear transpose), so the gradient is born at [N, OH, W_lo] and never exists at full resolution.
+constexpr int UP_CACHE = 5;   // float4 channel groups a lane keeps in registers: 8 lanes x 5 x 4 = 160 classes
+struct UpPix { const float* p00; const float* p01; const float* p10; const float* p11; float a0, a1, b0, b1; };
+__device__ __forceinline__ UpPix up_pix(const float* lo, int ld, int n, int H, int W, const Lerp& a, const Lerp& b) {
+    const float* base = lo + (long)n * H * W * ld;
+    UpPix u;
+    u.p00 = base + ((long)a.i0 * W + b.i0) * ld; u.p01 = base + ((long)a.i0 * W + b.i1) * ld;
+    u.p10 = base + ((long)a.i1 * W + b.i0) * ld; u.p11 = base + ((long)a.i1 * W + b.i1) * ld;
+    u.a0 = a.l0; u.a1 = a.l1; u.b0 = b.l0; u.b1 = b.l1;
+    return u;
+}
+// same expression as bilinear_fwd_kernel (pool_resize.hip)
+__device__ __forceinline__ float4 up4(const UpPix& u, int q) {
+    const float4 v00 = ld4(u.p00 + q * 4), v01 = ld4(u.p01 + q * 4), v10 = ld4(u.p10 + q * 4), v11 = ld4(u.p11 + q * 4);
+    float4 o;
+    o.x = u.a0 * (u.b0 * v00.x + u.b1 * v01.x) + u.a1 * (u.b0 * v10.x + u.b1 * v11.x);
+    o.y = u.a0 * (u.b0 * v00.y + u.b1 * v01.y) + u.a1 * (u.b0 * v10.y + u.b1 * v11.y);
+    o.z = u.a0 * (u.b0 * v00.z + u.b1 * v01.z) + u.a1 * (u.b0 * v10.z + u.b1 * v11.z);
+    o.w = u.a0 * (u.b0 * v00.w + u.b1 * v01.w) + u.a1 * (u.b0 * v10.w + u.b1 * v11.w);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__ lo, int ld, int N, int H, int W, int C, int OH, int OW, int ac,
+                                                       const int64_t* __restrict__ target, long ignore, const float* __restrict__ cw,
+                                                       float* __restrict__ lse_out, double* __restrict__ part) {
+    const int g = threadIdx.x & (LPP - 1);
+    const long ppb = 256 / LPP;
+    const int c4n = (C + 3) >> 2;
+    const long rows = (long)N * OH * OW;
+    const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
+    float lsum = 0.f, lcnt = 0.f;
+    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
+        const int ow = (int)(r % OW);
+        const long tq = r / OW;
+        const int oh = (int)(tq % OH), n = (int)(tq / OH);
+        const UpPix u = up_pix(lo, ld, n, H, W, bl_src(oh, sh, H, ac), bl_src(ow, sw, W, ac));
+        const long t = target[r];
+        const bool valid = t != ignore && t >= 0 && t < C;
+        // interpolate once: a lane keeps its (up to UP_CACHE) channel groups in registers for the max and the exp-sum passes;
+        // wider class counts (> 32 * UP_CACHE) recompute the tail
+        float4 vc[UP_CACHE];
+#pragma unroll
+        for (int k = 0; k < UP_CACHE; ++k) { const int q = g + k * LPP; vc[k] = q < c4n ? up4(u, q) : zero4(); }
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < UP_CACHE; ++k) {
+            const int q = g + k * LPP, c = q * 4;
+            if (q < c4n) {
+                m = fmaxf(m, vc[k].x);
+                if (c + 1 < C) m = fmaxf(m, vc[k].y);
+                if (c + 2 < C) m = fmaxf(m, vc[k].z);
+                if (c + 3 < C) m = fmaxf(m, vc[k].w);
+            }
+        }
+        for (int q = g + UP_CACHE * LPP; q < c4n; q += LPP) {
+            const float4 v = up4(u, q);
+            const int c = q * 4;
+            m = fmaxf(m, v.x);
+            if (c + 1 < C) m = fmaxf(m, v.y);
+            if (c + 2 < C) m = fmaxf(m, v.z);
+            if (c + 3 < C) m = fmaxf(m, v.w);
+        }
+        m = grp_max(m);
+        float s = 0.f, x_t = 0.f;
+#pragma unroll
+        for (int k = 0; k < UP_CACHE; ++k) {
+            const int q = g + k * LPP, c = q * 4;
+            if (q < c4n) {
+                const float4 v = vc[k];
+                s += expf(v.x - m);
+                if (c + 1 < C) s += expf(v.y - m);
+                if (c + 2 < C) s += expf(v.z - m);
+                if (c + 3 < C) s += expf(v.w - m);
+                if (valid && t >= c && t < c + 4) { const int o = (int)(t - c); x_t = o == 0 ? v.x : o == 1 ? v.y : o == 2 ? v.z : v.w; }
+            }
+        }
+        for (int q = g + UP_CACHE * LPP; q < c4n; q += LPP) {
+            const float4 v = up4(u, q);
+            const int c = q * 4;
+            s += expf(v.x - m);
+            if (c + 1 < C) s += expf(v.y - m);
+            if (c + 2 < C) s += expf(v.z - m);
+            if (c + 3 < C) s += expf(v.w - m);
+            if (valid && t >= c && t < c + 4) { const int o = (int)(t - c); x_t = o == 0 ? v.x : o == 1 ? v.y : o == 2 ? v.z : v.w; }
+        }
+        s = grp_sum(s);
+        const float xt = grp_sum(x_t);
+        const float lse = m + logf(s);
+        if (g == 0) {
+            lse_out[r] = lse;
+            if (valid) { const float w = cw ? cw[t] : 1.f; lsum += w * (lse - xt); lcnt += w; }
+        }
+    }
+    lsum = wave_sum(lsum); lcnt = wave_sum(lcnt);
+    __shared__ float sm[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sm[wave] = lsum; sm[4 + wave] = lcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (double)sm[0] + sm[1] + sm[2] + sm[3];
+        part[2 * blockIdx.x + 1] = (double)sm[4] + sm[5] + sm[6] + sm[7];
+    }
+}
+
+// pass W of the backward: tmp[(n, oh, wl), c] = sum_ow ww(ow -> wl) * w_t * (softmax(n, oh, ow)[c] - [t == c]) * g / denominator
+// (thread = one float4 channel group of one (n, oh, wl) row; ~2 * OW/W + 2 candidate output columns each)
+__global__ __launch_bounds__(256) void upce_bwd_w_kernel(const float* __restrict__ lo, int ld, int N, int H, int W, int C, int OH, int OW, int ac,
+                                                         const int64_t* __restrict__ target, const float* __restrict__ lse, long ignore,
+                                                         const float* __restrict__ cw, const float* __restrict__ loss_out,
+                                                         const float* __restrict__ grad_out, float* __restrict__ tmp, int ldt) {
+    const int c4n = (C + 3) / 4;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= c4n) return;
+    const int c = c4 * 4;
+    const long rows = (long)N * OH * W;
+    const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
+    const float gs0 = grad_out[0] / loss_out[1];
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
+        const int wl = (int)(r % W);
+        const long tq = r / W;                    // n * OH + oh
+        const int oh = (int)(tq % OH), n = (int)(tq / OH);
+        const Lerp a = bl_src(oh, sh, H, ac);
+        int lo_c, hi_c;
+        bl_range(wl, sw, W, OW, ac, lo_c, hi_c);
+        // every output column with a non-zero weight on wl interpolates between wl and ONE of its neighbours: blend the two
+        // low-resolution rows (a.i0, a.i1) once for the columns wl-1, wl, wl+1 and reuse them for all ~2*OW/W candidates
+        const float* base = lo + (long)n * H * W * ld + c;
+        const int wm = max(wl - 1, 0), wp = min(wl + 1, W - 1);
+        float4 R[3];
+        {
+            const int cols[3] = {wm, wl, wp};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 t0 = ld4(base + ((long)a.i0 * W + cols[j]) * ld), t1 = ld4(base + ((long)a.i1 * W + cols[j]) * ld);
+                R[j] = make_float4(a.l0 * t0.x + a.l1 * t1.x, a.l0 * t0.y + a.l1 * t1.y, a.l0 * t0.z + a.l1 * t1.z, a.l0 * t0.w + a.l1 * t1.w);
+            }
+        }
+        float4 acc = zero4();
+        for (int ow = lo_c; ow <= hi_c; ++ow) {
+            const Lerp b = bl_src(ow, sw, W, ac);
+            const float wt = (b.i0 == wl ? b.l0 : 0.f) + (b.i1 == wl ? b.l1 : 0.f);
+            if (wt == 0.f) continue;
+            const long hp = tq * OW + ow;
+            const long t = target[hp];
+            if (t == ignore || t < 0 || t >= C) continue;
+            const float4 r0 = b.i0 == wl ? R[1] : (b.i0 < wl ? R[0] : R[2]);
+            const float4 r1 = b.i1 == wl ? R[1] : (b.i1 < wl ? R[0] : R[2]);
+            const float4 v = make_float4(b.l0 * r0.x + b.l1 * r1.x, b.l0 * r0.y + b.l1 * r1.y, b.l0 * r0.z + b.l1 * r1.z, b.l0 * r0.w + b.l1 * r1.w);
+            const float l = lse[hp];
+            const float k = wt * (cw ? gs0 * cw[t] : gs0);
+            acc.x += k * (expf(v.x - l) - (t == c ? 1.f : 0.f));
+            if (c + 1 < C) acc.y += k * (expf(v.y - l) - (t == c + 1 ? 1.f : 0.f));
+            if (c + 2 < C) acc.z += k * (expf(v.z - l) - (t == c + 2 ? 1.f : 0.f));
+            if (c + 3 < C) acc.w += k * (expf(v.w - l) - (t == c + 3 ? 1.f : 0.f));
+        }
+        st4(tmp + r * ldt + c, acc);
     }
 }
 
@@ -409,6 +582,45 @@ int segmi_ce_bwd(const float* logits, int ld, const int64_t* target, const float
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, lse, rows, C,
                        ignore_index, class_weight, loss_out, grad_out, dlogits, lddl);
     return segmi_launch_status();
+}
+
+size_t segmi_upsample_ce_workspace(int N, int H, int W, int C, int OH, int OW) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return 0;
+    const size_t a = segmi_ce_workspace((long)N * OH * OW);
+    const size_t b = (size_t)N * OH * W * ((C + 3) & ~3) * sizeof(float);     // pass-W buffer of the backward
+    return a > b ? a : b;
+}
+
+int segmi_upsample_ce_fwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                          const int64_t* target, long ignore_index, const float* class_weight, float* lse, float* loss_out,
+                          void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits_lo || !target || !lse || !loss_out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    const long rows = (long)N * OH * OW;
+    if (!workspace || workspace_bytes < segmi_ce_workspace(rows)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_blocks(rows);
+    hipLaunchKernelGGL(upce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits_lo, ld, N, H, W, C, OH, OW, align_corners ? 1 : 0, target,
+                       ignore_index, class_weight, lse, (double*)workspace);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, loss_out);
+    return segmi_launch_status();
+}
+
+int segmi_upsample_ce_bwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                          const int64_t* target, const float* lse, long ignore_index, const float* class_weight,
+                          const float* loss_out, const float* grad_out, float* dlogits_lo, int lddl, void* workspace,
+                          size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits_lo || !target || !lse || !loss_out || !grad_out || !dlogits_lo || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0)
+        return SEGMI_ERR_BADARG;
+    if ((ld & 3) || ld < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_upsample_ce_workspace(N, H, W, C, OH, OW) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ldt = (C + 3) & ~3, ac = align_corners ? 1 : 0;
+    float* tmp = (float*)workspace;
+    RowGeom g0 = row_geom((long)N * OH * W, C, 1, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL(upce_bwd_w_kernel, g0.grid, g0.block, 0, st, logits_lo, ld, N, H, W, C, OH, OW, ac, target, lse, ignore_index,
+                       class_weight, loss_out, grad_out, tmp, ldt);
+    return segmi_internal_bilinear_bwd_height(tmp, ldt, dlogits_lo, lddl, N, H, W, C, OH, OW, ac, st);
 }
 
 /* workspace: 3 doubles per block (dice partials) + 3 int64 per block (target statistics) */

@@ -8,6 +8,7 @@
 //   aten::upsample_bilinear2d(+bwd)      models/pspnet.py:35-36,86,91; models/deeplabv3_plus.py:291,328,361;
 //                                        models/unet.py:46-47
 #include "rowgeom.h"
+#include "bilinear.h"
 
 namespace {
 
@@ -155,24 +156,7 @@ __global__ __launch_bounds__(256) void aap_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------ bilinear
-// Source coordinate exactly as aten's area_pixel_compute_source_index (fp32):
-//   align_corners: src = dst * (in-1)/(out-1)            (scale 0 when out == 1)
-//   otherwise    : src = max(0, fma(in/out, dst+0.5, -0.5))
-struct Lerp { int i0, i1; float l0, l1; };
-__device__ __forceinline__ float bl_scale(int in, int out, int ac) {
-    if (ac) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    return (float)in / (float)out;
-}
-__device__ __forceinline__ Lerp bl_src(int dst, float scale, int in, int ac) {
-    float s = ac ? scale * (float)dst : fmaxf(__fmaf_rn(scale, (float)dst + 0.5f, -0.5f), 0.f);
-    Lerp L;
-    L.i0 = min((int)s, in - 1);
-    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
-    L.l1 = s - (float)L.i0;
-    L.l0 = 1.f - L.l1;
-    return L;
-}
-
+// (source-coordinate helpers Lerp / bl_scale / bl_src / bl_range: bilinear.h, shared with the fused upsample+loss kernels)
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                            int N, int H, int W, int C, int OH, int OW, int ac) {
     const int c4n = (C + 3) / 4;
@@ -195,18 +179,6 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
         o.w = a.l0 * (b.l0 * v00.w + b.l1 * v01.w) + a.l1 * (b.l0 * v10.w + b.l1 * v11.w);
         st4(y + r * ldy + c4 * 4, o);
     }
-}
-
-// candidate output range [lo, hi] whose source coordinate can touch input index i
-__device__ __forceinline__ void bl_range(int i, float scale, int in, int out, int ac, int& lo, int& hi) {
-    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
-    float a, b;
-    if (ac) { a = ((float)i - 1.f) / scale; b = ((float)i + 1.f) / scale; }
-    else    { a = ((float)i - 0.5f) / scale - 0.5f; b = ((float)i + 1.5f) / scale - 0.5f; }
-    lo = max(0, (int)floorf(a) - 1);
-    hi = min(out - 1, (int)ceilf(b) + 1);
-    if (i == 0) lo = 0;              // clamped sources (src < 0 -> 0)
-    if (i == in - 1) hi = out - 1;   // clamped i1
 }
 
 // Backward = exact transpose of the forward in GATHER form (deterministic, no atomics), done separably:
@@ -449,6 +421,19 @@ int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H,
     hipLaunchKernelGGL(bilinear_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, N, H, W, C, OH, OW, align_corners ? 1 : 0);
     return segmi_launch_status();
 }
+
+}  // extern "C"
+
+// Height pass of the separable bilinear backward on a width-reduced buffer tmp[N, OH, W, ldt] — internal (C++ linkage, not part
+// of the C ABI): the fused upsample + cross-entropy backward of loss.hip produces tmp itself.
+int segmi_internal_bilinear_bwd_height(const float* tmp, int ldt, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                                       int ac, hipStream_t st) {
+    RowGeom g1 = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID);
+    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), g1.grid, g1.block, 0, st, tmp, ldt, dx, lddx, N, H, W, C, OH, OW, ac);
+    return segmi_launch_status();
+}
+
+extern "C" {
 
 size_t segmi_bilinear_bwd_workspace(int N, int H, int W, int C, int OH, int OW) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return 0;

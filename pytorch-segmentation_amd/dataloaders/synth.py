@@ -5,8 +5,14 @@ data loading.  `Synth` yields the same thing the trainer consumes — (image fp3
 exposes the attributes the trainer reads: `batch_size`, `MEAN`, `STD`, `dataset.num_classes`, `dataset.palette`, `__len__`.
 Batches are a pure function of (seed, index), so the reference trainer on CPU and this trainer on the GPU see identical data.
 `device=` keeps the batches resident in HBM (what a DataPrefetcher, base/base_dataloader.py:49-85, delivers).
+
+Data parallelism: the reference's nn.DataParallel scatters ONE loader batch over the GPUs; with one process per GPU each rank
+draws its own shard instead: iteration i of rank r is global batch i * world + r (`rank` / `world` default to the
+torch.distributed group when it is initialised), so W ranks consume W different batches per step and the averaged gradient is
+that of the W-times larger global batch.  `len()` is the number of iterations PER RANK.
 """
 import torch
+import torch.distributed as dist
 
 
 class _SynthDataset:
@@ -20,7 +26,7 @@ class Synth:
     STD = [0.229, 0.224, 0.225]
 
     def __init__(self, num_classes=2, batch_size=2, height=256, width=256, iters=4, ignore_index=255, seed=1234, block=16,
-                 device=None, **_):
+                 device=None, rank=None, world=None, **_):
         self.dataset = _SynthDataset(num_classes)
         self.batch_size = batch_size
         self.shape = (batch_size, 3, height, width)
@@ -29,6 +35,9 @@ class Synth:
         self.seed = seed
         self.block = block
         self.device = device
+        ddp = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank() if ddp else 0) if rank is None else int(rank)
+        self.world = (dist.get_world_size() if ddp else 1) if world is None else int(world)
 
     def __len__(self):
         return self.iters
@@ -48,4 +57,4 @@ class Synth:
 
     def __iter__(self):
         for i in range(self.iters):
-            yield self.batch(i)
+            yield self.batch(i * self.world + self.rank)      # this rank's shard of global step i

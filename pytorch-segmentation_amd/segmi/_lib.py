@@ -70,6 +70,9 @@ SIGNATURES = {
     "segmi_ce_workspace": (sz, [i64]),
     "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, vp, sz, vp]),
     "segmi_ce_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, vp, i32, vp]),
+    "segmi_upsample_ce_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
+    "segmi_upsample_ce_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, sz, vp]),
+    "segmi_upsample_ce_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_dice_workspace": (sz, [i64]),
     "segmi_dice_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, vp, sz, vp]),
     "segmi_dice_bwd": (i32, [vp, i32, vp, vp, i64, i32, vp, vp, vp, i32, vp]),

@@ -80,6 +80,7 @@ class GradAllReducer:
             cur_bytes += nb
         if cur:
             self._make_bucket(cur)
+        self._fired = set()        # id(param) of the parameters whose gradient arrived in the current iteration
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _make_bucket(self, params):
@@ -103,8 +104,10 @@ class GradAllReducer:
             b["pending"], b["launched"], b["work"] = len(b["params"]), False, None
         for p in self.params:
             p.grad = self._where[id(p)][1]
+        self._fired.clear()
 
     def _on_grad(self, p):
+        self._fired.add(id(p))
         idx, view = self._where[id(p)]
         g = p.grad
         if g is not view:
@@ -135,9 +138,14 @@ class GradAllReducer:
             b["work"] = dist.all_reduce(b["buf"], op=op, group=self.group, async_op=True)
             b["scale"] = self.average
 
-    def finish(self):
+    def finish(self, optimizer=None):
         """Block the compute stream (not the host, on GPU) until every bucket is reduced.  Buckets whose
-        parameters got no gradient this iteration (unused branches) are reduced here with zeros."""
+        parameters got no gradient this iteration (unused branches) are reduced here with zeros.
+
+        optimizer: a segmi.optim.SGD whose table was laid out per bucket (`optimizer.set_segments(reducer.segments())`): the
+        fused update of a bucket's parameters is launched right after the wait on ITS all-reduce, so it runs while the later
+        buckets (the gradients backward produced last: stem, layer1) are still being reduced on the side stream — the
+        optimizer step of the reference (trainer.py:71, after the whole DataParallel gather) moved into the exchange."""
         for b in self.buckets:
             if not b["launched"]:
                 for p in b["params"]:       # parameters without a gradient this iteration contribute zeros
@@ -147,7 +155,14 @@ class GradAllReducer:
                             view.copy_(p.grad)
                         p.grad = view
                 self._launch(b)
-        for b in self.buckets:
+        # Parameters that received no gradient in this iteration (PSPNet(use_aux=False).auxiliary_branch, heads outside the
+        # executed path): the reference leaves their .grad None, so torch.optim.SGD skips them — no weight decay, no momentum
+        # update.  Their bucket slots take part in the reduction as zeros (all ranks agree); the view is hidden from the
+        # optimizer until zero_grad() re-attaches it for the next iteration.
+        for p in self.params:
+            if id(p) not in self._fired:
+                p.grad = None
+        for i, b in enumerate(self.buckets):
             w = b["work"]
             if w is not None:
                 w.wait()                      # nccl: current stream waits for the collective's stream
@@ -155,6 +170,15 @@ class GradAllReducer:
                     b["buf"].div_(self.world)
                 b["work"] = None
             b["pending"], b["launched"] = len(b["params"]), False
+            if optimizer is not None:
+                optimizer.step_segment(i)
+        if optimizer is not None:
+            for i in range(len(self.buckets), optimizer.num_segments):
+                optimizer.step_segment(i)     # parameters the reducer does not own (none for a whole-model reducer)
+
+    def segments(self):
+        """Parameter lists per bucket, in completion order — the layout `segmi.optim.SGD.set_segments` wants."""
+        return [list(b["params"]) for b in self.buckets]
 
     def remove(self):
         for h in self._hooks:
@@ -230,5 +254,15 @@ class DistributedModel(torch.nn.Module):
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
 
-    def finish_gradients(self):
-        self.reducer.finish()
+    def finish_gradients(self, optimizer=None):
+        """Wait for the gradient all-reduces; with `optimizer` (a segmi.optim.SGD prepared by `attach_optimizer`) also apply
+        the update bucket by bucket — the caller then must NOT call optimizer.step() for this iteration."""
+        self.reducer.finish(optimizer)
+
+    def attach_optimizer(self, optimizer):
+        """Lay a segmi.optim.SGD out per gradient bucket so that finish_gradients(optimizer) can step each bucket as soon as its
+        all-reduce is done.  Returns True when the optimizer supports it (other optimizers keep the plain step())."""
+        if hasattr(optimizer, "set_segments"):
+            optimizer.set_segments(self.reducer.segments())
+            return True
+        return False

@@ -18,7 +18,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_dropout_epoch",
 ]
 
 
@@ -724,8 +724,24 @@ class _BilinearFn(torch.autograd.Function):
 
 
 def interpolate_bilinear(x, size, align_corners=False):
-    """F.interpolate(x, size=size, mode='bilinear', align_corners=align_corners)."""
-    return _BilinearFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=align_corners).
+
+    The result remembers what it was interpolated from (`_segmi_src`): a loss that receives it untouched can evaluate itself
+    on the LOW-resolution tensor with the interpolation folded into its kernel (`upsampled_cross_entropy`), so the
+    full-resolution logits are written once for the caller (the drop-in contract: trainer.py:63-65 checks their size, metrics
+    read them) but never read by the loss, and their gradient never exists."""
+    y = _BilinearFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+    if x.dim() == 4 and x.shape[1] <= 256 and (int(size[0]) > x.shape[2] or int(size[1]) > x.shape[3]):
+        y._segmi_src = (x, bool(align_corners), y._version)
+    return y
+
+
+def upsample_source(t):
+    """(low-resolution tensor, align_corners) if `t` is an unmodified result of interpolate_bilinear, else None."""
+    src = getattr(t, "_segmi_src", None)
+    if src is None or t._version != src[2]:
+        return None
+    return src[0], src[1]
 
 
 # --------------------------------------------------------------------------- concat / dropout
@@ -836,22 +852,32 @@ def _class_weight(weight, C, dev, what):
 
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index, weight, reduction, group):
+    def forward(ctx, logits, target, ignore_index, weight, reduction, group, up):
+        # up = None: logits are at the target's resolution.  up = align_corners flag: logits are LOW resolution and the loss is
+        # that of their bilinear upsampling to the target's size (interpolation fused into the kernels)
         logits = to_nhwc(logits, "cross_entropy")
         N, C, H, W = logits.shape
         if target.dtype != torch.int64 or not target.is_cuda:
             raise SegmiError("cross_entropy: target must be an int64 CUDA tensor")
-        if tuple(target.shape) != (N, H, W):
+        if target.dim() != 3 or target.shape[0] != N or (up is None and tuple(target.shape) != (N, H, W)):
             raise SegmiError("cross_entropy: target shape %s does not match logits %s" % (tuple(target.shape), tuple(logits.shape)))
         target = target.contiguous()
-        rows, dev, st = N * H * W, logits.device, _stream()
+        OH, OW = int(target.shape[1]), int(target.shape[2])
+        rows, dev, st = N * OH * OW, logits.device, _stream()
         cw = _class_weight(weight, C, dev, "cross_entropy")
         lse = torch.empty(rows, device=dev, dtype=torch.float32)
         out = torch.empty(3, device=dev, dtype=torch.float32)  # {mean, denominator, numerator}
-        nws = lib.segmi_ce_workspace(rows)
-        ws = workspace(nws, dev)
-        check(lib.segmi_ce_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index,
-                               cw.data_ptr() if cw is not None else None, lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "ce_fwd")
+        if up is None:
+            nws = lib.segmi_ce_workspace(rows)
+            ws = workspace(nws, dev)
+            check(lib.segmi_ce_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index,
+                                   cw.data_ptr() if cw is not None else None, lse.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st), "ce_fwd")
+        else:
+            nws = lib.segmi_upsample_ce_workspace(N, H, W, C, OH, OW)
+            ws = workspace(nws, dev)
+            check(lib.segmi_upsample_ce_fwd(logits.data_ptr(), ld_of(logits), N, H, W, C, OH, OW, 1 if up else 0, target.data_ptr(),
+                                            ignore_index, cw.data_ptr() if cw is not None else None, lse.data_ptr(), out.data_ptr(),
+                                            ws.data_ptr(), nws, st), "upsample_ce_fwd")
         pg, world = _dist_world(group)
         if reduction == "sum":
             norm = torch.ones(3, device=dev, dtype=torch.float32)     # bwd divides by norm[1] = 1
@@ -867,6 +893,7 @@ class _CrossEntropyFn(torch.autograd.Function):
             norm, value = out, out[0]
         ctx.save_for_backward(logits, target, lse, norm, cw)
         ctx.ignore_index = ignore_index
+        ctx.up = up
         return value
 
     @staticmethod
@@ -875,17 +902,35 @@ class _CrossEntropyFn(torch.autograd.Function):
         N, C, H, W = logits.shape
         g = g.contiguous().float()
         dl = empty_nhwc(N, C, H, W, logits.device)
-        check(lib.segmi_ce_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C,
-                               ctx.ignore_index, cw.data_ptr() if cw is not None else None, norm.data_ptr(), g.data_ptr(),
-                               dl.data_ptr(), ld_of(dl), _stream()), "ce_bwd")
-        return dl, None, None, None, None, None
+        if ctx.up is None:
+            check(lib.segmi_ce_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), lse.data_ptr(), N * H * W, C,
+                                   ctx.ignore_index, cw.data_ptr() if cw is not None else None, norm.data_ptr(), g.data_ptr(),
+                                   dl.data_ptr(), ld_of(dl), _stream()), "ce_bwd")
+        else:
+            OH, OW = int(target.shape[1]), int(target.shape[2])
+            nws = lib.segmi_upsample_ce_workspace(N, H, W, C, OH, OW)
+            ws = workspace(nws + 16, logits.device)
+            wp = (ws.data_ptr() + 15) & ~15
+            check(lib.segmi_upsample_ce_bwd(logits.data_ptr(), ld_of(logits), N, H, W, C, OH, OW, 1 if ctx.up else 0, target.data_ptr(),
+                                            lse.data_ptr(), ctx.ignore_index, cw.data_ptr() if cw is not None else None, norm.data_ptr(),
+                                            g.data_ptr(), dl.data_ptr(), ld_of(dl), wp, nws, _stream()), "upsample_ce_bwd")
+        return dl, None, None, None, None, None, None
 
 
 def cross_entropy(logits, target, ignore_index=255, weight=None, reduction="mean", group=None):
     """nn.CrossEntropyLoss(weight=..., ignore_index=..., reduction='mean'|'sum') on [N,C,H,W] logits / [N,H,W] int64 target."""
     if reduction not in ("mean", "sum"):
         raise SegmiError("cross_entropy: reduction must be 'mean' or 'sum' (got %r)" % (reduction,))
-    return _CrossEntropyFn.apply(logits, target, int(ignore_index), weight, reduction, group)
+    return _CrossEntropyFn.apply(logits, target, int(ignore_index), weight, reduction, group, None)
+
+
+def upsampled_cross_entropy(logits_lo, target, align_corners=False, ignore_index=255, weight=None, reduction="mean", group=None):
+    """cross_entropy(F.interpolate(logits_lo, size=target.shape[1:], mode='bilinear', align_corners=...), target, ...) with the
+    interpolation evaluated inside the loss kernels: no [N,C,H,W] logits, no [N,C,H,W] gradient (include/segmi.h
+    segmi_upsample_ce_fwd / _bwd)."""
+    if reduction not in ("mean", "sum"):
+        raise SegmiError("cross_entropy: reduction must be 'mean' or 'sum' (got %r)" % (reduction,))
+    return _CrossEntropyFn.apply(logits_lo, target, int(ignore_index), weight, reduction, group, bool(align_corners))
 
 
 def _loss_inputs(logits, target, what):

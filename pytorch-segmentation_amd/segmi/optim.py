@@ -4,7 +4,8 @@
 config.json (`base/base_trainer.py:57` `get_instance(torch.optim, 'optimizer', config, trainable_params)`), including parameter
 groups with their own lr (differential learning rates).  One kernel launch updates every parameter (`segmi_sgd_step`) instead
 of torch's three foreach passes.  State layout (`state[p]['momentum_buffer']`) matches torch.optim.SGD, so optimizer
-state_dicts interchange with checkpoints written by the reference.
+state_dicts interchange with checkpoints written by the reference (buffers that arrive contiguous-NCHW for a channels_last
+filter are re-laid in the parameter's memory order on the first step).
 """
 import ctypes as C
 
@@ -40,6 +41,8 @@ class SGD(torch.optim.Optimizer):
             raise ValueError("segmi.optim.SGD supports up to 8 parameter groups")
         self._table = None
         self._sig = None
+        self._segments = None          # optional: parameter lists whose chunks are contiguous in the table (gradient buckets)
+        self._seg_ranges = []
         self.capturable = bool(capturable)
         self._ring = self._ring_events = self._hyper_dev = None
         self._ring_pos = 0
@@ -68,27 +71,61 @@ class SGD(torch.optim.Optimizer):
         ev.record()
         self._ring_events[i] = ev
 
+    def set_segments(self, segments):
+        """Lay the chunk table out segment by segment (`segments`: lists of parameters, e.g. the gradient buckets of
+        segmi.distributed.GradAllReducer in the order their all-reduces complete) so that `step_segment(i)` can update one
+        bucket's parameters as soon as ITS all-reduce has finished, while later buckets are still on the wire
+        (reference: one optimizer.step() after the whole gather, base/base_trainer.py:46-57 + trainer.py:70-71)."""
+        self._segments = [list(seg) for seg in segments]
+        self._sig = None
+
+    def _ordered(self):
+        """[(group index, param)] in table order, and the segment boundaries (in parameters)."""
+        gi_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        if not self._segments:
+            return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g["params"]], None
+        seen, order, bounds = set(), [], []
+        for seg in self._segments:
+            start = len(order)
+            for p in seg:
+                if id(p) in gi_of and id(p) not in seen:
+                    seen.add(id(p))
+                    order.append((gi_of[id(p)], p))
+            bounds.append((start, len(order)))
+        start = len(order)
+        order += [(gi, p) for gi, g in enumerate(self.param_groups) for p in g["params"] if id(p) not in seen]
+        bounds.append((start, len(order)))          # parameters outside every segment: a last segment of their own
+        return order, bounds
+
     def _build(self):
         """Chunk table on the device; rebuilt only if a gradient / parameter / buffer pointer changed."""
         ce = lib.segmi_sgd_chunk_elems()
         entries, sig = [], []
-        for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
-                    st["momentum_buffer"] = torch.zeros(p.numel(), dtype=p.dtype, device=p.device).as_strided(p.shape, p.stride())
-                buf, g = st["momentum_buffer"], p.grad
-                if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and _same_layout(g, p) and _same_layout(buf, p)):
-                    raise RuntimeError("segmi.optim.SGD: parameter, gradient and momentum buffer must be float32 CUDA tensors with "
-                                       "identical (dense) strides")
-                n = p.numel()
-                sig.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, gi))
-                for off in range(0, n, ce):
-                    cnt = min(ce, n - off)
-                    ptrs = [t.data_ptr() + 4 * off for t in (p, g, buf)]
-                    entries.append((ptrs[0], ptrs[1], ptrs[2], cnt, gi, int(cnt % 4 == 0 and all(q % 16 == 0 for q in ptrs))))
+        order, bounds = self._ordered()
+        first_chunk = []                 # chunk index at which parameter i of `order` starts
+        for gi, p in order:
+            first_chunk.append(len(entries))
+            if p.grad is None:
+                continue
+            st = self.state[p]
+            if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                st["momentum_buffer"] = torch.zeros(p.numel(), dtype=p.dtype, device=p.device).as_strided(p.shape, p.stride())
+            buf, g = st["momentum_buffer"], p.grad
+            if buf.shape == p.shape and (not _same_layout(buf, p) or buf.device != p.device or buf.dtype != p.dtype):
+                # a state_dict written by the reference (or by torch.optim.SGD) holds contiguous NCHW momentum buffers, while
+                # k > 1 filters live channels_last here (KRSC in memory): re-lay the buffer once in the parameter's own layout
+                fixed = torch.empty_like(p)           # preserve_format: the parameter's (dense, permuted) strides
+                fixed.copy_(buf)
+                buf = st["momentum_buffer"] = fixed
+            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and _same_layout(g, p) and _same_layout(buf, p)):
+                raise RuntimeError("segmi.optim.SGD: parameter, gradient and momentum buffer must be float32 CUDA tensors with "
+                                   "identical (dense) strides")
+            n = p.numel()
+            sig.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, gi))
+            for off in range(0, n, ce):
+                cnt = min(ce, n - off)
+                ptrs = [t.data_ptr() + 4 * off for t in (p, g, buf)]
+                entries.append((ptrs[0], ptrs[1], ptrs[2], cnt, gi, int(cnt % 4 == 0 and all(q % 16 == 0 for q in ptrs))))
         sig = tuple(sig)
         if sig != self._sig:
             if torch.cuda.is_current_stream_capturing():
@@ -101,6 +138,22 @@ class SGD(torch.optim.Optimizer):
             self._table = host.to(self.param_groups[0]["params"][0].device)
             self._n = len(entries)
             self._sig = sig
+            first_chunk.append(len(entries))
+            self._seg_ranges = [(first_chunk[a], first_chunk[b] - first_chunk[a]) for a, b in bounds] if bounds else [(0, len(entries))]
+
+    @torch.no_grad()
+    def step_segment(self, i):
+        """Update the parameters of segment i only (see set_segments); a full iteration calls it once per segment, plus once
+        for index len(segments) (parameters outside every segment)."""
+        if i == 0 or self._table is None:
+            self._build()                     # once per iteration: pointer signature check (rebuilds only if something moved)
+        start, count = self._seg_ranges[i]
+        if count:
+            self._launch(start, count)
+
+    @property
+    def num_segments(self):
+        return len(self._segments) + 1 if self._segments else 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -111,12 +164,18 @@ class SGD(torch.optim.Optimizer):
         self._build()
         if not self._n:
             return loss
+        self._launch(0, self._n)
+        return loss
+
+    def _launch(self, start, count):
+        loss = None
+        table = self._table.data_ptr() + start * C.sizeof(_Chunk)
         if self.capturable:
             if not torch.cuda.is_current_stream_capturing():
                 self.push_hyper()                  # eager step: always current.  Captured step: the caller pushes before each replay
             elif self._hyper_dev is None:
                 raise RuntimeError("segmi.optim.SGD(capturable=True): run one eager step (or push_hyper()) before capturing")
-            check(lib.segmi_sgd_step_dev(self._table.data_ptr(), self._n, self._hyper_dev.data_ptr(),
+            check(lib.segmi_sgd_step_dev(table, count, self._hyper_dev.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream), "sgd_step_dev")
             return loss
         ng = len(self.param_groups)
@@ -124,6 +183,6 @@ class SGD(torch.optim.Optimizer):
         lr = f(*[float(g["lr"]) for g in self.param_groups])
         wd = f(*[float(g["weight_decay"]) for g in self.param_groups])
         mom = f(*[float(g["momentum"]) for g in self.param_groups])
-        check(lib.segmi_sgd_step(self._table.data_ptr(), self._n, C.addressof(lr), C.addressof(wd), C.addressof(mom), ng,
+        check(lib.segmi_sgd_step(table, count, C.addressof(lr), C.addressof(wd), C.addressof(mom), ng,
                                  torch.cuda.current_stream().cuda_stream), "sgd_step")
         return loss

@@ -27,7 +27,6 @@ class Trainer(BaseTrainer):
         self.metrics = SegMetrics(self.num_classes, self.device)
         self.psp = self.config["arch"]["type"][:3] == "PSP"
         self.iteration_losses = []
-        self._graphed = None             # (GraphedStep, static data, static target) once captured (trainer.hip_graph)
         # side-stream H2D staging of the next batch (reference trainer.py:30-33); loaders that already yield device tensors pass through
         if prefetch and self.device.type == "cuda":
             self.train_loader = DataPrefetcher(self.train_loader, device=self.device)
@@ -47,35 +46,6 @@ class Trainer(BaseTrainer):
             loss = self.loss(output, target)
         return output, loss
 
-    def _graph_step(self, data, target):
-        """trainer.hip_graph: the step of `_train_epoch` replayed from a hipGraph on static input buffers.  Batches whose shape
-        differs from the captured one (a ragged last batch) run eagerly.  The outputs of a replay live in the graph's static
-        buffers and are overwritten by the next replay, so the values handed back are clones (the loss; the logits only feed
-        the device-side metric counters of this iteration)."""
-        from segmi.graph import GraphedStep
-
-        def eager(d, t):
-            self.model.zero_grad()
-            output, loss = self._forward_loss(d, t)
-            loss.backward()
-            self.model.finish_gradients()
-            self.optimizer.step()
-            return output, loss
-
-        if self._graphed is None:
-            out = eager(data, target)          # this iteration's real step, eagerly (allocations, SGD table, hyper-parameters)
-            sd, st = data.clone(), target.clone()
-            gs = GraphedStep(lambda: eager(sd, st), warmup=0, pre_replay=self.optimizer.push_hyper)   # capture only: executes nothing
-            self._graphed = (gs, sd, st)
-            return out
-        gs, sd, st = self._graphed
-        if data.shape != sd.shape or target.shape != st.shape:
-            return eager(data, target)
-        sd.copy_(data, non_blocking=True)
-        st.copy_(target, non_blocking=True)
-        output, loss = gs()
-        return output, loss.detach().clone()
-
     def _train_epoch(self, epoch):
         self.model.train()
         if self.config["arch"]["args"].get("freeze_bn"):
@@ -91,12 +61,12 @@ class Trainer(BaseTrainer):
             data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
             self.lr_scheduler.step(epoch=epoch - 1)
 
-            if self.use_graph:
-                output, loss = self._graph_step(data, target)
+            self.model.zero_grad()
+            output, loss = self._forward_loss(data, target)
+            loss.backward()
+            if self.bucket_step:
+                self.model.finish_gradients(self.optimizer)       # all-reduce wait + fused SGD, bucket by bucket
             else:
-                self.model.zero_grad()
-                output, loss = self._forward_loss(data, target)
-                loss.backward()
                 self.model.finish_gradients()
                 self.optimizer.step()
 
@@ -117,8 +87,8 @@ class Trainer(BaseTrainer):
                     epoch, batch_idx, len(self.train_loader), avg, s["Pixel_Accuracy"], s["Mean_IoU"],
                     self.batch_time.average, self.data_time.average))
 
-        self.total_loss.update(float(loss_sum) / max(n_iter, 1), n_iter)
-        seg_metrics = self.metrics.summary()
+        self.total_loss.update(self._epoch_mean(loss_sum, n_iter), n_iter)
+        seg_metrics = self.metrics.all_reduce().summary()     # global-batch counters: identical results on every rank
         for k, v in list(seg_metrics.items())[:-1]:
             self.writer.add_scalar("%s/%s" % (self.wrt_mode, k), v, self.wrt_step)
         for i, g in enumerate(self.optimizer.param_groups):
@@ -142,13 +112,23 @@ class Trainer(BaseTrainer):
                 loss_sum += self.loss(output, target)
                 self.metrics.update(output, target)
                 n_iter += 1
-        self.total_loss.update(float(loss_sum) / max(n_iter, 1), n_iter)
+        self.total_loss.update(self._epoch_mean(loss_sum, n_iter), n_iter)
         self.wrt_step = epoch * len(self.val_loader)
         self.writer.add_scalar("%s/loss" % self.wrt_mode, self.total_loss.average, self.wrt_step)
-        seg_metrics = self.metrics.summary()
+        seg_metrics = self.metrics.all_reduce().summary()
         for k, v in list(seg_metrics.items())[:-1]:
             self.writer.add_scalar("%s/%s" % (self.wrt_mode, k), v, self.wrt_step)
         return {"val_loss": self.total_loss.average, **seg_metrics}
+
+    def _epoch_mean(self, loss_sum, n_iter):
+        """Mean per-iteration loss of the epoch over ALL ranks (every rank must take the same monitor / early-stop decision
+        in BaseTrainer.train, otherwise one of them leaves the loop and the others hang in the next collective).  The per-rank
+        losses already carry the global-batch weighting (utils/losses.py), so their average is the global-batch loss."""
+        t = torch.stack([loss_sum.detach().double().reshape(()), torch.tensor(float(n_iter), dtype=torch.float64, device=loss_sum.device)])
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t)
+        return float(t[0]) / max(float(t[1]), 1.0)
 
     def _reset_metrics(self):
         self.batch_time = AverageMeter()

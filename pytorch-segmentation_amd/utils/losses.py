@@ -21,8 +21,9 @@ class CrossEntropyLoss2d(nn.Module):
     fused log-softmax + NLL pass; backward recomputes softmax from the saved log-sum-exp.
     weight: per-class rescaling (weighted mean = sum w_t l / sum w_t over valid pixels); reduction 'mean' | 'sum'."""
 
-    def __init__(self, weight=None, ignore_index=255, reduction="mean", process_group="auto"):
+    def __init__(self, weight=None, ignore_index=255, reduction="mean", process_group="auto", fuse_upsample=True):
         super().__init__()
+        self.fuse_upsample = bool(fuse_upsample)
         if reduction not in ("mean", "sum"):
             raise NotImplementedError("reduction=%r: the fused CE kernel reduces on the device ('mean' | 'sum'); the reference's "
                                       "trainer needs a scalar (trainer.py:66-70)" % (reduction,))
@@ -32,6 +33,13 @@ class CrossEntropyLoss2d(nn.Module):
         self.process_group = process_group
 
     def forward(self, output, target):
+        src = ops.upsample_source(output) if self.fuse_upsample else None
+        if src is not None and tuple(output.shape[2:]) == tuple(target.shape[1:]):
+            # `output` is the model's final F.interpolate of low-resolution logits, untouched (models/pspnet.py:85-91,
+            # models/deeplabv3_plus.py:361): evaluate the loss on the low-resolution tensor with the interpolation inside the
+            # kernel — same value and gradient, without reading the full-resolution logits or creating their gradient
+            return ops.upsampled_cross_entropy(src[0], target, src[1], self.ignore_index, self.weight, self.reduction,
+                                               _group(self.process_group))
         return ops.cross_entropy(output, target, self.ignore_index, self.weight, self.reduction, _group(self.process_group))
 
 

@@ -49,6 +49,16 @@ class SegMetrics:
     def update(self, output, target):
         ops.seg_metrics_accumulate(output, target, self.acc)
 
+    def all_reduce(self, group=None):
+        """Sum the counters over all ranks of a data-parallel job (exact: int64), so that every rank derives the SAME epoch
+        metrics — and therefore takes the same monitor / early-stop / checkpoint decision — from the global batch, as the
+        reference does on its gathered outputs (trainer.py:84-86).  A collective: call it on every rank.  Returns a summed COPY
+        semantics-wise by reducing in place; call once per epoch, after the last update."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.acc, group=group)
+        return self
+
     def counts(self):
         """(correct, labeled, inter[C], union[C]) as numpy — synchronises."""
         a = self.acc.cpu().numpy()

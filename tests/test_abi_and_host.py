@@ -262,3 +262,18 @@ def test_every_cfg2_conv_layer_dispatches_to_an_lds_dma_kernel():
             assert names[0].startswith("conv_dma_kernel<128, 128"), names[0]
         if K <= 32:
             assert names[0].startswith("conv_dma_kernel<128, 32"), names[0]
+
+
+def test_synth_loader_shards_batches_by_rank():
+    """Data parallelism: rank r of W draws global batch i*W + r at iteration i, so the W ranks of a job train on W different
+    batches per step (every rank used to see the same data) and together cover exactly the single-process sequence."""
+    from dataloaders import Synth
+    kw = dict(num_classes=3, batch_size=2, height=32, width=32, iters=3, seed=5)
+    single = [b for b in Synth(iters=6, **{k: v for k, v in kw.items() if k != "iters"})]
+    r0 = [b for b in Synth(rank=0, world=2, **kw)]
+    r1 = [b for b in Synth(rank=1, world=2, **kw)]
+    assert len(r0) == len(r1) == 3
+    for i in range(3):
+        assert not torch.equal(r0[i][0], r1[i][0])
+        assert torch.equal(r0[i][0], single[2 * i][0]) and torch.equal(r1[i][1], single[2 * i + 1][1])
+    assert Synth(**kw).world == 1 and Synth(**kw).rank == 0          # no process group: the whole sequence

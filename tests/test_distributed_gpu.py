@@ -210,6 +210,24 @@ def _nccl_worker(rank, world, port, ret):
         red.remove()
         net(x).square().mean().backward()
         ok = all(torch.allclose(got[k], p.grad, rtol=1e-6, atol=1e-8) for k, p in net.named_parameters())
+        # fused SGD launched per bucket right after the bucket's all-reduce (finish(optimizer)) == one torch.optim.SGD step after all
+        import copy
+        from segmi.optim import SGD
+        net2, netr = copy.deepcopy(net), copy.deepcopy(net)
+        red2 = GradAllReducer(net2.parameters(), bucket_bytes=16 << 10, always_reduce=True)
+        opt2 = SGD(net2.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        opt2.set_segments(red2.segments())
+        optr = torch.optim.SGD(netr.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        for it in range(3):
+            xb = torch.randn(32, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+            red2.zero_grad()
+            net2(xb).square().mean().backward()
+            red2.finish(opt2)
+            optr.zero_grad()
+            netr(xb).square().mean().backward()
+            optr.step()
+        seg_ok = len(red2.buckets) >= 2 and opt2.num_segments == len(red2.buckets) + 1 and all(
+            torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(net2.parameters(), netr.parameters()))
         ctx = SyncBNContext()
         part = torch.arange(12.0, device=dev)
         parts, n = ctx.gather_stats(part)
@@ -217,7 +235,7 @@ def _nccl_worker(rank, world, port, ret):
         t = torch.ones(3, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         torch.cuda.synchronize()
-        ret[rank] = {"ok": ok, "nb": len(red.buckets), "gather": n}
+        ret[rank] = {"ok": ok, "nb": len(red.buckets), "gather": n, "seg_ok": seg_ok}
     finally:
         dist.destroy_process_group()
 
@@ -229,4 +247,41 @@ def test_rccl_call_path_single_rank(cuda):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
-    assert ret[0]["ok"] and ret[0]["nb"] >= 2 and ret[0]["gather"] == 1
+    assert ret[0]["ok"] and ret[0]["nb"] >= 2 and ret[0]["gather"] == 1 and ret[0]["seg_ok"]
+
+
+def _trainer_worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "pytorch-segmentation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        import train
+        config = json.load(open(os.path.join(ROOT, "pytorch-segmentation_amd", "config.json")))
+        config["train_loader"]["args"].update(height=96, width=96, iters=3)
+        config["val_loader"]["args"].update(height=96, width=96, iters=2)
+        config["trainer"].update(save_dir=os.path.join(tmp, "ck"), log_dir=os.path.join(tmp, "log"), epochs=2, save_period=2)
+        seen = []
+        tr = train.main(config, None)
+        first = next(iter(tr.train_loader))[0]
+        ret[rank] = {"first": first.float().cpu().sum().item(), "losses": [float(v) for v in tr.iteration_losses],
+                     "best": float(tr.mnt_best), "total_loss": float(tr.total_loss.average),
+                     "summary": {k: float(v) for k, v in list(tr.metrics.summary().items())[:2]},
+                     "w": tr.model.state_dict()["module.final_conv.bias"].cpu().clone(), "ckpt": os.path.isdir(tr.checkpoint_dir) and rank == 0}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trainer_shards_data_and_agrees_on_epoch_results(cuda, tmp_path):
+    """`train.main` on two ranks (sharing cuda:0; gloo on device tensors): every rank trains on ITS shard of each global step
+    (different batches), the monitored epoch results — loss, metrics, best value — are identical on all ranks (all-reduced
+    counters), so both take the same early-stop / checkpoint decisions, and the replicas stay bit-identical."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["first"] != b["first"] and a["losses"] != b["losses"]            # different shards
+    assert a["best"] == b["best"] and a["total_loss"] == b["total_loss"] and a["summary"] == b["summary"]
+    assert torch.equal(a["w"], b["w"])

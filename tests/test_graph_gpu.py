@@ -1,13 +1,12 @@
 """GPU: hipGraph capture of a training step (segmi/graph.py) and the device-side dropout epoch that makes it valid.
 
-OPT-IN until its first run on hardware (written after the round's GPU budget was spent): SEGMI_TEST_GRAPH=1."""
-import os
-
+First run on hardware: round 2.  Replays equal eager steps bit for bit; measured benefit on one GPU: none on cfg2 (88.8 vs 89.0
+img/s) and 1 % on the launch-heavy cfg1 (209 vs 206.5 img/s) — the GPU, not the host, paces these steps — so GraphedStep stays an
+opt-in tool (bench.py --graph) and the trainer integration of round 1 was removed."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SEGMI_TEST_GRAPH", "0") != "1", reason="opt-in: SEGMI_TEST_GRAPH=1")]
+pytestmark = pytest.mark.gpu
 
 
 def test_dropout_epoch_changes_masks_and_backward_regenerates_them(cuda):
@@ -133,34 +132,3 @@ def test_capturable_sgd_follows_the_lr_schedule_inside_a_graph(cuda):
     assert torch.equal(run(True, False), ref)           # device-resident hyper-parameters, eager
     got = run(True, True)                                # ... and replayed from a graph
     assert torch.equal(got, ref), (got - ref).abs().max().item()
-
-
-def test_trainer_with_hip_graph_matches_the_eager_trainer(cuda, tmp_path):
-    """config trainer.hip_graph = true: same 4-iteration UNet trajectory (Poly lr changes every iteration) as the eager
-    re-hosted Trainer, bit for bit (UNet has no dropout; every kernel is deterministic)."""
-    import json
-    import dataloaders
-    import models
-    from oracle.weights import synth_state_dict
-    from trainer import Trainer
-    from utils.losses import CrossEntropyLoss2d
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    rec = torch.load(os.path.join(ROOT, "tests", "golden", "trainer_unet.pt"), weights_only=False)
-
-    def run(graph):
-        config = json.loads(json.dumps(rec["config"]))
-        config["trainer"].update(save_dir=str(tmp_path / ("g" if graph else "e")), log_dir=str(tmp_path), save_period=10, hip_graph=graph)
-        loader = dataloaders.Synth(**config["train_loader"]["args"])
-        model = models.UNet(loader.dataset.num_classes, **config["arch"]["args"])
-        model.load_state_dict(synth_state_dict(rec["manifest"], seed=11))
-        tr = Trainer(model=model, loss=CrossEntropyLoss2d(ignore_index=config["ignore_index"]), resume=None, config=config,
-                     train_loader=loader, val_loader=None)
-        tr.train()
-        return [float(v) for v in tr.iteration_losses], tr.metrics.counts(), {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
-
-    le, ce, se = run(False)
-    lg, cg, sg = run(True)
-    assert le == lg, (le, lg)
-    assert float(ce[0]) == float(cg[0]) and float(ce[1]) == float(cg[1])
-    for k in se:
-        assert torch.equal(se[k], sg[k]), k

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _close(a, b, rtol=1e-5, atol=1e-6, what=""):
@@ -332,7 +333,8 @@ def test_losses_match_reference_golden(cuda, lname):
         assert torch.equal(t.cpu(), ref["target_after"]), (lname, case)     # Dice rewrites ignored pixels in place, CE/Focal do not
 
 
-@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255)])
+@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255),
+                                  (2, 21, 256, 256, 255), (1, 150, 256, 256, -1)])      # multi-block sort / scan: 131 072 and 65 536 pixels
 def test_lovasz_softmax_vs_oracle(cuda, case):
     """Multi-chunk sizes (ranks span several 2048-element scan blocks), 150 classes with ignore=-1 (ADE20K style), absent
     classes; block-constant masks so that errors are well separated (per-pixel gradients inside bit-equal tie groups are
@@ -396,6 +398,97 @@ def test_fused_sgd_matches_torch_sgd(cuda):
             assert torch.allclose(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"], rtol=1e-6, atol=2e-6), (step, i)
     # state layout interchangeable with torch.optim.SGD
     ob.load_state_dict(oa.state_dict())
+
+
+def test_fused_sgd_resumes_from_a_reference_written_state_dict(cuda):
+    """A checkpoint written by the reference holds CONTIGUOUS (NCHW) momentum buffers; k > 1 filters live channels_last here.
+    Optimizer.load_state_dict keeps the loaded strides, so the first fused step must re-lay the buffer (it used to raise
+    "identical (dense) strides") and then continue exactly like torch.optim.SGD resumed from the same state."""
+    from segmi.optim import SGD
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(32, 16, 3, 3, generator=g)
+    mom = torch.randn(32, 16, 3, 3, generator=g)                      # contiguous, as torch.save of a reference run stores it
+    grad = torch.randn(32, 16, 3, 3, generator=g)
+    state = {"state": {0: {"momentum_buffer": mom.clone()}},
+             "param_groups": [{"lr": 0.01, "momentum": 0.9, "dampening": 0, "weight_decay": 1e-4, "nesterov": False, "params": [0]}]}
+    pa = torch.nn.Parameter(w0.to(cuda).contiguous(memory_format=torch.channels_last))
+    pb = torch.nn.Parameter(w0.to(cuda))
+    oa = SGD([pa], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD([pb], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    oa.load_state_dict(state)
+    ob.load_state_dict({"state": {0: {"momentum_buffer": mom.clone()}}, "param_groups": [dict(ob.state_dict()["param_groups"][0])]})
+    for _ in range(2):
+        pa.grad = grad.to(cuda).contiguous(memory_format=torch.channels_last)
+        pb.grad = grad.to(cuda)
+        oa.step()
+        ob.step()
+    assert oa.state[pa]["momentum_buffer"].stride() == pa.stride()
+    assert torch.allclose(pa.detach(), pb.detach(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(oa.state[pa]["momentum_buffer"], ob.state[pb]["momentum_buffer"], rtol=1e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("lname", ["CrossEntropyLoss2d", "FocalLoss", "CE_DiceLoss"])
+def test_class_weighted_losses_match_torch(cuda, lname):
+    """Loss constructor surface of the reference (utils/losses.py:24-28,52-57,67-72): class `weight=` for CrossEntropy (weighted
+    mean = sum w_t l / sum w_t over valid pixels), `alpha=` for Focal (weights of the inner reduce=False CrossEntropy), both
+    reductions; value and gradient against the reference's own expressions evaluated by torch on CPU."""
+    import utils.losses as L
+    g = torch.Generator().manual_seed(8)
+    N, C, H, W = 2, 7, 9, 11
+    x = torch.randn(N, C, H, W, generator=g) * 2
+    t = torch.randint(0, C, (N, H, W), generator=g)
+    t[:, 0] = 255
+    w = torch.rand(C, generator=g) + 0.25
+    for kw in ({}, {"reduction": "sum"} if lname != "FocalLoss" else {"size_average": False}):
+        xr = x.clone().requires_grad_(True)
+        if lname == "CrossEntropyLoss2d":
+            ref = F.cross_entropy(xr, t, weight=w, ignore_index=255, **kw)
+            crit = L.CrossEntropyLoss2d(weight=w, ignore_index=255, **kw)
+        elif lname == "FocalLoss":
+            logpt = F.cross_entropy(xr, t, weight=w, ignore_index=255, reduction="none")
+            fl = ((1 - torch.exp(-logpt)) ** 2) * logpt
+            ref = fl.mean() if not kw else fl.sum()
+            crit = L.FocalLoss(gamma=2, alpha=w, ignore_index=255, **kw)
+        else:
+            from oracle import losses_ref
+            ref = F.cross_entropy(xr, t, weight=w, ignore_index=255, **kw) + losses_ref.dice(xr, t.clone(), 255)
+            crit = L.CE_DiceLoss(weight=w, ignore_index=255, **kw)
+        ref.backward()
+        xd = x.to(cuda).requires_grad_(True)
+        val = crit.to(cuda)(xd, t.clone().to(cuda))
+        val.backward()
+        assert torch.allclose(val.cpu(), ref.detach(), rtol=1e-5, atol=1e-6), (lname, kw, val.item(), ref.item())
+        scale = xr.grad.abs().max().item()
+        assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-5 * scale + 1e-9, (lname, kw)
+
+
+def test_conv_register_staged_fallback_kernels(cuda):
+    """The register-staged kernels (conv_gather_kernel / conv_wgrad_kernel: operands >= 4 GiB, or SEGMI_CONV_DMA=0) compute the
+    same convolution as the LDS-DMA path; run in a subprocess because the switch is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.join(%r, "pytorch-segmentation_amd"))
+from segmi import ops
+from segmi._lib import ConvDesc
+d = ConvDesc(2, 20, 24, 64, 128, 3, 3, 20, 24, 1, 2, 2, 64, 128)
+assert ops.conv_variant(d, 0).startswith("conv_gather_kernel"), ops.conv_variant(d, 0)
+dev = torch.device("cuda:0")
+for (N, C, H, W, K, R, st, pad, dil) in [(2, 64, 20, 24, 128, 3, 1, 2, 2), (2, 36, 15, 15, 21, 1, 1, 0, 1), (2, 3, 33, 33, 64, 3, 2, 1, 1), (2, 64, 16, 16, 64, 3, 2, 1, 1)]:
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, st, pad, dil); gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, None, st, pad, dil); yd.backward(gy.to(dev))
+    for a, b in ((yd, yr), (xd.grad, xr.grad), (wd.grad, wr.grad)):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4 * b.abs().max().item(), (N, C, H, W, K, R)
+print("FALLBACK_OK")
+''' % ROOT
+    env = dict(os.environ, SEGMI_CONV_DMA="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, (1, 2, 3, 6)), (3, 20, 13, 17, (1, 2, 3, 6)), (2, 8, 12, 12, (1, 2, 3, 6)), (1, 36, 97, 97, (1, 2, 3, 6)),
@@ -490,8 +583,100 @@ def test_bn_stats_finalize_fused_equals_two_calls(cuda, shape):
             part = torch.empty(3 * C, device=cuda)
             assert lib.segmi_bn_stats(x.data_ptr(), ops.ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st) == 0
             assert lib.segmi_bn_finalize(part.data_ptr(), 1, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 0, rm.data_ptr(),
-                                         rv.data_ptr(), nbt.data_ptr(), *ptrs, st) == 0
+                                         rv.data_ptr(), nbt.data_ptr(), *ptrs, None, st) == 0
         outs.append((coef.clone(), rm, rv, nbt))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert int(outs[1][3].item()) == 1
+
+
+def test_syncbn_clamp_var_formula_matches_reference(cuda):
+    """SynchronizedBatchNorm2d(clamp_var=True) = the reference's GPU formula `_compute_mean_std`
+    (utils/sync_batchnorm/batchnorm.py:128-145): inv_std = clamp(biased var, eps)^-0.5 (NOT (var + eps)^-0.5), running stats
+    from the unbiased variance.  (a) segmi_bn_finalize(clamp_mode=1) on the SURVEY App. C vector recorded from the real class
+    (tests/golden/misc.pt); (b) the module forward against that formula in torch (backward only has to run), on data with a
+    channel whose variance is below eps (where the two formulas differ by sqrt(2) and more)."""
+    from segmi import lib
+    from segmi._lib import check
+    from utils.sync_batchnorm import SynchronizedBatchNorm2d
+    rec = torch.load(os.path.join(GOLD, "misc.pt"), weights_only=False)["syncbn_mean_std"]
+    n, s, ss = float(rec["n"]), rec["sum"].double(), rec["ssum"].double()
+    C = 4                                                             # kernels want C % 4 == 0: pad with two benign channels
+    mean = torch.cat([s / n, torch.zeros(2, dtype=torch.float64)])
+    m2 = torch.cat([ss - s * s / n, torch.ones(2, dtype=torch.float64)])
+    part = torch.cat([torch.full((C,), n, dtype=torch.float64), mean, m2]).float().to(cuda)
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    out = torch.empty(4 * C + 4, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.segmi_bn_finalize(part.data_ptr(), 1, C, None, None, 1e-5, 0.1, 1, rm.data_ptr(), rv.data_ptr(), None,
+                                out.data_ptr(), out.data_ptr() + 4 * C, out.data_ptr() + 8 * C, out.data_ptr() + 12 * C,
+                                out.data_ptr() + 16 * C, st), "bn_finalize")
+    o = out.cpu()
+    assert torch.allclose(o[0:2], rec["mean"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(o[C:C + 2], rec["inv_std"], rtol=1e-5, atol=0), (o[C:C + 2], rec["inv_std"])
+    assert torch.allclose(rm.cpu()[:2], rec["running_mean"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rv.cpu()[:2], rec["running_var"], rtol=1e-5, atol=1e-7)
+    assert float(o[4 * C]) == n                                       # the element count handed to the backward pass on the device
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 8, 6, 5, generator=g)
+    x[:, 1] = 0.25 + 3.2e-3 * torch.randn(3, 6, 5, generator=g)      # variance ~ eps = 1e-5: clamp(var, eps)^-0.5 vs (var + eps)^-0.5 = sqrt(2)
+    x[:, 5] = -2.0                                                    # zero variance
+    bn = SynchronizedBatchNorm2d(8, clamp_var=True).to(cuda).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 8))
+        bn.bias.copy_(torch.linspace(-0.2, 0.2, 8))
+    xd = x.to(cuda).requires_grad_(True)
+    y = bn(xd)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(cuda))
+    xr = x.double().requires_grad_(True)
+    cnt = x.numel() / 8
+    mu = xr.sum((0, 2, 3)) / cnt
+    bias_var = (xr * xr).sum((0, 2, 3)) / cnt - mu * mu
+    inv = bias_var.clamp(1e-5) ** -0.5
+    yr = (xr - mu[None, :, None, None]) * (inv * bn.weight.detach().cpu().double())[None, :, None, None] + bn.bias.detach().cpu().double()[None, :, None, None]
+    # the clamped channels multiply (x - mean) by clamp(var, eps)^-0.5 = 316: an fp32 mean that is off by 1e-7 shows as 3e-5
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=1e-4), (y.detach().cpu().double() - yr.detach()).abs().max()
+    plain = (bias_var.detach() + 1e-5) ** -0.5
+    assert float((inv.detach()[1] / plain[1])) > 1.3                  # the test data really separates the two formulas
+
+
+@pytest.mark.parametrize("case", [(2, 21, 16, 16, 128, 128, False, False), (1, 19, 13, 13, 97, 97, True, False), (2, 150, 9, 11, 36, 44, True, True),
+                                  (2, 5, 8, 8, 61, 50, False, True), (1, 3, 1, 1, 7, 7, True, False)])
+def test_cross_entropy_fused_with_final_upsample(cuda, case):
+    """the loss of the model's final F.interpolate(logits, size=input size) evaluated from the LOW-resolution
+    logits (segmi_upsample_ce_fwd/_bwd: interpolation inside the loss kernels, gradient born at low resolution) equals
+    torch's cross_entropy(interpolate(.)) in value and in the gradient w.r.t. the low-resolution logits — integer (8x) and
+    fractional scales, both align_corners conventions, class weights, ignored rows — and the drop-in module takes the fused path
+    exactly when it is handed an interpolate_bilinear result (autograd itself forbids in-place edits of such a tensor, so the
+    tag cannot go stale on a tensor that still carries it)."""
+    import utils.losses as L
+    from segmi import ops
+    N, C, h, w, H, W, ac, weighted = case
+    g = torch.Generator().manual_seed(23)
+    lo = torch.randn(N, C, h, w, generator=g) * 2
+    t = torch.randint(0, C, (N, H, W), generator=g)
+    t[:, : max(1, H // 10)] = 255
+    wt = (torch.rand(C, generator=g) + 0.25) if weighted else None
+    lr = lo.clone().requires_grad_(True)
+    ref = F.cross_entropy(F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=ac), t, weight=wt, ignore_index=255)
+    (ref * 1.7).backward()
+    crit = L.CrossEntropyLoss2d(weight=wt, ignore_index=255).to(cuda)
+    ld = lo.to(cuda).requires_grad_(True)
+    up = ops.interpolate_bilinear(ld * 1.0, (H, W), ac)
+    assert ops.upsample_source(up) is not None
+    val = crit(up, t.to(cuda))
+    (val * 1.7).backward()
+    assert abs(val.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-6, (val.item(), ref.item())
+    scale = lr.grad.abs().max().item()
+    assert (ld.grad.cpu() - lr.grad).abs().max().item() <= 2e-5 * scale + 1e-9, (ld.grad.cpu() - lr.grad).abs().max().item() / scale
+    # the unfused route (fusion switched off, or a tensor that is not an interpolate_bilinear result) gives the same numbers
+    crit2 = L.CrossEntropyLoss2d(weight=wt, ignore_index=255, fuse_upsample=False).to(cuda)
+    ld2 = lo.to(cuda).requires_grad_(True)
+    up2 = ops.interpolate_bilinear(ld2 * 1.0, (H, W), ac)
+    val2 = crit2(up2, t.to(cuda))
+    (val2 * 1.7).backward()
+    assert abs(val2.item() - val.item()) <= 1e-6 * abs(val.item()) + 1e-7
+    assert (ld2.grad - ld.grad).abs().max().item() <= 2e-5 * scale + 1e-9
+    assert ops.upsample_source(up2.detach() + 0) is None and ops.upsample_source(up2.detach()) is None     # new tensors carry no tag

@@ -24,10 +24,15 @@ prof)
   find gpurun_out/prof -name "*kernel_trace*" -size +30M -delete
   find gpurun_out/prof -type f | head ;;
 pmc)
-  rm -rf gpurun_out/pmc
-  ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -2 ) > gpurun_out/pmc.log
-  ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -2 ) >> gpurun_out/pmc.log
-  find gpurun_out/pmc -type f | head ;;
+  # HBM traffic of the conv launches of one cfg2 step, per arithmetic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes, kernel-trace only
+  for m in f32 bf16x3; do
+    rm -rf gpurun_out/pmc_$m
+    ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$m/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --conv-math $m 2>&1 | tail -2 ) > gpurun_out/pmc_$m.log
+    ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_$m/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --conv-math $m 2>&1 | tail -2 ) >> gpurun_out/pmc_$m.log
+    for d in fetch write; do f=$(find gpurun_out/pmc_$m/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_$m/$d/r_counter_collection.csv 2>/dev/null; done
+    python tools/traffic_json.py gpurun_out/pmc_$m gpurun_out/cfg2_conv_traffic_$m.json
+    find gpurun_out/pmc_$m -name "*kernel_trace*" -delete
+  done ;;
 x3)
   # first hardware run of the bf16x3 convolution arithmetic: opt-in accuracy tests, then A/B of the isolated layers and
   # of the whole training step (SEGMI_CONV_MATH is read at the first convolution of the process)
@@ -68,10 +73,12 @@ graph)
   done ;;
 testsx3)
   # acceptance run of the bf16x3 conv arithmetic: the ENTIRE gpu suite (incl. the BASELINE-shape audits) at unchanged tolerances
-  ( SEGMI_CONV_MATH=bf16x3 SEGMI_TEST_BF16X3=1 timeout 1500 python -m pytest tests -m gpu -q -rA -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|gradient" | tail -60 ) > gpurun_out/pytest_gpu_bf16x3.log
+  ( SEGMI_CONV_MATH=bf16x3 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_bf16x3.log
+  ( SEGMI_CONV_MATH=bf16x3 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_bf16x3.log
   cat gpurun_out/pytest_gpu_bf16x3.log ;;
 testsf32)
-  ( timeout 1500 python -m pytest tests -m gpu -q -rA -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|gradient" | tail -60 ) > gpurun_out/pytest_gpu_f32.log
+  ( SEGMI_CONV_MATH=f32 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_f32.log
+  ( SEGMI_CONV_MATH=f32 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_f32.log
   cat gpurun_out/pytest_gpu_f32.log ;;
 graphdbg)
   ( SEGMI_TEST_GRAPH=1 timeout 600 python -X faulthandler -m pytest tests/test_graph_gpu.py -m gpu -x -q -s 2>&1 | grep -v "^  File" | head -80 ) > gpurun_out/graph_tests_dbg.log
@@ -82,6 +89,11 @@ x3exp)
     ( SEGMI_CONV_MATH=$m timeout 300 python tools/conv_bench.py psp_bottleneck l4_3x3_d4 l4_1x1_up --op fwd 2>&1 | grep -v amdgpu.ids ) > gpurun_out/x3exp_$m.txt
     echo "== $m"; cat gpurun_out/x3exp_$m.txt
   done ;;
+quick)
+  # the tests touched last + bench with the alt leg
+  ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_unet_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf -s 2>&1 | grep -E "passed|failed|FAILED|ERROR|Error|assert|UNet grad" | tail -30 ) > gpurun_out/quick_f32.log
+  ( SEGMI_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -s 2>&1 | grep -E "passed|failed|FAILED|ERROR|Error|assert|UNet grad" | tail -30 ) > gpurun_out/quick_bf16x3.log
+  cat gpurun_out/quick_f32.log gpurun_out/quick_bf16x3.log ;;
 spawn)
   # the self-launching multi-GPU bench on a 1-GPU box: two ranks share cuda:0 (gloo on device tensors; RCCL needs one GPU per rank)
   ( timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -4 ) > gpurun_out/spawn.log; cat gpurun_out/spawn.log ;;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Build profiles/r01_cfg2_conv_traffic.json from the two rocprofv3 PMC passes of `tools/gpu_round.sh pmc`
+"""Build profiles/rNN_cfg2_conv_traffic_<math>.json (bench.py looks the dominant kernel up in it BY NAME) from the two rocprofv3 PMC passes of `tools/gpu_round.sh pmc`
 (gpurun_out/pmc/{fetch,write}/r_counter_collection.csv): HBM/MALL bytes of the conv implicit-GEMM launches of ONE cfg2 step.
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-counts
@@ -13,7 +13,7 @@ import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_cfg2_conv_traffic.json"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_cfg2_conv_traffic_f32.json"
 STEPS = 2.0
 CONV = ("conv_dma_kernel", "conv_wgrad_dma_kernel", "splitk_reduce_kernel", "conv_gather_kernel", "conv_wgrad_kernel")
 
@@ -44,7 +44,7 @@ cf = sum(v for k, v in fetch.items() if k.startswith(CONV)) * 1024.0
 cw = sum(v for k, v in write.items() if k.startswith(CONV)) * 1024.0
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 "
-              "--warmup 1 --no-cpu --no-roofline; MI355X, round 1 (tools/gpu_round.sh pmc + tools/traffic_json.py)",
+              "--warmup 1 --no-cpu --no-roofline; MI355X (tools/gpu_round.sh pmc + tools/traffic_json.py)",
     "scope": "all conv implicit-GEMM launches (conv_dma_kernel*, conv_wgrad_dma_kernel*, splitk_reduce_kernel) of ONE cfg2 training step",
     "fetch_bytes_raw": cf,
     "fetch_bytes_corrected": 2 * cf,
