@@ -212,6 +212,27 @@ int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, in
 int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, int C, float p, int channelwise,
                   uint64_t seed, const uint64_t* seed_epoch_dev, segmi_stream_t stream);
 
+/* ------------------------------------------------------------------ training-time augmentation */
+/* The cv2 / PIL sequence of BaseDataSet._augmentation + __getitem__ (base/base_dataset.py:63-136) on the device, one call per
+ * stage and sample; images are uint8 HWC (3 channels), labels int32 HW, all device memory; the random decisions are the
+ * caller's (dataloaders/gpu_augment.py draws them in the reference's order).
+ *   segmi_aug_resize : cv2.resize INTER_LINEAR (image) / INTER_NEAREST (label) to dst_h x dst_w                     (:71-72)
+ *   segmi_aug_rotate : cv2.warpAffine, bilinear / nearest, constant border 0; inv_affine6 = the INVERSE of
+ *                      getRotationMatrix2D((w/2, h/2), angle, 1.0) as 6 host floats {m00 m01 m02 m10 m11 m12}         (:76-81)
+ *   segmi_aug_blur   : cv2.GaussianBlur(ksize x ksize, sigma), BORDER_REFLECT_101; kernel_half4 = host floats {centre, +-1,
+ *                      +-2, +-3 taps} of getGaussianKernel (ksize odd <= 7); scratch = 3*h*w floats                    (:113-117)
+ *   segmi_aug_finish : zero padding at the bottom / right up to the crop, crop at (start_h, start_w), optional fliplr,
+ *                      ToTensor + Normalize(mean, std) into the fp32 NHWC batch slot `out` (pixel stride ld >= 4, channels
+ *                      3..ld-1 zeroed) and the int64 label slot                                                     (:84-110,129-136) */
+int segmi_aug_resize(const uint8_t* image, const int32_t* label, int src_h, int src_w, uint8_t* out_image, int32_t* out_label,
+                     int dst_h, int dst_w, segmi_stream_t stream);
+int segmi_aug_rotate(const uint8_t* image, const int32_t* label, int h, int w, const float* inv_affine6, uint8_t* out_image,
+                     int32_t* out_label, segmi_stream_t stream);
+int segmi_aug_blur(const uint8_t* image, int h, int w, int ksize, const float* kernel_half4, float* scratch, uint8_t* out_image,
+                   segmi_stream_t stream);
+int segmi_aug_finish(const uint8_t* image, const int32_t* label, int h, int w, int crop_h, int crop_w, int start_h, int start_w,
+                     int flip, const float* mean3, const float* std3, float* out, int ld, int64_t* out_label, segmi_stream_t stream);
+
 /* ------------------------------------------------------------------ per-pixel losses (K10/K11/K12) */
 /* CrossEntropyLoss2d (utils/losses.py:24-31): nn.CrossEntropyLoss(weight, ignore_index, reduction='mean'):
  * sum_i w[t_i] * (-log_softmax_i[t_i]) / sum_i w[t_i] over pixels with target != ignore_index; class_weight (C floats,

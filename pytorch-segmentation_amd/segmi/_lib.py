@@ -67,6 +67,10 @@ SIGNATURES = {
     "segmi_bilinear_bwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
     "segmi_bilinear_bwd": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "segmi_dropout": (i32, [vp, i32, vp, i32, i32, i64, i32, f32, i32, u64, vp, vp]),
+    "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp]),
+    "segmi_aug_rotate": (i32, [vp, vp, i32, i32, C.POINTER(f32), vp, vp, vp]),
+    "segmi_aug_blur": (i32, [vp, i32, i32, i32, C.POINTER(f32), vp, vp, vp]),
+    "segmi_aug_finish": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
     "segmi_ce_workspace": (sz, [i64]),
     "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, vp, sz, vp]),
     "segmi_ce_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, vp, i32, vp]),
