@@ -212,6 +212,28 @@ int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, in
 int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, int C, float p, int channelwise,
                   uint64_t seed, const uint64_t* seed_epoch_dev, segmi_stream_t stream);
 
+/* ------------------------------------------------------------------ factored PSP bottleneck (models/pspnet.py:25-38) */
+/* conv3x3(cat[features, up(p_1), ..., up(p_L)]) = conv3x3(features; W[:, :Cx]) + sum_l sum_taps B * T_l with
+ * T_l = p_l (x) W[:, slice_l] a small GEMM (csrc/pyramid_bottleneck.hip): the upsampled pyramid branches and the concat buffer
+ * are never built and half of the bottleneck's MACs disappear.  Pieces:
+ *   segmi_filter_slice / _unslice : channel slice [c0, c0+Cs) of a KRSC filter [K, RS, Ctot] as a contiguous [K*RS, Cs] matrix
+ *                                   with rows ordered (k, rs) (rs_major = 0: itself a KRSC filter) or (rs, k) (rs_major = 1:
+ *                                   the 1x1 filter whose output channel rs*K + k is T's layout); unslice scatters a gradient
+ *                                   slice back into the full KRSC gradient.
+ *   segmi_pyramid_up_fwd          : y[n,h,w,k] = sum_l sum_{r,s} bilinear(align_corners=True, b_l x b_l -> H x W) of
+ *                                   T_l[n, :, :, (r*3+s)*K + k] evaluated at (h+r-1, w+s-1), zero outside the map (the 3x3
+ *                                   convolution's padding).  T_l: [N, b_l, b_l, 9K] dense.  y is OVERWRITTEN (pixel stride ldy).
+ *   segmi_pyramid_up_bwd          : the transpose: G_l (same layout as T_l) from dy [N, H, W, K] (pixel stride lddy).
+ * Workspace (both directions): segmi_pyramid_up_workspace, 16-byte aligned.  K % 4 == 0, at most 4 levels. */
+int segmi_filter_slice(const float* w_krsc, int K, int RS, int Ctot, int c0, int Cs, int rs_major, float* out, segmi_stream_t stream);
+int segmi_filter_unslice(const float* grad_slice, int K, int RS, int Ctot, int c0, int Cs, int rs_major, float* dw_krsc,
+                         segmi_stream_t stream);
+size_t segmi_pyramid_up_workspace(int N, int H, int W, int K, int nlevels, const int* bins);
+int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int nlevels, const int* bins, float* y, int ldy,
+                         void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins, float* const* G,
+                         void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+
 /* ------------------------------------------------------------------ training-time augmentation */
 /* The cv2 / PIL sequence of BaseDataSet._augmentation + __getitem__ (base/base_dataset.py:63-136) on the device, one call per
  * stage and sample; images are uint8 HWC (3 channels), labels int32 HW, all device memory; the random decisions are the

@@ -5,8 +5,10 @@ and checkpoint key names follow models/pspnet.py:11-105 of the reference; every 
 forward/backward is a libsegmi HIP kernel (NHWC, fp32 MFMA implicit-GEMM convolutions, fused
 BN+ReLU(+residual), one-launch adaptive pooling and gather-form bilinear resize).
 """
+import os
 from itertools import chain
 
+import torch
 import torch.nn as nn
 
 from base import BaseModel
@@ -42,10 +44,25 @@ class _PSPModule(nn.Module):
         # all pyramid levels pooled in ONE pass over the feature map (and one gradient write in backward); the
         # AdaptiveAvgPool2d modules stay in `stages` so checkpoint keys / indices are the reference's
         pooled = ops.pyramid_pool(features, bins) if fused else [stage[0](features) for stage in self.stages]
-        pyramid = [features]
-        for stage, p in zip(self.stages, pooled):
-            pyramid.append(ops.interpolate_bilinear(snn.run_fused(list(stage)[1:], p), size, align_corners=True))
+        branches = [snn.run_fused(list(stage)[1:], p) for stage, p in zip(self.stages, pooled)]      # [N, C/4, b, b] each
+        conv = self.bottleneck[0]
+        if self.factored and self._factorable(conv, features, branches):
+            # concat + 3x3 convolution in factored form: the convolution runs over the feature channels only, the (linear)
+            # upsample-then-convolve of every pyramid branch is a b*b-pixel GEMM plus a separable interpolation — half of the
+            # bottleneck's MACs and the 4096-channel concat buffer disappear (segmi.ops.pyramid_bottleneck_conv)
+            y = ops.pyramid_bottleneck_conv(features, branches, conv.weight)
+            return snn.run_fused(list(self.bottleneck)[1:], y)
+        pyramid = [features] + [ops.interpolate_bilinear(b, size, align_corners=True) for b in branches]
         return self.bottleneck(ops.cat(pyramid))
+
+    factored = os.environ.get("SEGMI_PSP_FACTORED", "1") != "0"      # A/B switch; the unfactored path is the test reference
+
+    @staticmethod
+    def _factorable(conv, features, branches):
+        return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                and conv.bias is None and conv.groups == 1 and len(branches) <= 4 and features.shape[1] % 4 == 0
+                and conv.out_channels % 4 == 0 and all(b.shape[1] % 4 == 0 and b.shape[2] == b.shape[3] for b in branches)
+                and conv.weight.is_contiguous(memory_format=torch.channels_last))
 
 
 class PSPNet(BaseModel):

@@ -17,7 +17,7 @@ from ._lib import ConvDesc, SegmiError, check, lib
 from .profile import span
 
 __all__ = [
-    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "interpolate_bilinear",
+    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
     "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_dropout_epoch",
 ]
 
@@ -697,6 +697,126 @@ class _PyramidPoolFn(torch.autograd.Function):
 def pyramid_pool(x, bins):
     """[F.adaptive_avg_pool2d(x, b) for b in bins] — the PSP pyramid (models/pspnet.py:25-37) — fused."""
     return _PyramidPoolFn.apply(x, *[int(b) for b in bins])
+
+
+# --------------------------------------------------------------------------- factored PSP bottleneck
+def _conv_call(kind, d, C, *args):
+    """One libsegmi convolution launch wrapped in a roofline span (kind 0 fwd, 1 dgrad, 2 wgrad)."""
+    fn = (lib.segmi_conv2d_fwd, lib.segmi_conv2d_dgrad, lib.segmi_conv2d_wgrad)[kind]
+    with span(lambda: conv_variant(d, kind), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        check(fn(d, *args), ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")[kind])
+
+
+class _PyramidBottleneckFn(torch.autograd.Function):
+    """y = conv3x3(cat([x, up(p_1), ..., up(p_L)], 1), weight, padding=1) with up = bilinear(align_corners=True) to x's size —
+    the PSP module's concat + bottleneck convolution (models/pspnet.py:32-38) — evaluated in factored form: the convolution
+    proper runs over x's channels only; each pyramid branch contributes through T_l = p_l (x) W[:, slice_l] (a 1x1 convolution
+    with 9K output channels on the b x b map) and a separable bilinear assembly (csrc/pyramid_bottleneck.hip).  Backward is the
+    exact transpose: dgrad / wgrad over x's channels, dy reduced to G_l = dT_l, then dgrad / wgrad of the 1x1 convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, *ps):
+        x = to_nhwc(x, "pyramid_bottleneck")
+        _need_cuda(weight, "pyramid_bottleneck")
+        N, Cx, H, W = x.shape
+        K, Ct, R, S = weight.shape
+        ps = [to_nhwc(p, "pyramid_bottleneck") for p in ps]
+        cs = [p.shape[1] for p in ps]
+        bins = [p.shape[2] for p in ps]
+        if (R, S) != (3, 3) or Ct != Cx + sum(cs) or not weight.is_contiguous(memory_format=torch.channels_last) or (weight.data_ptr() & 15):
+            raise SegmiError("pyramid_bottleneck: needs a channels_last 3x3 filter over %d + %s channels, got %s" % (Cx, cs, tuple(weight.shape)))
+        if (Cx & 3) or (K & 3) or any(c & 3 for c in cs) or any(p.shape[2] != p.shape[3] or ld_of(p) != p.shape[1] for p in ps) or len(ps) > 4:
+            raise SegmiError("pyramid_bottleneck: channel counts must be multiples of 4 and the pyramid maps square and dense")
+        dev, st = x.device, _stream()
+        nl = len(ps)
+        barr = (ctypes.c_int * nl)(*bins)
+        # contiguous operands: the x-channel slice as a KRSC filter, each pyramid slice as a 1x1 filter with rows (rs, k)
+        fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
+        check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
+        y = empty_nhwc(N, K, H, W, dev)
+        Ts, c0 = [], Cx
+        for p, c, b in zip(ps, cs, bins):
+            fs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)
+            check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, c0, c, 1, fs.data_ptr(), st), "filter_slice")
+            t = torch.empty((N, b, b, 9 * K), device=dev, dtype=torch.float32)
+            d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, c, 9 * K)
+            nws = lib.segmi_conv2d_fwd_workspace(d)
+            ws = workspace(nws, dev) if nws else None
+            _conv_call(0, d, c, p.data_ptr(), fs.data_ptr(), None, t.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st)
+            Ts.append(t)
+            c0 += c
+        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, barr)
+        ws = workspace(nws + 16, dev)
+        tp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in Ts])
+        check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, barr, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
+        d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(y))
+        _conv_call(0, d, Cx, x.data_ptr(), fx.data_ptr(), None, y.data_ptr(), 1, None, 0, st)        # accumulate onto the pyramid part
+        ctx.save_for_backward(x, weight, *ps)
+        ctx.geom = (N, Cx, H, W, K, Ct, tuple(cs), tuple(bins))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, *ps = ctx.saved_tensors
+        N, Cx, H, W, K, Ct, cs, bins = ctx.geom
+        dy = to_nhwc(dy, "pyramid_bottleneck.backward")
+        dev, st = x.device, _stream()
+        nl = len(ps)
+        barr = (ctypes.c_int * nl)(*bins)
+        dwb = torch.empty(K * 9 * Ct, device=dev, dtype=torch.float32)          # full KRSC gradient, filled slice by slice
+        fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
+        check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
+        # ---- feature channels: plain dgrad / wgrad of the 3x3 convolution over Cx channels
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(Cx * 9 * K, device=dev, dtype=torch.float32)
+            check(lib.segmi_filter_krsc_to_crsk(fx.data_ptr(), wt.data_ptr(), K, 3, 3, Cx, K, st), "krsc_to_crsk")
+            dx = empty_nhwc(N, Cx, H, W, dev)
+            d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(dx), ld_of(dy))
+            _conv_call(1, d, Cx, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st)
+        d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(dy))
+        nws = lib.segmi_conv2d_wgrad_workspace(d)
+        ws = workspace(nws, dev) if nws else None
+        dfx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
+        _conv_call(2, d, Cx, x.data_ptr(), dy.data_ptr(), dfx.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st)
+        check(lib.segmi_filter_unslice(dfx.data_ptr(), K, 9, Ct, 0, Cx, 0, dwb.data_ptr(), st), "filter_unslice")
+        # ---- pyramid branches: G_l = dT_l by the transposed interpolation, then the 1x1 convolution's dgrad / wgrad
+        Gs = [torch.empty((N, b, b, 9 * K), device=dev, dtype=torch.float32) for b in bins]
+        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, barr)
+        ws = workspace(nws + 16, dev)
+        gp = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in Gs])
+        check(lib.segmi_pyramid_up_bwd(dy.data_ptr(), ld_of(dy), N, H, W, K, nl, barr, gp, (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_bwd")
+        dps, c0 = [], Cx
+        for li, (p, c, b, g) in enumerate(zip(ps, cs, bins, Gs)):
+            fs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)
+            check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, c0, c, 1, fs.data_ptr(), st), "filter_slice")
+            dp = None
+            if ctx.needs_input_grad[2 + li]:
+                wt = torch.empty(c * 9 * K, device=dev, dtype=torch.float32)
+                check(lib.segmi_filter_krsc_to_crsk(fs.data_ptr(), wt.data_ptr(), 9 * K, 1, 1, c, 9 * K, st), "krsc_to_crsk")
+                dp = empty_nhwc(N, c, b, b, dev)
+                # dp = G x F as a FORWARD 1x1 convolution over G's 9K channels (filter = F transposed): the forward kernel splits
+                # the 4608-long reduction over the chip, the dgrad entry would walk it in 4 workgroups
+                d = ConvDesc(N, b, b, 9 * K, c, 1, 1, b, b, 1, 0, 1, 9 * K, ld_of(dp))
+                nws = lib.segmi_conv2d_fwd_workspace(d)
+                ws = workspace(nws, dev) if nws else None
+                _conv_call(0, d, 9 * K, g.data_ptr(), wt.data_ptr(), None, dp.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st)
+            dps.append(dp)
+            d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, ld_of(p), 9 * K)
+            nws = lib.segmi_conv2d_wgrad_workspace(d)
+            ws = workspace(nws, dev) if nws else None
+            dfs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)
+            _conv_call(2, d, c, p.data_ptr(), g.data_ptr(), dfs.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st)
+            check(lib.segmi_filter_unslice(dfs.data_ptr(), K, 9, Ct, c0, c, 1, dwb.data_ptr(), st), "filter_unslice")
+            c0 += c
+        dw = dwb.view(K, 3, 3, Ct).permute(0, 3, 1, 2) if ctx.needs_input_grad[1] else None
+        return (dx, dw) + tuple(dps)
+
+
+def pyramid_bottleneck_conv(x, pyramid, weight):
+    """F.conv2d(torch.cat([x] + [F.interpolate(p, x.shape[2:], mode='bilinear', align_corners=True) for p in pyramid], 1), weight,
+    padding=1) without building the upsampled maps or the concatenation (see _PyramidBottleneckFn)."""
+    return _PyramidBottleneckFn.apply(x, weight, *pyramid)
 
 
 # --------------------------------------------------------------------------- bilinear resize

@@ -170,3 +170,54 @@ def test_pspnet_batch_stat_gradients_within_reference_noise_floor(cuda):
           % (med_hip, max(e_hip), med_ref, max(e_ref)))
     assert med_hip <= 2.0 * med_ref + 1e-4
     assert max(e_hip) <= 3.0 * max(e_ref) + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 24, 24, 32, (1, 2, 3, 6)), (1, 32, 13, 17, 16, (1, 2, 3, 6)), (2, 16, 8, 8, 8, (2, 5)), (1, 128, 33, 33, 64, (1, 2, 3, 6))])
+def test_factored_psp_bottleneck_equals_cat_conv(cuda, shape):
+    """ops.pyramid_bottleneck_conv (csrc/pyramid_bottleneck.hip: convolution over the feature channels + per-branch GEMM +
+    separable interpolation) against the literal reference expression
+    conv3x3(cat([x] + [interpolate(p, size, bilinear, align_corners=True)]), W, padding=1) (models/pspnet.py:32-38) evaluated by
+    torch on CPU in fp64: output and ALL gradients (x, every pyramid branch, the full filter), incl. non-square maps."""
+    import torch.nn.functional as F
+    from segmi import ops
+    N, Cx, H, W, K, bins = shape
+    cs = Cx // 4
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Cx, H, W, generator=g)
+    ps = [torch.randn(N, cs, b, b, generator=g) for b in bins]
+    w = torch.randn(K, Cx + cs * len(bins), 3, 3, generator=g) * (2.0 / (9 * (Cx + cs * len(bins)))) ** 0.5
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in ps]
+    yr = F.conv2d(torch.cat([xr] + [F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True) for p in pr], 1), wr, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd = x.to(cuda).requires_grad_(True)
+    wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pd = [ops.to_nhwc(p.to(cuda)).requires_grad_(True) for p in ps]
+    yd = ops.pyramid_bottleneck_conv(xd, pd, wd)
+    yd.backward(gy.to(cuda))
+    pairs = [("y", yd, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad)] + [("dp%d" % b, a.grad, r.grad) for b, a, r in zip(bins, pd, pr)]
+    for name, a, r in pairs:
+        err = (a.detach().cpu().double() - r.detach()).abs().max().item()
+        assert err <= 1e-4 * r.abs().max().item(), (name, err, r.abs().max().item())
+
+
+def test_pspnet_factored_and_unfactored_paths_agree(cuda, monkeypatch):
+    """The whole model under both forms of the PSP bottleneck (SEGMI_PSP_FACTORED switch): logits, loss and every gradient."""
+    import models
+    from models.pspnet import _PSPModule
+    classes = 7
+    man = _manifest(_gold(), classes)
+    x, t = synth_batch(2, 3, 96, 112, classes, seed=5)
+    res = {}
+    for factored in (False, True):
+        monkeypatch.setattr(_PSPModule, "factored", factored)
+        m, _ = _build(cuda, man, classes, seed=9, frozen=True)
+        out, aux, loss = _step(m, x, t, cuda)
+        res[factored] = (out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    (o0, l0, g0), (o1, l1, g1) = res[False], res[True]
+    assert (o0 - o1).abs().max().item() <= 1e-4 * o0.abs().max().item()
+    assert abs(l0 - l1) < 1e-5
+    for k in g0:
+        e = (g0[k] - g1[k]).norm().item() / (g0[k].norm().item() + 1e-30)
+        assert e <= 1e-3, (k, e)
