@@ -1,25 +1,29 @@
 #!/usr/bin/env python
 """bench.py — training images/sec of the MI355X-native segmentation hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--conv-math f32|bf16x3] [--graph]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--no-alt] [--conv-math f32|bf16x3]
 
-A "step" is one pass of the hot path over one synthetic batch resident in HBM: zero_grad -> PSPNet-R50
-forward (train mode: BN batch statistics, dropout active, aux head) -> CrossEntropy(main) + 0.4*CE(aux)
--> backward -> gradient all-reduce (N>1, RCCL, overlapped with backward) -> SGD(momentum, weight decay)
-step — the reference's inner loop trainer.py:55-71.  Workload at every N: BASELINE.json configs[1]
-(PSPNet-ResNet50, 8 x 3x512x512, 21 classes) PER GPU, i.e. weak scaling; fp32 end to end (the
+`python bench.py --gpus N` drives all N GPUs by itself (it re-executes under torch.distributed.run, one rank per GPU over
+RCCL); the driver's own form `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` is what
+that re-execution issues and works directly as well.
+
+A "step" is one pass of the hot path over one synthetic batch resident in HBM: zero_grad -> PSPNet-R50 forward (train mode: BN
+batch statistics, dropout active, aux head) -> CrossEntropy(main) + 0.4*CE(aux) (global-batch mean over all ranks' valid
+pixels) -> backward -> gradient all-reduce (N>1, RCCL, bucketed, overlapped with backward) -> fused SGD(momentum, weight
+decay), per bucket right after its all-reduce — the reference's inner loop trainer.py:55-71.  Workload at every N:
+BASELINE.json configs[1] (PSPNet-ResNet50, 8 x 3x512x512, 21 classes) PER GPU, i.e. weak scaling; fp32 end to end (the
 reference's dtype; convolutions on v_mfma_f32_32x32x2_f32).
 
 Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
-  roofline     : the dominant kernel = the conv implicit-GEMM variant (MFMA-bound) with the largest total time,
-                 measured with HIP events per launch in an extra instrumented step: `achieved` = its algorithmic
-                 FLOPs per launch / its mean launch duration `avg_us` (compare with profiles/*kernel_stats*),
-                 `traffic` = its HBM bytes per launch from the committed rocprofv3 PMC passes; `all_conv` holds the
-                 same quantities over ALL conv launches of the step.
-  cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on
-                 this host's cores on a bounded sample (batch 2 of the same 512x512 workload).
+  roofline     : the dominant kernel = the conv implicit-GEMM variant (MFMA-bound) with the largest total time, measured with
+                 HIP events per launch in an extra instrumented step: `achieved` = its algorithmic FLOPs per launch / its mean
+                 launch duration `avg_us` (compare with profiles/*kernel_stats*), `traffic` = its HBM bytes per launch from the
+                 committed rocprofv3 PMC passes (null when no profile knows the kernel by its current name); `all_conv` holds
+                 the same quantities over ALL conv launches of the step.
+  cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on this host's cores on a
+                 bounded sample: the FULL batch of the same workload, one warm-up + timed steps within a 75 s cap (N = 1 only).
+  alt          : the same K steps with the convolutions on the bf16x3 arithmetic (fp32 products as three-plane bf16 splits on
+                 the bf16 matrix pipe), its own roofline object priced against BOTH ceilings.  Never the headline.
 """
 import argparse
 import json
@@ -275,7 +279,10 @@ def main():
                              "launches": sum(r["launches"] for r in summ.values()), "ms_per_step": round(tot_ms, 2),
                              "flops_per_step": tot_fl, "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
                              "traffic_bytes_per_step": step_traffic},
+                # step_frac prices the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as
+                # written) against the peak; the factored PSP bottleneck executes fewer (all_conv.flops_per_step is what ran)
                 "step_frac": round(value / world * flops_img / 1e12 / peak, 4),
+                "reference_formulation_flops_per_step": flops_img * nb,
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                  "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
 

@@ -20,15 +20,15 @@ layers)
   ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/conv_layers.txt; tail -3 gpurun_out/conv_layers.txt ;;
 prof)
   rm -rf gpurun_out/prof
-  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline 2>&1 | tail -2 ) > gpurun_out/prof.log
+  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
   find gpurun_out/prof -name "*kernel_trace*" -size +30M -delete
   find gpurun_out/prof -type f | head ;;
 pmc)
   # HBM traffic of the conv launches of one cfg2 step, per arithmetic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes, kernel-trace only
   for m in f32 bf16x3; do
     rm -rf gpurun_out/pmc_$m
-    ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$m/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --conv-math $m 2>&1 | tail -2 ) > gpurun_out/pmc_$m.log
-    ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_$m/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --conv-math $m 2>&1 | tail -2 ) >> gpurun_out/pmc_$m.log
+    ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$m/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt --conv-math $m 2>&1 | tail -2 ) > gpurun_out/pmc_$m.log
+    ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_$m/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt --conv-math $m 2>&1 | tail -2 ) >> gpurun_out/pmc_$m.log
     for d in fetch write; do f=$(find gpurun_out/pmc_$m/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_$m/$d/r_counter_collection.csv 2>/dev/null; done
     python tools/traffic_json.py gpurun_out/pmc_$m gpurun_out/cfg2_conv_traffic_$m.json
     find gpurun_out/pmc_$m -name "*kernel_trace*" -delete
