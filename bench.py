@@ -171,7 +171,7 @@ def main():
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = "gloo" if oversubscribed else "nccl"           # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("SEGMI_BENCH_BACKEND") or ("gloo" if oversubscribed else "nccl")     # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -295,6 +295,15 @@ def main():
     value = world * nb * args.steps / dt
     roof = None if args.no_roofline else roofline_of(args.conv_math, value)
 
+    # SyncBN: small latency-bound collectives per step (one all-gather forward + one all-reduce backward per BN layer; exact
+    # SyncBN needs both before the layer can proceed, so only parallel branches could share one)
+    syncbn_per_step = None
+    if args.sync_bn and ddp:
+        ctxs = [m.sync for m in model.modules() if getattr(m, "sync", None) is not None]
+        before = sum(c.collectives for c in ctxs)
+        step()
+        syncbn_per_step = sum(c.collectives for c in ctxs) - before
+
     # `alt`: the same K steps of the same job (it simply keeps training) with the convolutions on the OTHER arithmetic — fp32
     # products evaluated as three-plane bf16 splits on the bf16 matrix pipe (csrc/conv_igemm.hip).  Reported
     # beside the headline, never as it: the headline line is the fp32-MFMA parity path.
@@ -336,7 +345,8 @@ def main():
                        "global_batch": nb * world, "parallelism": "dp%d" % world,
                        "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
                        "rccl_ranks": (dist.get_world_size() if ddp and backend == "nccl" else 0), "final_loss": round(final_loss, 5),
-                       "conv_math": args.conv_math, "hip_graph": bool(args.graph)},
+                       "conv_math": args.conv_math, "hip_graph": bool(args.graph),
+                       "syncbn_collectives_per_step": syncbn_per_step},
             "roofline": roof, "cpu_baseline": cpu, "alt": alt,
         }
         print(json.dumps(line), flush=True)

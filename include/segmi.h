@@ -91,6 +91,22 @@ enum segmi_conv_math {
     SEGMI_CONV_MATH_F32 = 0,
     SEGMI_CONV_MATH_BF16X3 = 1
 };
+/* bf16x3 with the FILTER operand pre-split: segmi_filter_presplit writes the three bf16 planes {h, m, l} (plane stride n
+ * elements, n % 8 == 0, 6 bytes per filter element: segmi_filter_presplit_bytes) of an fp32 filter ONCE per step; the
+ * _presplit entry points take those planes instead of the fp32 filter (KRSC for fwd, CRSK for dgrad, i.e. the array that
+ * segmi_conv2d_fwd / _dgrad would have been given) and split only the activation operand in registers — half of the loop's VALU
+ * work.  Results are bit-identical to segmi_conv2d_fwd / _dgrad under SEGMI_CONV_MATH_BF16X3 (same split, same products,
+ * same order).  segmi_conv2d_presplit_ok(d, op) (op 0 fwd, 1 dgrad) says whether the variant applies to a problem (bf16x3
+ * selected, channel counts multiples of 8, >= 64-wide output tiles, unit-stride dgrad); segmi_conv_set_presplit(0) /
+ * SEGMI_CONV_PRESPLIT=0 switches it off process-wide (A/B). */
+int segmi_conv_set_presplit(int on);
+int segmi_conv2d_presplit_ok(const segmi_conv_desc* d, int op);
+size_t segmi_filter_presplit_bytes(long n);
+int segmi_filter_presplit(const float* w, long n, void* planes, segmi_stream_t stream);
+int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
+                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
+                                segmi_stream_t stream);
 int segmi_conv_set_math(int math);
 int segmi_conv_get_math(void);
 /* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */

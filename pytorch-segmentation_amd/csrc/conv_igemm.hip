@@ -50,6 +50,10 @@ struct GatherParams {
     // tap ids from the tables below.  R = 1, S = ntaps for the loop logic; wRS = the filter's real tap count.
     int sub, Hc, Wc, ph, pw, os, wRS;
     int tab_r[16], tab_s[16], tab_w[16];
+    // MATH_BF16X3_PRE: the filter arrives already split into three bf16 planes (segmi_filter_presplit): [3][Cd][R*S*Cs] bf16,
+    // plane stride `plane_bytes`; `wgt` is unused
+    const void* wplanes;
+    unsigned plane_bytes;
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -277,7 +281,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // The loop is software-pipelined over 16-wide k steps across chunk boundaries; two other loop structures (compiler-scheduled
 // per-chunk loop, packed residual subtractions) and a two-plane reduced-precision variant were measured on hardware in round 2
 // (profiles/r02_bf16x3_*) and removed: this one was the fastest (197 vs 182/186 TF/s on the PSP bottleneck).
-enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3 };
+enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3,
+       // internal variant of bf16x3 (fprop / dgrad only, never selected by the caller directly): the FILTER operand is read as
+       // pre-split bf16 planes, so only the activation operand is split in registers — half of the loop's VALU work
+       MATH_BF16X3_PRE = 2 };
 
 struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
 
@@ -342,7 +349,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile shape");
 
     extern __shared__ __attribute__((aligned(1024))) float smem[];
-    constexpr int STAGE = (BM + BN) * BK;               // floats per pipeline stage
+    constexpr bool BPRE = MATH == MATH_BF16X3_PRE;
+    // floats per pipeline stage: A = BM rows x 32 fp32; B = BN rows x 32 fp32, or (BPRE) three planes of BN rows x 32 bf16
+    constexpr int STAGE = BM * BK + (BPRE ? BN * 48 : BN * BK);
+    static_assert(!BPRE || (BN % 64 == 0), "pre-split B planes move 16 rows x 64 B per wave-instruction, 4 waves");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,8 +372,12 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     const int m0 = tm * BM, n0 = tn * BN;
 
     const i32x4 src_rsrc = make_rsrc(p.src, src_bytes);
-    const i32x4 wgt_rsrc = make_rsrc(p.wgt, wgt_bytes);
+    const i32x4 wgt_rsrc = make_rsrc(BPRE ? (const float*)p.wplanes : p.wgt, wgt_bytes);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)wave * (8 * BK * 4);
+    // BPRE: a wave-instruction deposits 16 plane rows of 64 B (32 bf16); lane -> (row lane/4, 16-byte slot lane%4); the slot a
+    // lane FETCHES is XOR-swizzled with (row/4)%4 so that the ds_read_b128 of 16 consecutive rows hit 16 distinct bank quads
+    const unsigned ldsB0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + BM * BK * 4 + (unsigned)wave * (16 * 64);
+    const int kgB = (lane & 3) ^ ((lane >> 4) & 3);
 
     // DMA role of this lane: row (wave*8 + lane/8) of every 32-row group, 16-byte slot lane%8
     const int rl = wave * 8 + (lane >> 3);
@@ -413,6 +427,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)((subm ? p.wRS : RS) * p.Cs) : OOB;
     }
 
+    auto issue_b_planes = [&](int r, int s, int c0, int buf) {
+        const unsigned Bp = ldsB0 + (unsigned)buf * (STAGE * 4);
+        const int cB = c0 + kgB * 8;                             // this lane's 8-channel group of the chunk
+        const bool cokB = cB < p.Cs;
+        const unsigned tapc = (unsigned)((r * p.S + s) * p.Cs + cB);
+        const unsigned rowlen = (unsigned)(p.R * p.S * p.Cs);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) {
+                const int k = n0 + i * 64 + wave * 16 + (lane >> 2);
+                const bool ok = cokB && k < p.Cd;
+                dma16(wgt_rsrc, ok ? (unsigned)pl * p.plane_bytes + ((unsigned)k * rowlen + tapc) * 2u : OOB, Bp + pl * (BN * 64) + i * (64 * 64));
+            }
+    };
     auto issue = [&](int r, int s, int c0, int buf) {
         const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BM * BK * 4;   // LDS byte addresses (wave's 8-row slice)
         const int c = c0 + kg * 4;
@@ -466,6 +495,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             const unsigned off = ((unsigned)(a_pix[i] + hs * p.Ws + ws) * (unsigned)p.lds + (unsigned)c) * 4u;
             dma16(src_rsrc, ok ? off : OOB, As + i * (32 * BK * 4));
         }
+        if constexpr (BPRE) { issue_b_planes(r, s, c0, buf); return; }   // (never combined with pack4 / parity-class launches: host side)
         const unsigned tapc = (unsigned)((r * p.S + s) * p.Cs + c);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -512,9 +542,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
         // (sched_group_barrier: 1 MFMA + its share of VALU per group), so neither pipe waits for the other inside a wave;
         // only the very first split of a tile is exposed, and the last step drains after the loop.
         constexpr int NMMA = TM * TN * 6;
-        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;   // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub = 44
-        float ra[2][TM][8], rb[2][TN][8];
+        // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub = 44; with pre-split filter planes only the A row-blocks are split
+        constexpr int VPG = ((TM + (BPRE ? 0 : TN)) * 44 + NMMA - 1) / NMMA;
+        float ra[2][TM][8], rb[2][TN][8];                    // (rb is dead under BPRE)
         Planes pa[2][TM], pb[2][TN];
+        const int swzB = (lrow32 >> 2) & 3;
         auto fetch = [&](const float* Ab, const float* Bb, int ks) {
             const int g0 = ks * 4 + lhalf * 2;
             const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
@@ -525,20 +557,41 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
                 ra[ks][i][0] = u.x; ra[ks][i][1] = u.y; ra[ks][i][2] = u.z; ra[ks][i][3] = u.w;
                 ra[ks][i][4] = v.x; ra[ks][i][5] = v.y; ra[ks][i][6] = v.z; ra[ks][i][7] = v.w;
             }
+            if constexpr (!BPRE) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
-                const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                rb[ks][j][0] = u.x; rb[ks][j][1] = u.y; rb[ks][j][2] = u.z; rb[ks][j][3] = u.w;
-                rb[ks][j][4] = v.x; rb[ks][j][5] = v.y; rb[ks][j][6] = v.z; rb[ks][j][7] = v.w;
+                for (int j = 0; j < TN; ++j) {
+                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
+                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
+                    rb[ks][j][0] = u.x; rb[ks][j][1] = u.y; rb[ks][j][2] = u.z; rb[ks][j][3] = u.w;
+                    rb[ks][j][4] = v.x; rb[ks][j][5] = v.y; rb[ks][j][6] = v.z; rb[ks][j][7] = v.w;
+                }
             }
         };
-        auto phase_b = [&]() {                                 // MFMAs of step 0 || split of step 1, then hand over the stage
+        // BPRE: the filter planes of step ks straight from LDS into the matrix-instruction operands (one ds_read_b128 per plane:
+        // 8 consecutive bf16 of the lane's row), slot un-swizzled as the DMA swizzled it
+        auto load_b_planes = [&](const float* Bb, int ks) {
+            const u32x4_t* base = reinterpret_cast<const u32x4_t*>(Bb);
+            const int slot = (ks * 2 + lhalf) ^ swzB;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + lrow32;
+                pb[ks][j].h = base[(0 * BN + row) * 4 + slot];
+                pb[ks][j].m = base[(1 * BN + row) * 4 + slot];
+                pb[ks][j].l = base[(2 * BN + row) * 4 + slot];
+            }
+        };
+        auto split_b = [&](int ks) {
+            if constexpr (!BPRE) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pb[ks][j] = split8(rb[ks][j]);
+            }
+        };
+        auto phase_b = [&](const float* Bb) {                  // MFMAs of step 0 || split of step 1, then hand over the stage
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BPRE) load_b_planes(Bb, 1);            // pb[1] is free: the pending step's MFMAs precede this point
 #pragma unroll
             for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
+            split_b(1);
             mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
@@ -546,6 +599,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (BPRE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pb[1]'s reads of this stage are consumed only next iteration
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
             __syncthreads();                                     // ... for every wave, and this stage is free again
             buf ^= 1;
@@ -556,11 +610,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             const float* Bb = Ab + BM * BK;
             fetch(Ab, Bb, 0);
             fetch(Ab, Bb, 1);
+            if constexpr (BPRE) load_b_planes(Bb, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
-            phase_b();
+            split_b(0);
+            phase_b(Bb);
         }
         for (int it = it0 + 1; it < T; ++it) {
             if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
@@ -568,19 +622,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             const float* Bb = Ab + BM * BK;
             fetch(Ab, Bb, 0);
             fetch(Ab, Bb, 1);                                  // both steps up front: step 1's LDS latency hides behind phase A
+            if constexpr (BPRE) load_b_planes(Bb, 0);            // pb[0] was consumed by the previous phase B
             // phase A: MFMAs of the pending step || split of step 0
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
+            split_b(0);
             mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
             }
-            phase_b();
+            phase_b(Bb);
         }
         if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
     } else
@@ -1138,6 +1192,20 @@ __global__ void colsum_final_kernel(const float* part, int nparts, int C, float*
     out[c] = acc;
 }
 
+// planes[p][i] (bf16, p = 0 h, 1 m, 2 l; plane stride n elements) of the fp32 array w[n]: the same split as split_pair, done once
+// per filter and step instead of once per workgroup and chunk
+__global__ __launch_bounds__(256) void filter_presplit_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ planes) {
+    const long n8 = n >> 3, pstride = n >> 1;                        // plane stride in dwords (2 bf16 per dword)
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long)gridDim.x * 256) {
+        const float4 a = ld4(w + g * 8), b = ld4(w + g * 8 + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const Planes q = split8(x);
+        *reinterpret_cast<u32x4_t*>(planes + g * 4) = q.h;
+        *reinterpret_cast<u32x4_t*>(planes + pstride + g * 4) = q.m;
+        *reinterpret_cast<u32x4_t*>(planes + 2 * pstride + g * 4) = q.l;
+    }
+}
+
 // ---------------------------------------------------------------------------------- host side
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
 int launch_gather(GatherParams& p, hipStream_t st) {
@@ -1188,6 +1256,24 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
 #define SEGMI_LAUNCH_DMA(FASTV, MATHV) \
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, FASTV, MATHV>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes)
+    if (p.wplanes) {
+        // pre-split filter planes (bf16x3 only; the caller checked presplit_ok): three bf16 planes of BN rows x 64 B per stage
+        if constexpr (BN % 64 == 0) {
+            const size_t ldsp = (size_t)2 * (BM * 128 + BN * 192);
+            static bool attr_set[2] = {false, false};      // benign race: idempotent
+            if (!attr_set[fast ? 1 : 0] && ldsp > 64 * 1024) {
+                if (fast) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3_PRE>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                else      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3_PRE>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                attr_set[fast ? 1 : 0] = true;
+            }
+            if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3_PRE>), grid, dim3(256), ldsp, st, p, src_bytes, wgt_bytes);
+            else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3_PRE>), grid, dim3(256), ldsp, st, p, src_bytes, wgt_bytes);
+        } else {
+            return SEGMI_ERR_BADARG;
+        }
+    } else
     switch (conv_math() * 2 + (fast ? 1 : 0)) {
         case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_DMA(true, MATH_F32); break;
         case MATH_F32 * 2:               SEGMI_LAUNCH_DMA(false, MATH_F32); break;
@@ -1202,6 +1288,15 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, (const float*)p.ws, p.dst, n4, p.ksplit, n4);
     }
     return segmi_launch_status();
+}
+
+int g_presplit = -1;  // SEGMI_CONV_PRESPLIT=0: bf16x3 splits the filter operand in registers too (A/B of the pre-split planes)
+bool conv_presplit() {
+    if (g_presplit < 0) {
+        const char* e = getenv("SEGMI_CONV_PRESPLIT");
+        g_presplit = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_presplit == 1;
 }
 
 int g_dma = -1;  // SEGMI_CONV_DMA=0 forces the register-staged kernels (A/B testing)
@@ -1230,7 +1325,8 @@ bool dma_half_m(int M, int Cd) {
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
-    const unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
+    unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
+    if (p.wplanes) wb = 3u * p.plane_bytes;                                    // three bf16 planes (presplit_ok bounded them)
     if (conv_dma() && sb && wb) {
         const bool half_m = dma_half_m(p.M, p.Cd);
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
@@ -1364,14 +1460,15 @@ size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d) {
     return fs.ksplit > 1 ? (size_t)fs.ksplit * d->N * d->P * d->Q * d->ldy * sizeof(float) : 0;
 }
 
-int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                     int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
-    if (!desc_ok(d) || !x || !w || !y) return SEGMI_ERR_BADARG;
-    if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < ((d->K + 3) & ~3) || !aligned16(x) || !aligned16(w) ||
-        !aligned16(y))
+static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w, const void* planes, const float* bias, float* y,
+                         int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!desc_ok(d) || !x || (!w && !planes) || !y) return SEGMI_ERR_BADARG;
+    if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < ((d->K + 3) & ~3) || !aligned16(x) ||
+        !aligned16(planes ? planes : (const void*)w) || !aligned16(y))
         return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = x; p.wgt = w; p.bias = bias; p.dst = y;
+    p.wplanes = planes; p.plane_bytes = planes ? (unsigned)((long)d->K * d->R * d->S * d->C * 2) : 0u;
     p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.Cs = d->C; p.lds = d->ldx;
     p.Hd = d->P; p.Wd = d->Q; p.Cd = d->K; p.ldd = d->ldy;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -1385,15 +1482,24 @@ int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, c
     return dispatch_gather<MODE_FPROP>(p, (hipStream_t)stream);
 }
 
-int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
-                       segmi_stream_t stream) {
-    if (!desc_ok(d) || !dy || !w_crsk || !dx) return SEGMI_ERR_BADARG;
+int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                     int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!w) return SEGMI_ERR_BADARG;
+    return conv_fwd_impl(d, x, w, nullptr, bias, y, accumulate, workspace, workspace_bytes, stream);
+}
+
+static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const float* w_crsk, const void* planes, float* dx, int accumulate,
+                           segmi_stream_t stream) {
+    if (!desc_ok(d) || !dy || (!w_crsk && !planes) || !dx) return SEGMI_ERR_BADARG;
     // the reduction axis is K here: the caller pads it to a multiple of 4 (Kpad = round_up(K,4) <= ldy)
     const int Kpad = (d->K + 3) & ~3;
-    if ((d->ldy & 3) || d->ldy < Kpad || (d->ldx & 3) || d->ldx < ((d->C + 3) & ~3) || !aligned16(dy) || !aligned16(w_crsk) || !aligned16(dx))
+    if ((d->ldy & 3) || d->ldy < Kpad || (d->ldx & 3) || d->ldx < ((d->C + 3) & ~3) || !aligned16(dy) ||
+        !aligned16(planes ? planes : (const void*)w_crsk) || !aligned16(dx))
         return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = dy; p.wgt = w_crsk; p.bias = nullptr; p.dst = dx;
+    p.wplanes = planes; p.plane_bytes = planes ? (unsigned)((long)d->C * d->R * d->S * Kpad * 2) : 0u;
+    if (planes && d->stride != 1) return SEGMI_ERR_BADARG;
     p.N = d->N; p.Hs = d->P; p.Ws = d->Q; p.Cs = Kpad; p.lds = d->ldy;
     p.Hd = d->H; p.Wd = d->W; p.Cd = d->C; p.ldd = d->ldx;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -1429,6 +1535,50 @@ int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w
             if (rc != SEGMI_OK) return rc;
         }
     return SEGMI_OK;
+}
+
+int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                       segmi_stream_t stream) {
+    if (!w_crsk) return SEGMI_ERR_BADARG;
+    return conv_dgrad_impl(d, dy, w_crsk, nullptr, dx, accumulate, stream);
+}
+
+// ---- bf16x3 with the FILTER pre-split into bf16 planes (half of the loop's split work moves to one small kernel per step)
+int segmi_conv_set_presplit(int on) { g_presplit = on ? 1 : 0; return SEGMI_OK; }
+
+int segmi_conv2d_presplit_ok(const segmi_conv_desc* d, int op) {
+    if (!desc_ok(d) || conv_math() != MATH_BF16X3 || !conv_dma() || !conv_presplit()) return 0;
+    const int Kpad = (d->K + 3) & ~3;
+    const int Cs = op == 0 ? d->C : Kpad, Cd = op == 0 ? d->K : d->C;
+    if (op != 0 && (op != 1 || d->stride != 1)) return 0;
+    if ((Cs & 7) || Cd <= 32) return 0;                               // 16-byte plane pieces = 8 channels; 64/128-wide output tiles only
+    const long n = (long)Cd * d->R * d->S * Cs;
+    if (!span32(n * 6 / 4)) return 0;                                 // three bf16 planes behind one 32-bit buffer descriptor
+    if (op == 0) return dma_eligible_fwd(d) ? 1 : 0;
+    return (span32((long)d->N * d->P * d->Q * d->ldy) && span32((long)d->C * d->R * d->S * Kpad)) ? 1 : 0;
+}
+
+size_t segmi_filter_presplit_bytes(long n) { return n > 0 ? (size_t)n * 6 : 0; }
+
+int segmi_filter_presplit(const float* w, long n, void* planes, segmi_stream_t stream) {
+    if (!w || !planes || n <= 0 || (n & 7)) return SEGMI_ERR_BADARG;
+    if (!aligned16(w) || !aligned16(planes)) return SEGMI_ERR_ALIGN;
+    long nb = (n / 8 + 255) / 256;
+    if (nb > SEGMI_MAX_GRID * 4) nb = SEGMI_MAX_GRID * 4;
+    hipLaunchKernelGGL(filter_presplit_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, n, (unsigned*)planes);
+    return segmi_launch_status();
+}
+
+int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
+                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!w_planes || !segmi_conv2d_presplit_ok(d, 0)) return SEGMI_ERR_BADARG;
+    return conv_fwd_impl(d, x, nullptr, w_planes, bias, y, accumulate, workspace, workspace_bytes, stream);
+}
+
+int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
+                                segmi_stream_t stream) {
+    if (!w_crsk_planes || !segmi_conv2d_presplit_ok(d, 1)) return SEGMI_ERR_BADARG;
+    return conv_dgrad_impl(d, dy, nullptr, w_crsk_planes, dx, accumulate, stream);
 }
 
 size_t segmi_conv2d_wgrad_workspace(const segmi_conv_desc* d) {
@@ -1488,7 +1638,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
         snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %d>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
-                 fast ? "true" : "false", conv_math());
+                 fast ? "true" : "false", segmi_conv2d_presplit_ok(d, op) ? (int)MATH_BF16X3_PRE : conv_math());
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;

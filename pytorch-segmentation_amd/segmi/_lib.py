@@ -37,6 +37,12 @@ SIGNATURES = {
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_conv2d_variant": (i32, [PD, i32, C.c_char_p, sz]),
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "segmi_conv_set_presplit": (i32, [i32]),
+    "segmi_conv2d_presplit_ok": (i32, [PD, i32]),
+    "segmi_filter_presplit_bytes": (sz, [i64]),
+    "segmi_filter_presplit": (i32, [vp, i64, vp, vp]),
+    "segmi_conv2d_fwd_presplit": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "segmi_conv2d_dgrad_presplit": (i32, [PD, vp, vp, vp, i32, vp]),
     "segmi_conv_set_math": (i32, [i32]),
     "segmi_conv_get_math": (i32, []),
     "segmi_dwconv2d_fwd": (i32, [PD, vp, vp, vp, vp]),

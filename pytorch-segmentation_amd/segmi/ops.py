@@ -208,6 +208,41 @@ def _conv_bytes(d, C):
     return 4 * (d.N * d.H * d.W * C + d.K * d.R * d.S * C + d.N * d.P * d.Q * d.K)
 
 
+def _presplit(w, n, dev):
+    """bf16x3 only: the three bf16 planes of an fp32 filter array (n elements), produced once per use by one small kernel so
+    that the convolution loop splits only its activation operand (include/segmi.h segmi_filter_presplit)."""
+    planes = torch.empty(lib.segmi_filter_presplit_bytes(n), dtype=torch.uint8, device=dev)
+    check(lib.segmi_filter_presplit(w.data_ptr(), n, planes.data_ptr(), _stream()), "filter_presplit")
+    return planes
+
+
+def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
+    """segmi_conv2d_fwd (or its pre-split-filter form when that applies) with its workspace and roofline span.
+    w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats."""
+    dev, st = x.device, _stream()
+    nws = lib.segmi_conv2d_fwd_workspace(d) if (bias is None and not accumulate) else 0
+    ws = workspace(nws, dev) if nws else None
+    wsp = ws.data_ptr() if ws is not None else None
+    bp = bias.data_ptr() if bias is not None else None
+    pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
+    with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        if pre is not None:
+            check(lib.segmi_conv2d_fwd_presplit(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
+        else:
+            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
+
+
+def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
+    """segmi_conv2d_dgrad (or its pre-split-filter form).  wt: flat CRSK filter of d.C * d.R * d.S * pad4(d.K) floats."""
+    dev, st = dy.device, _stream()
+    pre = _presplit(wt, d.C * d.R * d.S * pad4(d.K), dev) if lib.segmi_conv2d_presplit_ok(d, 1) else None
+    with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        if pre is not None:
+            check(lib.segmi_conv2d_dgrad_presplit(d, dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
+        else:
+            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -222,11 +257,7 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, K, P, Q, x.device)
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
-        nws = lib.segmi_conv2d_fwd_workspace(d) if bias is None else 0
-        ws = workspace(nws, x.device) if nws else None
-        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                       y.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, _stream()), "conv2d_fwd")
+        _conv_fwd(d, C, x, w, bias, y)
         ctx.save_for_backward(x, weight)
         ctx.geom = (N, C, H, W, K, R, S, P, Q, stride, pad, dil)
         ctx.has_bias = bias is not None
@@ -247,8 +278,7 @@ class _Conv2dFn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
             dx = empty_nhwc(N, C, H, W, x.device)
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
-            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-                check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "conv2d_dgrad")
+            _conv_dgrad(d, C, dy, wt, dx)
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
@@ -301,8 +331,7 @@ class _Conv2dSkipFn(torch.autograd.Function):
         wt = torch.empty(Ce * R * S * Kp, device=x.device, dtype=torch.float32)
         check(lib.segmi_filter_krsc_to_crsk(w.data_ptr(), wt.data_ptr(), K, R, S, Ce, Kp, st), "krsc_to_crsk")
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dskip), ld_of(dy))
-        with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dskip.data_ptr(), 1, st), "conv2d_dgrad(+=)")
+        _conv_dgrad(d, C, dy, wt, dskip, accumulate=1)
         dw = None
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
@@ -740,9 +769,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
             check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, c0, c, 1, fs.data_ptr(), st), "filter_slice")
             t = torch.empty((N, b, b, 9 * K), device=dev, dtype=torch.float32)
             d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, c, 9 * K)
-            nws = lib.segmi_conv2d_fwd_workspace(d)
-            ws = workspace(nws, dev) if nws else None
-            _conv_call(0, d, c, p.data_ptr(), fs.data_ptr(), None, t.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st)
+            _conv_fwd(d, c, p, fs, None, t)
             Ts.append(t)
             c0 += c
         nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, barr)
@@ -750,7 +777,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         tp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in Ts])
         check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, barr, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(y))
-        _conv_call(0, d, Cx, x.data_ptr(), fx.data_ptr(), None, y.data_ptr(), 1, None, 0, st)        # accumulate onto the pyramid part
+        _conv_fwd(d, Cx, x, fx, None, y, accumulate=1)                                                # accumulate onto the pyramid part
         ctx.save_for_backward(x, weight, *ps)
         ctx.geom = (N, Cx, H, W, K, Ct, tuple(cs), tuple(bins))
         return y
@@ -773,7 +800,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(fx.data_ptr(), wt.data_ptr(), K, 3, 3, Cx, K, st), "krsc_to_crsk")
             dx = empty_nhwc(N, Cx, H, W, dev)
             d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(dx), ld_of(dy))
-            _conv_call(1, d, Cx, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st)
+            _conv_dgrad(d, Cx, dy, wt, dx)
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(dy))
         nws = lib.segmi_conv2d_wgrad_workspace(d)
         ws = workspace(nws, dev) if nws else None
@@ -798,9 +825,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
                 # dp = G x F as a FORWARD 1x1 convolution over G's 9K channels (filter = F transposed): the forward kernel splits
                 # the 4608-long reduction over the chip, the dgrad entry would walk it in 4 workgroups
                 d = ConvDesc(N, b, b, 9 * K, c, 1, 1, b, b, 1, 0, 1, 9 * K, ld_of(dp))
-                nws = lib.segmi_conv2d_fwd_workspace(d)
-                ws = workspace(nws, dev) if nws else None
-                _conv_call(0, d, 9 * K, g.data_ptr(), wt.data_ptr(), None, dp.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st)
+                _conv_fwd(d, 9 * K, g, wt, None, dp)
             dps.append(dp)
             d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, ld_of(p), 9 * K)
             nws = lib.segmi_conv2d_wgrad_workspace(d)

@@ -89,13 +89,26 @@ def test_conv_math_switch_and_variant_names():
                 ops.set_conv_math(name)
         ops.set_conv_math("bf16x3")
         assert lib.segmi_conv_get_math() == 1
-        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>"
-        assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true, 1>"
+        # fprop / dgrad read the filter as pre-split bf16 planes where that applies (template argument 2) ...
+        assert lib.segmi_conv2d_presplit_ok(d, 0) == 1 and lib.segmi_conv2d_presplit_ok(d, 1) == 1
+        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 2>"
+        assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true, 2>"
         assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true, 1>")
+        # ... and fall back to the in-register split otherwise: switched off, channels not a multiple of 8, strided dgrad
+        lib.segmi_conv_set_presplit(0)
+        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>" and lib.segmi_conv2d_presplit_ok(d, 1) == 0
+        lib.segmi_conv_set_presplit(1)
+        assert lib.segmi_conv2d_presplit_ok(ConvDesc(8, 64, 64, 36, 512, 3, 3, 64, 64, 1, 1, 1, 36, 512), 0) == 0
+        assert lib.segmi_conv2d_presplit_ok(ConvDesc(8, 64, 64, 512, 512, 3, 3, 32, 32, 2, 1, 1, 512, 512), 1) == 0
+        assert lib.segmi_filter_presplit_bytes(1024) == 6 * 1024
         # workspace planning does not depend on the arithmetic
         assert lib.segmi_conv2d_wgrad_workspace(d) % (512 * 9 * 512 * 4) == 0
     finally:
+        lib.segmi_conv_set_presplit(1)
         ops.set_conv_math(prev)
+    ops.set_conv_math("f32")
+    assert lib.segmi_conv2d_presplit_ok(d, 0) == 0          # the fp32 MFMA path never takes planes
+    ops.set_conv_math(prev)
 
 
 def test_conv_kernels_are_compiled_without_scratch(tmp_path):
@@ -117,8 +130,9 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
         kern[name]["agpr_count"] = int(blk.split()[0])
     dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
-    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]   # last template argument = MATH (0 f32, 1 bf16x3)
-    assert per_math == [28, 28, 0, 0, 0], per_math
+    # last template argument = MATH: 0 f32, 1 bf16x3, 2 bf16x3 with pre-split filter planes (fprop / dgrad, 64- and 128-wide tiles)
+    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]
+    assert per_math == [28, 28, 16, 0, 0], per_math
     for n, v in dma.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
         # .vgpr_count is the unified total (arch VGPRs up to the accumulator offset + AGPRs); 2 x 256 = one SIMD's file

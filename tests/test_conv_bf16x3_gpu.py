@@ -172,3 +172,43 @@ def test_bf16x3_network_level_accuracy_over_seeds(cuda):
     assert mean["bf16x3"][0] <= 1.5 * mean["f32"][0] + 1e-7, mean
     for n in ("f32", "bf16x3"):
         assert mean[n][0] <= 3.0 * mean["cpu32"][0] + 1e-7 and mean[n][1] <= 3.0 * mean["cpu32"][1] + 1e-7, (n, mean)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 20, 24, 128, 3, 1, 1, 1), (4, 256, 32, 32, 256, 3, 1, 2, 2), (2, 128, 16, 16, 256, 1, 1, 0, 1),
+                                  (8, 2048, 2, 2, 512, 1, 1, 0, 1), (2, 72, 15, 15, 40, 3, 1, 1, 1), (1, 512, 9, 9, 64, 1, 1, 0, 1)])
+def test_bf16x3_presplit_filter_is_bit_identical(cuda, case):
+    """bf16x3 with the filter operand pre-split into bf16 planes once per call (segmi_filter_presplit + the *_presplit entry
+    points: only the activation operand is split inside the loop) gives BIT-IDENTICAL outputs and data gradients to the
+    in-register split: same planes, same six products, same order.  Covers 128- and 64-wide output tiles, 64-row tiles, forward
+    split-K, ragged tiles; a case whose channels are not a multiple of 8 must fall back (presplit_ok == 0)."""
+    from segmi import lib, ops
+    from segmi._lib import ConvDesc
+    N, C, H, W, K, R, stride, pad, dil = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    prev = ops.get_conv_math()
+    res = {}
+    try:
+        ops.set_conv_math("bf16x3")
+        P = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        d = ConvDesc(N, H, W, ops.pad4(C), K, R, R, P, P if H == W else (W + 2 * pad - dil * (R - 1) - 1) // stride + 1, stride, pad, dil, ops.pad4(C), ops.pad4(K))
+        for on in (1, 0):
+            assert lib.segmi_conv_set_presplit(on) == 0
+            ok = (lib.segmi_conv2d_presplit_ok(d, 0), lib.segmi_conv2d_presplit_ok(d, 1))
+            xd = x.to(cuda).requires_grad_(True)
+            wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            yd = ops.conv2d(xd, wd, None, stride, pad, dil)
+            gy = torch.randn(yd.shape, generator=torch.Generator().manual_seed(3)).to(cuda)
+            yd.backward(gy)
+            res[on] = (ok, yd.detach().clone(), xd.grad.clone(), wd.grad.clone())
+    finally:
+        lib.segmi_conv_set_presplit(1)
+        ops.set_conv_math(prev)
+    assert res[0][0] == (0, 0)
+    if C % 8 == 0:
+        assert res[1][0][0] == 1 and (res[1][0][1] == 1) == (ops.pad4(K) % 8 == 0 and C > 32)
+    else:
+        assert res[1][0][0] == 0
+    for a, b in zip(res[1][1:], res[0][1:]):
+        assert torch.equal(a, b)
