@@ -39,15 +39,16 @@ class KernelTimer:
         self.details.append(detail)
 
     def by_detail(self):
-        """[(name, detail, launches, total_ms, flops)] grouped by (name, detail), slowest first (synchronises)."""
+        """[(name, detail, launches, total_ms, flops, bytes)] grouped by (name, detail), slowest first (synchronises)."""
         torch.cuda.synchronize()
         acc = {}
-        for (name, flops, _, a, b), det in zip(self.spans, self.details):
-            r = acc.setdefault((name, det), [0, 0.0, 0])
+        for (name, flops, nbytes, a, b), det in zip(self.spans, self.details):
+            r = acc.setdefault((name, det), [0, 0.0, 0, 0])
             r[0] += 1
             r[1] += a.elapsed_time(b)
             r[2] += flops
-        return sorted(((k[0], k[1], v[0], v[1], v[2]) for k, v in acc.items()), key=lambda t: -t[3])
+            r[3] += nbytes
+        return sorted(((k[0], k[1], v[0], v[1], v[2], v[3]) for k, v in acc.items()), key=lambda t: -t[3])
 
     def summary(self):
         """{name: {"launches", "total_ms", "avg_us", "flops", "bytes"}} (synchronises)."""
