@@ -236,19 +236,21 @@ int segmi_dropout(const float* x, int ldx, float* y, int ldy, int N, long HW, in
  *                                   with rows ordered (k, rs) (rs_major = 0: itself a KRSC filter) or (rs, k) (rs_major = 1:
  *                                   the 1x1 filter whose output channel rs*K + k is T's layout); unslice scatters a gradient
  *                                   slice back into the full KRSC gradient.
- *   segmi_pyramid_up_fwd          : y[n,h,w,k] = sum_l sum_{r,s} bilinear(align_corners=True, b_l x b_l -> H x W) of
+ *   segmi_pyramid_up_fwd          : y[n,h,w,k] = sum_l sum_{r,s} bilinear(align_corners=True, bh_l x bw_l -> H x W) of
  *                                   T_l[n, :, :, (r*3+s)*K + k] evaluated at (h+r-1, w+s-1), zero outside the map (the 3x3
- *                                   convolution's padding).  T_l: [N, b_l, b_l, 9K] dense.  y is OVERWRITTEN (pixel stride ldy).
+ *                                   convolution's padding).  T_l: [N, bh_l, bw_l, 9K] dense.  y is OVERWRITTEN (pixel stride ldy).
+ *                                   (Also the DeepLab decoder's upsample + concat + 3x3, models/deeplabv3_plus.py:323-330: one
+ *                                   "level" of 33 x 33 nodes.)
  *   segmi_pyramid_up_bwd          : the transpose: G_l (same layout as T_l) from dy [N, H, W, K] (pixel stride lddy).
  * Workspace (both directions): segmi_pyramid_up_workspace, 16-byte aligned.  K % 4 == 0, at most 4 levels. */
 int segmi_filter_slice(const float* w_krsc, int K, int RS, int Ctot, int c0, int Cs, int rs_major, float* out, segmi_stream_t stream);
 int segmi_filter_unslice(const float* grad_slice, int K, int RS, int Ctot, int c0, int Cs, int rs_major, float* dw_krsc,
                          segmi_stream_t stream);
-size_t segmi_pyramid_up_workspace(int N, int H, int W, int K, int nlevels, const int* bins);
-int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int nlevels, const int* bins, float* y, int ldy,
-                         void* workspace, size_t workspace_bytes, segmi_stream_t stream);
-int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins, float* const* G,
-                         void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+size_t segmi_pyramid_up_workspace(int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w);
+int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w, float* y,
+                         int ldy, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w,
+                         float* const* G, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 
 /* ------------------------------------------------------------------ training-time augmentation */
 /* The cv2 / PIL sequence of BaseDataSet._augmentation + __getitem__ (base/base_dataset.py:63-136) on the device, one call per

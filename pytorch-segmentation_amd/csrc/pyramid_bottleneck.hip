@@ -29,15 +29,15 @@ namespace {
 
 constexpr int PB_MAX = 4;
 struct PbGeom {
-    int N, H, W, K, nl, nrow;     // nrow = sum of bins
-    int bins[PB_MAX], off[PB_MAX];
+    int N, H, W, K, nl, nrow, ncol;              // nrow = sum of bh (row nodes of all stages), ncol = sum of bw
+    int bh[PB_MAX], bw[PB_MAX], offh[PB_MAX], offw[PB_MAX];
 };
 struct PbPtrs { const float* t[PB_MAX]; float* g[PB_MAX]; };
 
-__device__ __forceinline__ int pb_stage(const PbGeom& g, int ii) {
+__device__ __forceinline__ int pb_stage(const PbGeom& g, const int (&off)[PB_MAX], int ii) {
     int s = 0;
 #pragma unroll
-    for (int q = 1; q < PB_MAX; ++q) s += (q < g.nl && ii >= g.off[q]) ? 1 : 0;
+    for (int q = 1; q < PB_MAX; ++q) s += (q < g.nl && ii >= off[q]) ? 1 : 0;
     return s;
 }
 __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) { a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w; }
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void pyr_up_w_kernel(PbGeom g, PbPtrs p, float
         long q = row / g.W;
         const int r = (int)(q % 3); q /= 3;
         const int ii = (int)(q % g.nrow), n = (int)(q / g.nrow);
-        const int s = pb_stage(g, ii), b = g.bins[s], i = ii - g.off[s];
+        const int s = pb_stage(g, g.offh, ii), b = g.bw[s], i = ii - g.offh[s];
         const float sc = bl_scale(b, g.W, 1);
-        const float* base = p.t[s] + ((long)(n * b + i) * b) * ldt + k4 * 4;
+        const float* base = p.t[s] + ((long)(n * g.bh[s] + i) * b) * ldt + k4 * 4;
         float4 acc = zero4();
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx) {
@@ -83,14 +83,14 @@ __global__ __launch_bounds__(256) void pyr_up_h_kernel(PbGeom g, const float* __
         const int h = (int)(q % g.H), n = (int)(q / g.H);
         float4 acc = zero4();
         for (int s = 0; s < g.nl; ++s) {
-            const int b = g.bins[s];
+            const int b = g.bh[s];
             const float sc = bl_scale(b, g.H, 1);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int hp = h + r - 1;
                 if (hp < 0 || hp >= g.H) continue;
                 const Lerp L = bl_src(hp, sc, b, 1);
-                const float* vp = V + ((((long)n * g.nrow + g.off[s]) * 3 + r) * g.W + w) * g.K + k4 * 4;
+                const float* vp = V + ((((long)n * g.nrow + g.offh[s]) * 3 + r) * g.W + w) * g.K + k4 * 4;
                 fma4(acc, L.l0, ld4(vp + (long)L.i0 * 3 * g.W * g.K));
                 if (L.l1 != 0.f) fma4(acc, L.l1, ld4(vp + (long)L.i1 * 3 * g.W * g.K));
             }
@@ -104,13 +104,13 @@ __global__ __launch_bounds__(256) void pyr_dn_w_kernel(PbGeom g, const float* __
     const int k4n = g.K >> 2;
     const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (k4 >= k4n) return;
-    const long rows = (long)g.N * g.H * g.nrow * 3;
+    const long rows = (long)g.N * g.H * g.ncol * 3;
     for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
         const int sx = (int)(row % 3);
         long q = row / 3;
-        const int jj = (int)(q % g.nrow);
-        const long nh = q / g.nrow;                                   // n*H + h
-        const int s = pb_stage(g, jj), b = g.bins[s], j = jj - g.off[s];
+        const int jj = (int)(q % g.ncol);
+        const long nh = q / g.ncol;                                   // n*H + h
+        const int s = pb_stage(g, g.offw, jj), b = g.bw[s], j = jj - g.offw[s];
         const float sc = bl_scale(b, g.W, 1);
         int lo, hi;
         bl_range(j, sc, b, g.W, 1, lo, hi);                           // interpolated positions wp that can touch node j
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void pyr_dn_h_kernel(PbGeom g, const float* __
     const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (k4 >= k4n) return;
     int nodes = 0;
-    for (int s = 0; s < g.nl; ++s) nodes += g.bins[s] * g.bins[s];
+    for (int s = 0; s < g.nl; ++s) nodes += g.bh[s] * g.bw[s];
     const long rows = (long)g.N * nodes * 9;
     const int ldt = 9 * g.K;
     for (long row = (long)blockIdx.y * blockDim.y + threadIdx.y; row < rows; row += (long)gridDim.y * blockDim.y) {
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void pyr_dn_h_kernel(PbGeom g, const float* __
         int node = (int)(q % nodes);
         const int n = (int)(q / nodes);
         int s = 0;
-        while (node >= g.bins[s] * g.bins[s]) { node -= g.bins[s] * g.bins[s]; ++s; }
-        const int b = g.bins[s], i = node / b, j = node - i * b;
+        while (node >= g.bh[s] * g.bw[s]) { node -= g.bh[s] * g.bw[s]; ++s; }
+        const int b = g.bh[s], bwid = g.bw[s], i = node / bwid, j = node - i * bwid;
         const float sc = bl_scale(b, g.H, 1);
         int lo, hi;
         bl_range(i, sc, b, g.H, 1, lo, hi);
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void pyr_dn_h_kernel(PbGeom g, const float* __
             if (h < 0 || h >= g.H) continue;
             const Lerp L = bl_src(hp, sc, b, 1);
             const float wt = (L.i0 == i ? L.l0 : 0.f) + (L.i1 == i ? L.l1 : 0.f);
-            if (wt != 0.f) fma4(acc, wt, ld4(U + ((((long)n * g.H + h) * g.nrow + g.off[s] + j) * 3 + sx) * g.K + k4 * 4));
+            if (wt != 0.f) fma4(acc, wt, ld4(U + ((((long)n * g.H + h) * g.ncol + g.offw[s] + j) * 3 + sx) * g.K + k4 * 4));
         }
-        st4(p.g[s] + ((long)(n * b + i) * b + j) * ldt + rs * g.K + k4 * 4, acc);
+        st4(p.g[s] + ((long)(n * b + i) * bwid + j) * ldt + rs * g.K + k4 * 4, acc);
     }
 }
 
@@ -175,13 +175,15 @@ __global__ __launch_bounds__(256) void filter_slice_kernel(const float* __restri
     }
 }
 
-bool pb_geom(int N, int H, int W, int K, int nl, const int* bins, PbGeom* g) {
-    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || (K & 3) || nl < 1 || nl > PB_MAX || !bins) return false;
-    g->N = N; g->H = H; g->W = W; g->K = K; g->nl = nl; g->nrow = 0;
-    for (int s = 0; s < PB_MAX; ++s) { g->bins[s] = 1; g->off[s] = 0; }
+bool pb_geom(int N, int H, int W, int K, int nl, const int* bins_h, const int* bins_w, PbGeom* g) {
+    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || (K & 3) || nl < 1 || nl > PB_MAX || !bins_h || !bins_w) return false;
+    g->N = N; g->H = H; g->W = W; g->K = K; g->nl = nl; g->nrow = 0; g->ncol = 0;
+    for (int s = 0; s < PB_MAX; ++s) { g->bh[s] = g->bw[s] = 1; g->offh[s] = g->offw[s] = 0; }
     for (int s = 0; s < nl; ++s) {
-        if (bins[s] < 1 || bins[s] > 64) return false;
-        g->bins[s] = bins[s]; g->off[s] = g->nrow; g->nrow += bins[s];
+        if (bins_h[s] < 1 || bins_h[s] > 256 || bins_w[s] < 1 || bins_w[s] > 256) return false;
+        g->bh[s] = bins_h[s]; g->bw[s] = bins_w[s];
+        g->offh[s] = g->nrow; g->nrow += bins_h[s];
+        g->offw[s] = g->ncol; g->ncol += bins_w[s];
     }
     return true;
 }
@@ -208,18 +210,19 @@ int segmi_filter_unslice(const float* grad_slice, int K, int RS, int Ctot, int c
     return segmi_launch_status();
 }
 
-size_t segmi_pyramid_up_workspace(int N, int H, int W, int K, int nlevels, const int* bins) {
+size_t segmi_pyramid_up_workspace(int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w) {
     PbGeom g;
-    if (!pb_geom(N, H, W, K, nlevels, bins, &g)) return 0;
-    return (size_t)N * g.nrow * 3 * (size_t)(H > W ? H : W) * K * sizeof(float);
+    if (!pb_geom(N, H, W, K, nlevels, bins_h, bins_w, &g)) return 0;
+    const size_t v = (size_t)N * g.nrow * 3 * W, u = (size_t)N * H * g.ncol * 3;      // forward / backward intermediate rows
+    return (v > u ? v : u) * K * sizeof(float);
 }
 
-int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int nlevels, const int* bins, float* y, int ldy,
-                         void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w, float* y,
+                         int ldy, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     PbGeom g;
-    if (!T || !y || !pb_geom(N, H, W, K, nlevels, bins, &g)) return SEGMI_ERR_BADARG;
+    if (!T || !y || !pb_geom(N, H, W, K, nlevels, bins_h, bins_w, &g)) return SEGMI_ERR_BADARG;
     if ((ldy & 3) || ldy < K) return SEGMI_ERR_ALIGN;
-    if (!workspace || workspace_bytes < segmi_pyramid_up_workspace(N, H, W, K, nlevels, bins) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < segmi_pyramid_up_workspace(N, H, W, K, nlevels, bins_h, bins_w) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
     PbPtrs p;
     for (int s = 0; s < PB_MAX; ++s) { p.t[s] = s < nlevels ? T[s] : nullptr; p.g[s] = nullptr; if (s < nlevels && !T[s]) return SEGMI_ERR_BADARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -231,19 +234,19 @@ int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int 
     return segmi_launch_status();
 }
 
-int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins, float* const* G,
-                         void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w,
+                         float* const* G, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     PbGeom g;
-    if (!dy || !G || !pb_geom(N, H, W, K, nlevels, bins, &g)) return SEGMI_ERR_BADARG;
+    if (!dy || !G || !pb_geom(N, H, W, K, nlevels, bins_h, bins_w, &g)) return SEGMI_ERR_BADARG;
     if ((lddy & 3) || lddy < K) return SEGMI_ERR_ALIGN;
-    if (!workspace || workspace_bytes < segmi_pyramid_up_workspace(N, H, W, K, nlevels, bins) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < segmi_pyramid_up_workspace(N, H, W, K, nlevels, bins_h, bins_w) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
     PbPtrs p;
     int nodes = 0;
     for (int s = 0; s < PB_MAX; ++s) { p.t[s] = nullptr; p.g[s] = s < nlevels ? G[s] : nullptr; if (s < nlevels && !G[s]) return SEGMI_ERR_BADARG; }
-    for (int s = 0; s < nlevels; ++s) nodes += bins[s] * bins[s];
+    for (int s = 0; s < nlevels; ++s) nodes += bins_h[s] * bins_w[s];
     hipStream_t st = (hipStream_t)stream;
     float* U = (float*)workspace;
-    RowGeom a = row_geom((long)N * H * g.nrow * 3, K, 1, SEGMI_MAX_GRID);
+    RowGeom a = row_geom((long)N * H * g.ncol * 3, K, 1, SEGMI_MAX_GRID);
     hipLaunchKernelGGL(pyr_dn_w_kernel, a.grid, a.block, 0, st, g, dy, lddy, U);
     RowGeom b = row_geom((long)N * nodes * 9, K, 1, SEGMI_MAX_GRID);
     hipLaunchKernelGGL(pyr_dn_h_kernel, b.grid, b.block, 0, st, g, (const float*)U, p);

@@ -300,8 +300,17 @@ class Decoder(nn.Module):
             snn.Conv2d(256, num_classes, 1, stride=1))
         initialize_weights(self)
 
+    factored = os.environ.get("SEGMI_DECODER_FACTORED", "1") != "0"      # A/B switch; the literal form is the test reference
+
     def forward(self, x, low_level_features):
         low = self.bn1(self.conv1(low_level_features), relu=True)
+        conv = self.output[0]
+        if self.factored and low.shape[1] % 4 == 0 and x.shape[1] % 4 == 0 and conv.weight.is_contiguous(memory_format=torch.channels_last):
+            # upsample(x) -> cat -> 3x3 convolution in factored form (segmi.ops.pyramid_bottleneck_conv): the
+            # convolution proper runs over the 48 low-level channels; the 256 upsampled channels contribute through a 1x1 GEMM on
+            # the low-resolution map and a separable interpolation — 84 % of this layer's MACs and the upsampled map disappear
+            y = ops.pyramid_bottleneck_conv(low, [x], conv.weight)
+            return snn.run_fused(list(self.output)[1:], y)
         x = ops.interpolate_bilinear(x, (low.size(2), low.size(3)), align_corners=True)
         return self.output(ops.cat([low, x]))
 

@@ -75,9 +75,9 @@ SIGNATURES = {
     "segmi_dropout": (i32, [vp, i32, vp, i32, i32, i64, i32, f32, i32, u64, vp, vp]),
     "segmi_filter_slice": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "segmi_filter_unslice": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "segmi_pyramid_up_workspace": (sz, [i32, i32, i32, i32, i32, vp]),
-    "segmi_pyramid_up_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
-    "segmi_pyramid_up_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "segmi_pyramid_up_workspace": (sz, [i32, i32, i32, i32, i32, vp, vp]),
+    "segmi_pyramid_up_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]),
+    "segmi_pyramid_up_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp]),
     "segmi_aug_rotate": (i32, [vp, vp, i32, i32, C.POINTER(f32), vp, vp, vp]),
     "segmi_aug_blur": (i32, [vp, i32, i32, i32, C.POINTER(f32), vp, vp, vp]),

@@ -751,31 +751,31 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         K, Ct, R, S = weight.shape
         ps = [to_nhwc(p, "pyramid_bottleneck") for p in ps]
         cs = [p.shape[1] for p in ps]
-        bins = [p.shape[2] for p in ps]
+        bins = [(int(p.shape[2]), int(p.shape[3])) for p in ps]          # (rows, columns) of every low-resolution map
         if (R, S) != (3, 3) or Ct != Cx + sum(cs) or not weight.is_contiguous(memory_format=torch.channels_last) or (weight.data_ptr() & 15):
             raise SegmiError("pyramid_bottleneck: needs a channels_last 3x3 filter over %d + %s channels, got %s" % (Cx, cs, tuple(weight.shape)))
-        if (Cx & 3) or (K & 3) or any(c & 3 for c in cs) or any(p.shape[2] != p.shape[3] or ld_of(p) != p.shape[1] for p in ps) or len(ps) > 4:
-            raise SegmiError("pyramid_bottleneck: channel counts must be multiples of 4 and the pyramid maps square and dense")
+        if (Cx & 3) or (K & 3) or any(c & 3 for c in cs) or any(ld_of(p) != p.shape[1] for p in ps) or len(ps) > 4:
+            raise SegmiError("pyramid_bottleneck: channel counts must be multiples of 4, the low-resolution maps dense, at most 4 of them")
         dev, st = x.device, _stream()
         nl = len(ps)
-        barr = (ctypes.c_int * nl)(*bins)
+        bh, bw = (ctypes.c_int * nl)(*[b[0] for b in bins]), (ctypes.c_int * nl)(*[b[1] for b in bins])
         # contiguous operands: the x-channel slice as a KRSC filter, each pyramid slice as a 1x1 filter with rows (rs, k)
         fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
         check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
         y = empty_nhwc(N, K, H, W, dev)
         Ts, c0 = [], Cx
-        for p, c, b in zip(ps, cs, bins):
+        for p, c, (b, b2) in zip(ps, cs, bins):
             fs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)
             check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, c0, c, 1, fs.data_ptr(), st), "filter_slice")
-            t = torch.empty((N, b, b, 9 * K), device=dev, dtype=torch.float32)
-            d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, c, 9 * K)
+            t = torch.empty((N, b, b2, 9 * K), device=dev, dtype=torch.float32)
+            d = ConvDesc(N, b, b2, c, 9 * K, 1, 1, b, b2, 1, 0, 1, c, 9 * K)
             _conv_fwd(d, c, p, fs, None, t)
             Ts.append(t)
             c0 += c
-        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, barr)
+        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, bh, bw)
         ws = workspace(nws + 16, dev)
         tp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in Ts])
-        check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, barr, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
+        check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, bh, bw, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(y))
         _conv_fwd(d, Cx, x, fx, None, y, accumulate=1)                                                # accumulate onto the pyramid part
         ctx.save_for_backward(x, weight, *ps)
@@ -789,7 +789,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         dy = to_nhwc(dy, "pyramid_bottleneck.backward")
         dev, st = x.device, _stream()
         nl = len(ps)
-        barr = (ctypes.c_int * nl)(*bins)
+        bh, bw = (ctypes.c_int * nl)(*[b[0] for b in bins]), (ctypes.c_int * nl)(*[b[1] for b in bins])
         dwb = torch.empty(K * 9 * Ct, device=dev, dtype=torch.float32)          # full KRSC gradient, filled slice by slice
         fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
         check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
@@ -808,26 +808,26 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         _conv_call(2, d, Cx, x.data_ptr(), dy.data_ptr(), dfx.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st)
         check(lib.segmi_filter_unslice(dfx.data_ptr(), K, 9, Ct, 0, Cx, 0, dwb.data_ptr(), st), "filter_unslice")
         # ---- pyramid branches: G_l = dT_l by the transposed interpolation, then the 1x1 convolution's dgrad / wgrad
-        Gs = [torch.empty((N, b, b, 9 * K), device=dev, dtype=torch.float32) for b in bins]
-        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, barr)
+        Gs = [torch.empty((N, b, b2, 9 * K), device=dev, dtype=torch.float32) for b, b2 in bins]
+        nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, bh, bw)
         ws = workspace(nws + 16, dev)
         gp = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in Gs])
-        check(lib.segmi_pyramid_up_bwd(dy.data_ptr(), ld_of(dy), N, H, W, K, nl, barr, gp, (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_bwd")
+        check(lib.segmi_pyramid_up_bwd(dy.data_ptr(), ld_of(dy), N, H, W, K, nl, bh, bw, gp, (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_bwd")
         dps, c0 = [], Cx
-        for li, (p, c, b, g) in enumerate(zip(ps, cs, bins, Gs)):
+        for li, (p, c, (b, b2), g) in enumerate(zip(ps, cs, bins, Gs)):
             fs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)
             check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, c0, c, 1, fs.data_ptr(), st), "filter_slice")
             dp = None
             if ctx.needs_input_grad[2 + li]:
                 wt = torch.empty(c * 9 * K, device=dev, dtype=torch.float32)
                 check(lib.segmi_filter_krsc_to_crsk(fs.data_ptr(), wt.data_ptr(), 9 * K, 1, 1, c, 9 * K, st), "krsc_to_crsk")
-                dp = empty_nhwc(N, c, b, b, dev)
+                dp = empty_nhwc(N, c, b, b2, dev)
                 # dp = G x F as a FORWARD 1x1 convolution over G's 9K channels (filter = F transposed): the forward kernel splits
                 # the 4608-long reduction over the chip, the dgrad entry would walk it in 4 workgroups
-                d = ConvDesc(N, b, b, 9 * K, c, 1, 1, b, b, 1, 0, 1, 9 * K, ld_of(dp))
+                d = ConvDesc(N, b, b2, 9 * K, c, 1, 1, b, b2, 1, 0, 1, 9 * K, ld_of(dp))
                 _conv_fwd(d, 9 * K, g, wt, None, dp)
             dps.append(dp)
-            d = ConvDesc(N, b, b, c, 9 * K, 1, 1, b, b, 1, 0, 1, ld_of(p), 9 * K)
+            d = ConvDesc(N, b, b2, c, 9 * K, 1, 1, b, b2, 1, 0, 1, ld_of(p), 9 * K)
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, dev) if nws else None
             dfs = torch.empty(9 * K * c, device=dev, dtype=torch.float32)

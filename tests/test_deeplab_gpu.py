@@ -104,3 +104,35 @@ def test_deeplab_frozen_bn_all_gradients_match_oracle(cuda, backbone, os_, shape
     errs.sort()
     print("gradient rel-L2 error vs fp64 oracle: median %.2e max %.2e" % (errs[len(errs) // 2], errs[-1]))
     assert errs[len(errs) // 2] <= 1e-3
+
+
+def test_deeplab_factored_and_literal_decoder_agree(cuda, monkeypatch):
+    """The DeepLab decoder's upsample + concat + 3x3 convolution in factored form (ops.pyramid_bottleneck_conv with one 4x-coarser,
+    non-square map) against the literal interpolate -> cat -> conv path: logits, loss and every parameter gradient (frozen BN)."""
+    import models
+    from models.deeplabv3_plus import Decoder
+    from utils.losses import CrossEntropyLoss2d
+    classes = 6
+    tmpl = models.DeepLab(classes, backbone="resnet50", pretrained=False, output_stride=16, freeze_bn=True)
+    sd = synth_state_dict([(k, tuple(v.shape)) for k, v in tmpl.state_dict().items()], seed=8)
+    x, t = synth_batch(2, 3, 129, 161, classes, seed=12)
+    res = {}
+    for factored in (False, True):
+        monkeypatch.setattr(Decoder, "factored", factored)
+        m = models.DeepLab(classes, backbone="resnet50", pretrained=False, output_stride=16, freeze_bn=True)
+        m.load_state_dict(sd)
+        m.to(cuda).train()
+        m.freeze_bn()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        out = m(x.to(cuda))
+        loss = CrossEntropyLoss2d(ignore_index=255)(out, t.to(cuda))
+        loss.backward()
+        res[factored] = (out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    (o0, l0, g0), (o1, l1, g1) = res[False], res[True]
+    assert (o0 - o1).abs().max().item() <= 1e-4 * o0.abs().max().item()
+    assert abs(l0 - l1) < 1e-5
+    for k in g0:
+        e = (g0[k] - g1[k]).norm().item() / (g0[k].norm().item() + 1e-30)
+        assert e <= 1e-3, (k, e)

@@ -172,7 +172,8 @@ def test_pspnet_batch_stat_gradients_within_reference_noise_floor(cuda):
     assert max(e_hip) <= 3.0 * max(e_ref) + 1e-3
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 24, 24, 32, (1, 2, 3, 6)), (1, 32, 13, 17, 16, (1, 2, 3, 6)), (2, 16, 8, 8, 8, (2, 5)), (1, 128, 33, 33, 64, (1, 2, 3, 6))])
+@pytest.mark.parametrize("shape", [(2, 64, 24, 24, 32, (1, 2, 3, 6)), (1, 32, 13, 17, 16, (1, 2, 3, 6)), (2, 16, 8, 8, 8, (2, 5)), (1, 128, 33, 33, 64, (1, 2, 3, 6)),
+                                   (2, 48, 33, 41, 32, ((9, 11),)), (1, 48, 65, 65, 64, ((17, 17),))])     # DeepLab decoder: one rectangular 4x-coarser map
 def test_factored_psp_bottleneck_equals_cat_conv(cuda, shape):
     """ops.pyramid_bottleneck_conv (csrc/pyramid_bottleneck.hip: convolution over the feature channels + per-branch GEMM +
     separable interpolation) against the literal reference expression
@@ -181,10 +182,11 @@ def test_factored_psp_bottleneck_equals_cat_conv(cuda, shape):
     import torch.nn.functional as F
     from segmi import ops
     N, Cx, H, W, K, bins = shape
-    cs = Cx // 4
+    bins = [b if isinstance(b, tuple) else (b, b) for b in bins]
+    cs = Cx // 4 if len(bins) > 1 else 40
     g = torch.Generator().manual_seed(4)
     x = torch.randn(N, Cx, H, W, generator=g)
-    ps = [torch.randn(N, cs, b, b, generator=g) for b in bins]
+    ps = [torch.randn(N, cs, b[0], b[1], generator=g) for b in bins]
     w = torch.randn(K, Cx + cs * len(bins), 3, 3, generator=g) * (2.0 / (9 * (Cx + cs * len(bins)))) ** 0.5
     xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     pr = [p.double().requires_grad_(True) for p in ps]
@@ -196,7 +198,7 @@ def test_factored_psp_bottleneck_equals_cat_conv(cuda, shape):
     pd = [ops.to_nhwc(p.to(cuda)).requires_grad_(True) for p in ps]
     yd = ops.pyramid_bottleneck_conv(xd, pd, wd)
     yd.backward(gy.to(cuda))
-    pairs = [("y", yd, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad)] + [("dp%d" % b, a.grad, r.grad) for b, a, r in zip(bins, pd, pr)]
+    pairs = [("y", yd, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad)] + [("dp%dx%d" % b, a.grad, r.grad) for b, a, r in zip(bins, pd, pr)]
     for name, a, r in pairs:
         err = (a.detach().cpu().double() - r.detach()).abs().max().item()
         assert err <= 1e-4 * r.abs().max().item(), (name, err, r.abs().max().item())
