@@ -152,6 +152,18 @@ def _filter_krsc(w, Ce):
     return out
 
 
+def _filter_grad_buffer(w, Ce):
+    """(flat KRSC buffer for the wgrad kernel, gradient tensor or None).  When the filter itself is KRSC in memory and needs no
+    channel padding, the buffer IS the gradient tensor with the parameter's own (dense) strides — an owning tensor, not a view,
+    so autograd's AccumulateGrad adopts it instead of cloning it (44 device copies per PSPNet-R50 step otherwise)."""
+    K, C, R, S = w.shape
+    if Ce == C and _filter_is_krsc(w):
+        mf = torch.channels_last if (R > 1 or S > 1 or not w.is_contiguous()) else torch.contiguous_format
+        dw = torch.empty((K, C, R, S), device=w.device, dtype=torch.float32, memory_format=mf)
+        return dw, dw
+    return torch.empty(K * R * S * Ce, device=w.device, dtype=torch.float32), None
+
+
 def _filter_grad_like(dw_krsc, w, Ce):
     """[K,R,S,Ce] wgrad buffer -> gradient tensor with weight's shape and memory layout."""
     K, C, R, S = w.shape
@@ -283,11 +295,11 @@ class _Conv2dFn(torch.autograd.Function):
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, x.device) if nws else None
-            dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
+            dwb, dw_owned = _filter_grad_buffer(weight, Ce)
             with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
-            dw = _filter_grad_like(dwb, weight, Ce)
+            dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             rows = N * P * Q
             nws = lib.segmi_colsum_workspace(rows, K)
@@ -337,11 +349,11 @@ class _Conv2dSkipFn(torch.autograd.Function):
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, x.device) if nws else None
-            dwb = torch.empty(K * R * S * Ce, device=x.device, dtype=torch.float32)
+            dwb, dw_owned = _filter_grad_buffer(weight, Ce)
             with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
-            dw = _filter_grad_like(dwb, weight, Ce)
+            dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         return dskip, dw, None, None, None
 
 
@@ -790,7 +802,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         dev, st = x.device, _stream()
         nl = len(ps)
         bh, bw = (ctypes.c_int * nl)(*[b[0] for b in bins]), (ctypes.c_int * nl)(*[b[1] for b in bins])
-        dwb = torch.empty(K * 9 * Ct, device=dev, dtype=torch.float32)          # full KRSC gradient, filled slice by slice
+        dwb = torch.empty((K, Ct, 3, 3), device=dev, dtype=torch.float32, memory_format=torch.channels_last)   # KRSC memory, filled slice by slice
         fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
         check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
         # ---- feature channels: plain dgrad / wgrad of the 3x3 convolution over Cx channels
@@ -834,7 +846,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
             _conv_call(2, d, c, p.data_ptr(), g.data_ptr(), dfs.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st)
             check(lib.segmi_filter_unslice(dfs.data_ptr(), K, 9, Ct, c0, c, 1, dwb.data_ptr(), st), "filter_unslice")
             c0 += c
-        dw = dwb.view(K, 3, 3, Ct).permute(0, 3, 1, 2) if ctx.needs_input_grad[1] else None
+        dw = dwb if ctx.needs_input_grad[1] else None
         return (dx, dw) + tuple(dps)
 
 
