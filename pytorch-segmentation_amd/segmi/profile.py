@@ -15,19 +15,69 @@ _ACTIVE = None
 _NULL = contextlib.nullcontext()
 
 
+def _b4(*elems):
+    return 4 * sum(int(e) for e in elems)
+
+
+# HBM-bound entry points of the C ABI -> algorithmic bytes of one call, from its positional arguments (include/segmi.h order):
+# every tensor the call must read or write crosses HBM once.  Used by KernelTimer(membound=True), which times these calls
+# with HIP events exactly like the convolutions (tools/membound_ops.py prints the table).
+MEMBOUND_BYTES = {
+    "segmi_bn_stats_finalize": lambda a: _b4(a[2] * a[3]),
+    "segmi_bn_stats": lambda a: _b4(a[2] * a[3]),
+    "segmi_bn_apply": lambda a: _b4((2 + (a[2] is not None)) * a[6] * a[7]),
+    "segmi_bn_bwd_reduce": lambda a: _b4((2 + (a[4] is not None)) * a[6] * a[7]),
+    "segmi_bn_bwd_apply": lambda a: _b4((3 + (a[4] is not None) + (a[19] is not None)) * a[6] * a[7]),
+    "segmi_maxpool_fwd": lambda a: _b4(a[5] * a[8] * (a[6] * a[7] + a[9] * a[10])) + a[5] * a[8] * a[9] * a[10],
+    "segmi_maxpool_bwd": lambda a: _b4(a[5] * a[8] * (a[6] * a[7] + a[9] * a[10])) + a[5] * a[8] * a[9] * a[10],
+    "segmi_pyramid_pool_fwd": lambda a: _b4(a[2] * a[3] * a[4] * a[5]),
+    "segmi_pyramid_pool_bwd": lambda a: _b4(a[4] * a[5] * a[6] * a[7]),
+    "segmi_pyramid_up_fwd": lambda a: _b4(a[1] * a[2] * a[3] * a[4]),
+    "segmi_pyramid_up_bwd": lambda a: _b4(a[2] * a[3] * a[4] * a[5]),
+    "segmi_upsample_ce_fwd": lambda a: 12 * a[2] * a[6] * a[7] + _b4(a[2] * a[3] * a[4] * a[5]),
+    "segmi_upsample_ce_bwd": lambda a: 12 * a[2] * a[6] * a[7] + _b4(2 * a[2] * a[6] * a[4] * ((a[5] + 3) & ~3), 2 * a[2] * a[3] * a[4] * a[5]),
+    "segmi_ce_fwd": lambda a: _b4(a[3] * a[4]) + 12 * a[3],
+    "segmi_ce_bwd": lambda a: _b4(2 * a[4] * a[5]) + 12 * a[4],
+    "segmi_bilinear_fwd": lambda a: _b4(a[4] * a[7] * (a[5] * a[6] + a[8] * a[9])),
+    "segmi_bilinear_bwd": lambda a: _b4(a[4] * a[7] * (a[5] * a[6] + a[8] * a[9])),
+    "segmi_dropout": lambda a: _b4(2 * a[4] * a[5] * a[6]),
+    "segmi_copy_rows": lambda a: _b4(2 * a[4] * a[5]),
+    "segmi_nchw_to_nhwc": lambda a: _b4(2 * a[2] * a[3] * a[4] * a[5]),
+    "segmi_relu_fwd": lambda a: _b4(2 * a[4] * a[5]),
+    "segmi_add": lambda a: _b4(3 * a[6] * a[7]),
+}
+
+
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, membound=False):
         self.spans = []   # (name, flops, bytes, start_event, end_event)
         self.details = []
+        self.membound = membound
+        self._patched = {}
 
     def __enter__(self):
         global _ACTIVE
         self._prev, _ACTIVE = _ACTIVE, self
+        if self.membound:
+            from ._lib import lib      # the ctypes functions are attributes of the CDLL object: swap in timing wrappers
+            for name, nbytes in MEMBOUND_BYTES.items():
+                fn = getattr(lib, name)
+                self._patched[name] = fn
+
+                def wrapper(*args, _fn=fn, _name=name, _nb=nbytes):
+                    with self._span(_name, 0, _nb(args)):
+                        return _fn(*args)
+                setattr(lib, name, wrapper)
         return self
 
     def __exit__(self, *exc):
         global _ACTIVE
         _ACTIVE = self._prev
+        if self._patched:
+            from ._lib import lib
+            for name, fn in self._patched.items():
+                setattr(lib, name, fn)
+            self._patched = {}
 
     @contextlib.contextmanager
     def _span(self, name, flops, nbytes, detail=None):
