@@ -205,12 +205,13 @@ int segmi_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, i
 /* Fused pyramid pooling: the <= 4 AdaptiveAvgPool2d(b) of the PSP module (models/pspnet.py:25-37, bins 1,2,3,6) over ONE
  * read of x (cell sums over the union of all window boundaries, then assembly), and their backward as ONE write of dx from
  * the small dy tensors (instead of four full-size gradient maps that autograd adds).  `bins`, `y`/`dy`, `ldy` are HOST
- * arrays of nlevels entries (device pointers inside); bins[l] <= 8. */
+ * arrays of nlevels entries (device pointers inside); bins[l] <= 8.  Both directions use a workspace of
+ * segmi_pyramid_pool_workspace bytes (per-cell sums forward, per-cell gradients backward), 16-byte aligned. */
 size_t segmi_pyramid_pool_workspace(int N, int H, int W, int C, int nlevels, const int* bins);
 int segmi_pyramid_pool_fwd(const float* x, int ldx, int N, int H, int W, int C, int nlevels, const int* bins, float* const* y,
                            const int* ldy, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 int segmi_pyramid_pool_bwd(const float* const* dy, const int* lddy, float* dx, int lddx, int N, int H, int W, int C,
-                           int nlevels, const int* bins, segmi_stream_t stream);
+                           int nlevels, const int* bins, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* aten::upsample_bilinear2d (+bwd), align_corners in {0,1}: models/pspnet.py:35-36,86,91;
  * models/deeplabv3_plus.py:291,328,361; models/unet.py:46-47.  bwd is the exact transpose in
  * gather form (deterministic, no atomics), evaluated separably (width pass into the workspace, then height pass). */

@@ -298,34 +298,46 @@ __global__ __launch_bounds__(256) void pyramid_assemble_kernel(const float* __re
     st4(p.y[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
 }
 
-// dx[n,h,w,c] = sum_l sum_{windows (i,j) of level l containing (h,w)} dy_l[n,i,j,c] / area
-__global__ __launch_bounds__(256) void pyramid_bwd_kernel(float* __restrict__ dx, int lddx, PyrGeom g, PyrPtrs p) {
+// dx[n,h,w,c] = sum_l sum_{windows (i,j) of level l containing (h,w)} dy_l[n,i,j,c] / area.  All pixels of a cell (the map cut at
+// every window boundary of every level: <= 24 x 24 cells) receive the SAME value, so it is computed once per (n, cell, channel)
+// — the nested window search — and the full-size pass only looks its cell up and streams the gradient out (a per-pixel search
+// made this write-only kernel instruction-bound: 250 us for 268 MB at cfg2, 13 % of the HBM rate).
+__global__ __launch_bounds__(256) void pyramid_bwd_cells_kernel(float* __restrict__ cellgrad, PyrGeom g, PyrPtrs p) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= g.C || threadIdx.y) return;
+    const int cell = blockIdx.y, n = blockIdx.z;
+    const int sh = cell / g.aw.nseg, sw = cell - sh * g.aw.nseg;
+    float4 acc = zero4();
+    for (int l = 0; l < g.nl; ++l) {
+        const int b = g.bins[l];
+        for (int i = 0; i < b; ++i) {
+            if (sh < g.ah.lo[l][i] || sh >= g.ah.hi[l][i]) continue;
+            const int hh = g.ah.brk[g.ah.hi[l][i]] - g.ah.brk[g.ah.lo[l][i]];
+            for (int j = 0; j < b; ++j) {
+                if (sw < g.aw.lo[l][j] || sw >= g.aw.hi[l][j]) continue;
+                const float inv = 1.f / (float)(hh * (g.aw.brk[g.aw.hi[l][j]] - g.aw.brk[g.aw.lo[l][j]]));
+                const float4 v = ld4(p.dy[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4);
+                acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
+            }
+        }
+    }
+    const int Cp = (g.C + 3) & ~3;
+    st4(cellgrad + ((long)(n * g.ah.nseg + sh) * g.aw.nseg + sw) * Cp + c4 * 4, acc);
+}
+
+__global__ __launch_bounds__(256) void pyramid_bwd_expand_kernel(const float* __restrict__ cellgrad, float* __restrict__ dx, int lddx, PyrGeom g) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 * 4 >= g.C) return;
+    const int Cp = (g.C + 3) & ~3;
     const long rows = (long)g.N * g.H * g.W;
     for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
         const int w = (int)(r % g.W);
         const long t = r / g.W;
         const int h = (int)(t % g.H), n = (int)(t / g.H);
-        // the pixel's cell (no divisions: <= 24 breakpoints per axis), then every window whose segment range covers the cell
-        int sh = 0, sw = 0;
+        int sh = 0, sw = 0;                                  // the pixel's cell (no divisions: <= 24 breakpoints per axis)
         while (g.ah.brk[sh + 1] <= h) ++sh;
         while (g.aw.brk[sw + 1] <= w) ++sw;
-        float4 acc = zero4();
-        for (int l = 0; l < g.nl; ++l) {
-            const int b = g.bins[l];
-            for (int i = 0; i < b; ++i) {
-                if (sh < g.ah.lo[l][i] || sh >= g.ah.hi[l][i]) continue;
-                const int hh = g.ah.brk[g.ah.hi[l][i]] - g.ah.brk[g.ah.lo[l][i]];
-                for (int j = 0; j < b; ++j) {
-                    if (sw < g.aw.lo[l][j] || sw >= g.aw.hi[l][j]) continue;
-                    const float inv = 1.f / (float)(hh * (g.aw.brk[g.aw.hi[l][j]] - g.aw.brk[g.aw.lo[l][j]]));
-                    const float4 v = ld4(p.dy[l] + ((long)(n * b + i) * b + j) * p.ld[l] + c4 * 4);
-                    acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
-                }
-            }
-        }
-        st4(dx + r * lddx + c4 * 4, acc);
+        st4(dx + r * lddx + c4 * 4, ld4(cellgrad + ((long)(n * g.ah.nseg + sh) * g.aw.nseg + sw) * Cp + c4 * 4));
     }
 }
 
@@ -486,17 +498,21 @@ int segmi_pyramid_pool_fwd(const float* x, int ldx, int N, int H, int W, int C, 
 }
 
 int segmi_pyramid_pool_bwd(const float* const* dy, const int* lddy, float* dx, int lddx, int N, int H, int W, int C, int nlevels,
-                           const int* bins, segmi_stream_t stream) {
+                           const int* bins, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     PyrGeom g;
-    if (!dy || !lddy || !dx || !pyr_geom(N, H, W, C, nlevels, bins, &g)) return SEGMI_ERR_BADARG;
+    if (!dy || !lddy || !dx || !pyr_geom(N, H, W, C, nlevels, bins, &g) || N > 65535) return SEGMI_ERR_BADARG;
     if (!ldok(lddx, C)) return SEGMI_ERR_ALIGN;
+    if (!workspace || workspace_bytes < segmi_pyramid_pool_workspace(N, H, W, C, nlevels, bins) || ((uintptr_t)workspace & 15)) return SEGMI_ERR_WORKSPACE;
     PyrPtrs p;
     for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
         p.y[l] = nullptr; p.dy[l] = l < nlevels ? dy[l] : nullptr; p.ld[l] = l < nlevels ? lddy[l] : 0;
         if (l < nlevels && (!dy[l] || !ldok(lddy[l], C))) return dy[l] ? SEGMI_ERR_ALIGN : SEGMI_ERR_BADARG;
     }
+    hipStream_t st = (hipStream_t)stream;
+    RowGeom cg = row_geom(1, C, 1, 1);
+    hipLaunchKernelGGL(pyramid_bwd_cells_kernel, dim3(cg.grid.x, (unsigned)(g.ah.nseg * g.aw.nseg), (unsigned)N), cg.block, 0, st, (float*)workspace, g, p);
     RowGeom rg = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID);
-    hipLaunchKernelGGL(pyramid_bwd_kernel, rg.grid, rg.block, 0, (hipStream_t)stream, dx, lddx, g, p);
+    hipLaunchKernelGGL(pyramid_bwd_expand_kernel, rg.grid, rg.block, 0, st, (const float*)workspace, dx, lddx, g);
     return segmi_launch_status();
 }
 

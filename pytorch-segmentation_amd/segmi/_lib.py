@@ -106,7 +106,7 @@ SIGNATURES = {
     "segmi_sgd_step_dev": (i32, [vp, i32, vp, vp]),
     "segmi_pyramid_pool_workspace": (sz, [i32, i32, i32, i32, i32, vp]),
     "segmi_pyramid_pool_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
-    "segmi_pyramid_pool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "segmi_pyramid_pool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
 }
 
 

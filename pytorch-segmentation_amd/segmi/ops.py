@@ -731,7 +731,10 @@ class _PyramidPoolFn(torch.autograd.Function):
         dp = (ctypes.c_void_p * nl)(*[d.data_ptr() for d in dys])
         ld = (ctypes.c_int * nl)(*[ld_of(d) for d in dys])
         barr = (ctypes.c_int * nl)(*bins)
-        check(lib.segmi_pyramid_pool_bwd(dp, ld, dx.data_ptr(), ld_of(dx), N, H, W, C, nl, barr, _stream()), "pyramid_pool_bwd")
+        nws = lib.segmi_pyramid_pool_workspace(N, H, W, C, nl, barr)
+        ws = workspace(nws + 16, dev)
+        check(lib.segmi_pyramid_pool_bwd(dp, ld, dx.data_ptr(), ld_of(dx), N, H, W, C, nl, barr, (ws.data_ptr() + 15) & ~15, nws, _stream()),
+              "pyramid_pool_bwd")
         return (dx,) + (None,) * nl
 
 
