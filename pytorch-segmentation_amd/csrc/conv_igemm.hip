@@ -341,7 +341,7 @@ __device__ __forceinline__ void mma_bf16x3(f32x16 (&acc)[TM][TN], const Planes (
 // keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
 // an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
 template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int MATH>
-__global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;      // wave-instructions per wave per tile (8 rows each, 4 waves)
@@ -687,8 +687,35 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
     // runtime of short-reduction (1x1, C = 256) tiles.  Each wave transposes its 64x32 column block in its own LDS slice
     // (the pipeline stages are free now) and emits 16-byte stores of 4 consecutive channels: 16 instead of 64 per lane.
     constexpr int EP = 36;                                // padded row pitch (floats) of the staging slice
+    constexpr int NQ = TM * 4;                            // 8-row store steps of the wave's TM*32 rows
     float* stage = smem + wave * (TM * 32 * EP);          // TM*32 rows x 32 columns per pass
     const int er = lane >> 3, ec = (lane & 7) * 4;        // store role: row er (+8 per step), channels ec..ec+3
+    // destination row of every store step, once for all column passes (-1: row past M)
+    long roff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int m = m0 + wm0 + q * 8 + er;
+        long pix = m;
+        if (subm) {                                       // parity-class launch: row -> (n, hc*os + ph, wc*os + pw)
+            const int hw = p.Hc * p.Wc;
+            const int n = m / hw, rem = m - n * hw;
+            const int hc = rem / p.Wc, wc = rem - hc * p.Wc;
+            pix = ((long)n * p.Hd + (hc * p.os + p.ph)) * p.Wd + (wc * p.os + p.pw);
+        }
+        roff[q] = m < p.M ? pix * p.ldd : -1;
+    }
+    // accumulate (dgrad into the gradient the residual branch already wrote): ALL of the tile's previous values are requested
+    // here, before the LDS transposition — issued one by one between the stores, as a load-wait-add-store chain per step, the
+    // 16 HBM round trips of a tile were serialised and dominated short-reduction (1x1) layers
+    float4 prev[TN][NQ];
+    if (p.accumulate) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn0 + j * 32 + ec;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) prev[j][q] = (k < cd4 && roff[q] >= 0) ? ld4(p.dst + roff[q] + k) : zero4();
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -702,25 +729,20 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(GatherParams p, unsigned 
             bv.x = k < p.Cd ? p.bias[k] : 0.f; bv.y = k + 1 < p.Cd ? p.bias[k + 1] : 0.f;
             bv.z = k + 2 < p.Cd ? p.bias[k + 2] : 0.f; bv.w = k + 3 < p.Cd ? p.bias[k + 3] : 0.f;
         }
+        float4 v[NQ];
 #pragma unroll
-        for (int q = 0; q < TM * 4; ++q) {
-            const int row = q * 8 + er;
-            const int m = m0 + wm0 + row;
-            float4 v = ld4(stage + row * EP + ec);        // same wave wrote it: LDS is in order per wave
-            if (kok && m < p.M) {
-                long pix = m;
-                if (subm) {                               // parity-class launch: row -> (n, hc*os + ph, wc*os + pw)
-                    const int hw = p.Hc * p.Wc;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int hc = rem / p.Wc, wc = rem - hc * p.Wc;
-                    pix = ((long)n * p.Hd + (hc * p.os + p.ph)) * p.Wd + (wc * p.os + p.pw);
-                }
-                float* o = p.dst + pix * p.ldd + k;
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (p.accumulate) { const float4 u = ld4(o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-                st4(o, v);
-            }
+        for (int q = 0; q < NQ; ++q) v[q] = ld4(stage + (q * 8 + er) * EP + ec);   // same wave wrote it: LDS is in order per wave
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            v[q].x += bv.x; v[q].y += bv.y; v[q].z += bv.z; v[q].w += bv.w;
+            if (p.accumulate) { v[q].x += prev[j][q].x; v[q].y += prev[j][q].y; v[q].z += prev[j][q].z; v[q].w += prev[j][q].w; }
+            // pin the finished value HERE, in straight-line code: sunk into the predicated store blocks below, every block would
+            // wait for its own operand with s_waitcnt vmcnt(0) — which on gfx9 also waits for the PREVIOUS STORE to be acknowledged
+            asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
         }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (kok && roff[q] >= 0) st4(p.dst + roff[q] + k, v[q]);
     }
 }
 
@@ -1379,22 +1401,27 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     if (lo > hi) lo = hi;
     if (lo < 1) lo = 1;
     // below 8 rounds the round quantisation is real (576 workgroups on 512 slots run as two rounds): take the first split in
-    // [lo, hi] whose last round is >= 90 % full, else the fullest
-    long ns = lo;
+    // [lo, 2*lo] whose last round is >= 97 % full, else the fullest of that window (a larger split only for > 2 % more), and
+    // beyond the window the first that is >= 90 % full
+    // (the split is realised as an integer number of chunks per workgroup, so the candidates are the distinct ceil(chunks / cps))
+    auto splits_of = [&](long cps) { return (chunks + cps - 1) / cps; };
+    long cps = (chunks + lo - 1) / lo;
     double best = -1.0;
-    for (long c = lo; c <= hi; ++c) {
-        const long wg = tiles * c;
+    for (long c = cps; c >= 1; --c) {
+        const long n = splits_of(c);
+        if (n > hi && best >= 0.0) break;
+        const long wg = tiles * n;
         const long rounds = (wg + slots - 1) / slots;
         const double eff = rounds >= 8 ? 1.0 : (double)wg / (double)(rounds * slots);
-        if (eff > best + 1e-9) { best = eff; ns = c; }
-        if (eff >= 0.9) break;
+        if (eff > best + (best < 0.9 ? 1e-9 : 0.02)) { best = eff; cps = c; }
+        if (eff >= 0.97 || (n >= 2 * lo && best >= 0.9)) break;
     }
     if (const char* e = getenv("SEGMI_WGRAD_SPLIT")) {           // tuning hook
         const long f = atol(e);
-        if (f >= 1 && f <= max_split) ns = f;
+        if (f >= 1 && f <= max_split) cps = (chunks + f - 1) / f;
     }
-    pl.chunks_per_split = (int)((chunks + ns - 1) / ns);
-    pl.nsplit = (int)((chunks + pl.chunks_per_split - 1) / pl.chunks_per_split);
+    pl.chunks_per_split = (int)cps;
+    pl.nsplit = (int)splits_of(cps);
     return pl;
 }
 
