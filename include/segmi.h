@@ -80,6 +80,18 @@ int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy
 int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
 int segmi_filter_krsc_to_crsk(const float* w_krsc, float* w_crsk, int K, int R, int S, int C, int Kpad,
                               segmi_stream_t stream);
+/* The same transposition for n filters in ONE launch (a training step needs it once per convolution and step: the filters
+ * change with every optimizer step).  `table_dev` is a DEVICE array of n entries; entry i's tile_begin is the sum of
+ * segmi_filter_tx_tiles() of the entries before it, total_tiles the sum over all of them.  Replaces the same
+ * aten::cudnn_convolution_backward_input filter handling as segmi_filter_krsc_to_crsk. */
+typedef struct segmi_filter_tx {
+    const float* w_krsc;
+    float* w_crsk;
+    int K, R, S, C, Kpad;
+    int tile_begin;
+} segmi_filter_tx;
+long segmi_filter_tx_tiles(int K, int R, int S, int C, int Kpad);
+int segmi_filter_krsc_to_crsk_multi(const segmi_filter_tx* table_dev, int n, long total_tiles, segmi_stream_t stream);
 /* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
  *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
  *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and

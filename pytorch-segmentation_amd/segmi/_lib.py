@@ -23,6 +23,12 @@ class ConvDesc(C.Structure):
 
 PD = C.POINTER(ConvDesc)
 
+
+class FilterTx(C.Structure):
+    """struct segmi_filter_tx (one entry of the batched filter transposition)"""
+    _fields_ = [("w_krsc", vp), ("w_crsk", vp), ("K", i32), ("R", i32), ("S", i32), ("C", i32), ("Kpad", i32), ("tile_begin", i32)]
+
+
 # name -> (restype, argtypes); mirrors include/segmi.h one to one (tests/test_abi.py checks it)
 SIGNATURES = {
     "segmi_strerror": (C.c_char_p, [i32]),
@@ -37,6 +43,8 @@ SIGNATURES = {
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_conv2d_variant": (i32, [PD, i32, C.c_char_p, sz]),
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "segmi_filter_tx_tiles": (i64, [i32, i32, i32, i32, i32]),
+    "segmi_filter_krsc_to_crsk_multi": (i32, [vp, i32, i64, vp]),
     "segmi_conv_set_presplit": (i32, [i32]),
     "segmi_conv2d_presplit_ok": (i32, [PD, i32]),
     "segmi_filter_presplit_bytes": (sz, [i64]),

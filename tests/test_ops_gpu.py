@@ -76,6 +76,58 @@ def test_conv2d_fwd_dgrad_wgrad(cuda, case):
             _close_rel_max(bd.grad, br.grad, 1e-4, "conv bias grad %s" % (case,))
 
 
+def test_filter_transposes_are_pooled_per_step(cuda):
+    """Every parameter-backed filter of a step is transposed for its data-gradient pass by ONE launch
+    (segmi_filter_krsc_to_crsk_multi); the pooled copies equal the single-filter kernel's bit for bit, and a second step
+    sees the filters the optimizer wrote in between."""
+    from segmi import ops
+    from segmi._lib import lib
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32, 3), (48, 64, 1), (20, 48, 3), (128, 20, 1), (36, 128, 5)]      # K, C, R — chained C -> K
+    ws = [(torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for K, C, R in shapes]
+    x = torch.randn(2, 32, 14, 15, generator=g)
+
+    def step():
+        xd = x.to(cuda).requires_grad_(True)
+        h = xd
+        for w in ws:
+            h = ops.conv2d(h, w, None, 1, w.shape[2] // 2, 1)
+        h.square().sum().backward()
+        return xd.grad.clone()
+
+    def reference():
+        xr = x.clone().requires_grad_(True)
+        h = xr
+        for w in ws:
+            h = F.conv2d(h, w.detach().cpu(), None, padding=w.shape[2] // 2)
+        h.square().sum().backward()
+        return xr.grad
+
+    tx = ops._filter_transposes
+    n0 = tx.launches
+    g1 = step()
+    assert tx.launches == n0 + 1, "expected one pooled transposition per step"
+    _close_rel_max(g1, reference(), 2e-4, "dgrad chain through pooled filters")
+    # the pooled copies are the single-filter kernel's output
+    for w in ws:
+        K, C, R, _ = w.shape
+        Kp = (K + 3) // 4 * 4
+        pooled = tx.get(w, w, K, R, R, C, Kp)
+        assert pooled is not None
+        single = torch.empty(C * R * R * Kp, device=cuda)
+        assert lib.segmi_filter_krsc_to_crsk(w.data_ptr(), single.data_ptr(), K, R, R, C, Kp, None) == 0
+        assert torch.equal(pooled, single)
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)
+            w.grad = None
+    g2 = step()
+    assert tx.launches == n0 + 2
+    _close_rel_max(g2, reference(), 2e-4, "dgrad chain after a filter update")
+    assert (g2 - g1).abs().max() > 0
+
+
 BN_CASES = [(2, 64, 9, 11), (4, 128, 7, 7), (8, 2048, 4, 4), (2, 16, 33, 35), (2, 728, 5, 5)]
 
 
