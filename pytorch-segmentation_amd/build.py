@@ -21,6 +21,8 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
+# per-file additions (see DESIGN.md §4.1b "packed-fp32 results next to another process's bf16 MFMA kernels")
+EXTRA_FLAGS = {"pool_resize.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -51,7 +53,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr))
