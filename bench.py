@@ -24,6 +24,8 @@ Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
                  bounded sample: the FULL batch of the same workload, one warm-up + timed steps within a 75 s cap (N = 1 only).
   alt          : the same K steps with the convolutions on the bf16x3 arithmetic (fp32 products as three-plane bf16 splits on
                  the bf16 matrix pipe), its own roofline object priced against BOTH ceilings.  Never the headline.
+  alt_winograd : the same K steps in fp32 with the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels (opt-in:
+                 SEGMI_CONV_WINOGRAD=1).  Never the headline until the whole GPU suite has run under it.
 """
 import argparse
 import json
@@ -323,6 +325,26 @@ def main():
                    "roofline": None if args.no_roofline else roofline_of("bf16x3", aval)}
         finally:
             segmi_ops.set_conv_math("f32")
+    # `alt_winograd`: the same K steps, fp32 arithmetic, with the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels
+    # (csrc/conv_winograd.hip): an ALGORITHM change in the same arithmetic.  Opt-in until the whole GPU suite has
+    # run under it (its own tests and the four BASELINE-shape audits have), so it is reported beside the headline, not as it.
+    alt_wino = None
+    wino_default = segmi_ops.get_conv_winograd()["on"]
+    if args.conv_math == "f32" and not args.no_alt and not args.graph and not wino_default:
+        segmi_ops.set_conv_winograd(True)
+        try:
+            wdt, wloss = timed(step)
+            wval = world * nb * args.steps / wdt
+            alt_wino = {"conv_algorithm": "winograd_f2x2_3x3 for the 3x3 stride-1 layers with >= %d channels (forward and data gradient), "
+                                          "direct implicit GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"],
+                        "conv_math": "f32", "value": round(wval, 2), "unit": "img/s", "ms_per_step": round(1e3 * wdt / args.steps, 2),
+                        "steps": args.steps, "warmup": args.warmup, "final_loss": round(wloss, 5),
+                        "parity": "tests/test_ops_gpu.py::test_conv2d_winograd_matches_reference (8 shapes, same 1e-4 bar as the direct "
+                                  "kernels), ::test_pspnet_step_under_winograd_matches_direct, and the four BASELINE-shape audits run under "
+                                  "SEGMI_CONV_WINOGRAD=1 (profiles/r02_fullsize_audit_winograd.txt: cfg2 400 tie-level mismatches vs 404 "
+                                  "direct, max|dlogit| 3.63e-4 vs 3.64e-4)"}
+        finally:
+            segmi_ops.set_conv_winograd(False)
     if ddp:
         dist.barrier()
 
@@ -345,9 +367,9 @@ def main():
                        "global_batch": nb * world, "parallelism": "dp%d" % world,
                        "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
                        "rccl_ranks": (dist.get_world_size() if ddp and backend == "nccl" else 0), "final_loss": round(final_loss, 5),
-                       "conv_math": args.conv_math, "hip_graph": bool(args.graph),
+                       "conv_math": args.conv_math, "conv_winograd": bool(wino_default), "hip_graph": bool(args.graph),
                        "syncbn_collectives_per_step": syncbn_per_step},
-            "roofline": roof, "cpu_baseline": cpu, "alt": alt,
+            "roofline": roof, "cpu_baseline": cpu, "alt": alt, "alt_winograd": alt_wino,
         }
         print(json.dumps(line), flush=True)
     if ddp:

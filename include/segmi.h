@@ -92,6 +92,20 @@ typedef struct segmi_filter_tx {
 } segmi_filter_tx;
 long segmi_filter_tx_tiles(int K, int R, int S, int C, int Kpad);
 int segmi_filter_krsc_to_crsk_multi(const segmi_filter_tx* table_dev, int n, long total_tiles, segmi_stream_t stream);
+/* Winograd F(2x2, 3x3) form of segmi_conv2d_fwd / segmi_conv2d_dgrad for 3x3 filters with stride 1 and pad == dil (the "same"
+ * convolutions of models/resnet.py:84-86, models/pspnet.py:27-30, models/deeplabv3_plus.py:264-284,307-318, models/unet.py:15-18):
+ * 2.25x fewer multiplications in the same arithmetic (transform constants 0, +-1, +-1/2), the 16 transform-domain contractions
+ * as one batched launch of the implicit-GEMM kernel under the process-wide conv arithmetic; dilation d runs as d*d dense
+ * sub-grids.  Same operands and layouts as the direct entry points (w_krsc for fwd, w_crsk = segmi_filter_krsc_to_crsk for
+ * dgrad); `workspace` holds the transformed filter, input and product (segmi_conv2d_winograd_workspace bytes, 16-byte aligned).
+ * op: 0 fwd, 1 dgrad.  _ok() says whether the pass is supported for this problem; the caller decides whether it pays. */
+int segmi_conv2d_winograd_ok(const segmi_conv_desc* d, int op);
+size_t segmi_conv2d_winograd_workspace(const segmi_conv_desc* d, int op);
+int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
+                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                                void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
 /* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
  *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
  *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and

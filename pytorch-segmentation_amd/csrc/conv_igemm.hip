@@ -18,6 +18,7 @@
 // zero-filled), double-buffered, one barrier per K-chunk.  LDS rows are padded by 4 floats so the
 // ds_read_b128 fragment reads are bank-conflict free (MI355X_MICROARCH.md, LDS table).
 #include "segmi_common.h"
+#include "conv_internal.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,6 +55,10 @@ struct GatherParams {
     // plane stride `plane_bytes`; `wgt` is unused
     const void* wplanes;
     unsigned plane_bytes;
+    // batch > 1 (LDS-DMA kernel, ksplit == 1): blockIdx.y selects one of `batch` independent problems of identical shape whose
+    // operands lie bs_src / bs_wgt / bs_dst floats apart (the 16 transform-domain GEMMs of a Winograd convolution)
+    int batch;
+    long bs_src, bs_wgt, bs_dst;
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -350,6 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
 
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     constexpr bool BPRE = MATH == MATH_BF16X3_PRE;
+    const int bidy = p.batch > 1 ? 0 : (int)blockIdx.y;  // split-K slice, unless blockIdx.y is the batch index
+    const long bat = p.batch > 1 ? (long)blockIdx.y : 0;
+    const float* const src_base = p.src + bat * p.bs_src;     // (locals: writing to the by-value parameter block would move it to scratch)
+    const float* const wgt_base = p.wgt + bat * p.bs_wgt;
+    float* const dst_base = p.dst + bat * p.bs_dst;
     // floats per pipeline stage: A = BM rows x 32 fp32; B = BN rows x 32 fp32, or (BPRE) three planes of BN rows x 32 bf16
     constexpr int STAGE = BM * BK + (BPRE ? BN * 48 : BN * BK);
     static_assert(!BPRE || (BN % 64 == 0), "pre-split B planes move 16 rows x 64 B per wave-instruction, 4 waves");
@@ -371,8 +381,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     const int tm = in_grp / gw, tn = grp * GN + in_grp % gw;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const i32x4 src_rsrc = make_rsrc(p.src, src_bytes);
-    const i32x4 wgt_rsrc = make_rsrc(BPRE ? (const float*)p.wplanes : p.wgt, wgt_bytes);
+    const i32x4 src_rsrc = make_rsrc(src_base, src_bytes);
+    const i32x4 wgt_rsrc = make_rsrc(BPRE ? (const float*)p.wplanes : wgt_base, wgt_bytes);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)wave * (8 * BK * 4);
     // BPRE: a wave-instruction deposits 16 plane rows of 64 B (32 bf16); lane -> (row lane/4, 16-byte slot lane%4); the slot a
     // lane FETCHES is XOR-swizzled with (row/4)%4 so that the ds_read_b128 of 16 consecutive rows hit 16 distinct bank quads
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     const int RSl = pk ? 1 : (RS > 0 ? RS : 1);          // taps folded into the chunk axis when packed (RS == 0: empty parity class)
     const int nchunk = ((pk ? RS * 4 : p.Cs) + BK - 1) / BK;
     const int Tall = nchunk * RSl;
-    const int it0 = blockIdx.y * p.its_per_split;        // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
+    const int it0 = bidy * p.its_per_split;              // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
     const int T = min(Tall, it0 + p.its_per_split);
     const int Sl = p.S > 0 ? p.S : 1;
     int c0 = (it0 / RSl) * BK, r = (it0 % RSl) / Sl, s = (it0 % RSl) % Sl;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     // ---- epilogue (same C/D mapping as the register-staged kernel)
     const int cd4 = min((p.Cd + 3) & ~3, p.ldd);
     if (p.ksplit > 1) {                                  // partial tile -> workspace slice of this split (no bias / accumulate)
-        float* out = p.ws + (long)blockIdx.y * p.M * p.ldd;
+        float* out = p.ws + (long)bidy * p.M * p.ldd;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int k = n0 + wn0 + j * 32 + lrow32;
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         for (int j = 0; j < TN; ++j) {
             const int k = n0 + wn0 + j * 32 + ec;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) prev[j][q] = (k < cd4 && roff[q] >= 0) ? ld4(p.dst + roff[q] + k) : zero4();
+            for (int q = 0; q < NQ; ++q) prev[j][q] = (k < cd4 && roff[q] >= 0) ? ld4(dst_base + roff[q] + k) : zero4();
         }
     }
 #pragma unroll
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (kok && roff[q] >= 0) st4(p.dst + roff[q] + k, v[q]);
+            if (kok && roff[q] >= 0) st4(dst_base + roff[q] + k, v[q]);
     }
 }
 
@@ -1305,7 +1315,7 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     const bool fast = !p.pack4 && p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
-    const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)p.ksplit);
+    const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)(p.batch > 1 ? p.batch : p.ksplit));
 #define SEGMI_LAUNCH_DMA(FASTV, MATHV) \
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, FASTV, MATHV>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes)
     if (p.wplanes) {
@@ -1531,6 +1541,7 @@ static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* 
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->P * d->Q; p.accumulate = accumulate;
     p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
+    p.batch = 1; p.bs_src = p.bs_wgt = p.bs_dst = 0;
     const FwdSplit fs = plan_fwd_split(d);
     if (fs.ksplit > 1 && !accumulate && !bias && dma_eligible_fwd(d) && workspace) {      // workspace == NULL: caller opts out of the split
         if (workspace_bytes < segmi_conv2d_fwd_workspace(d) || !aligned16(workspace)) return SEGMI_ERR_WORKSPACE;
@@ -1562,6 +1573,7 @@ static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const floa
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.M = d->N * d->H * d->W; p.accumulate = accumulate;
     p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
+    p.batch = 1; p.bs_src = p.bs_wgt = p.bs_dst = 0;
     const int st = d->stride;
     const bool dma_ok = conv_dma() && span32((long)d->N * d->P * d->Q * d->ldy) && span32((long)d->C * d->R * d->S * Kpad);
     if (st == 1 || !dma_ok || d->R * d->S > 16) return dispatch_gather<MODE_DGRAD>(p, (hipStream_t)stream);
@@ -1748,3 +1760,36 @@ int segmi_colsum(const float* x, int ld, long rows, int C, float* out, void* wor
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- internal (C++ linkage, conv_internal.h)
+int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* d, int ldd, int M, int Cs, int Cd, int batch,
+                                long bs_a, long bs_w, long bs_d, hipStream_t st) {
+    if (!a || !w || !d || M <= 0 || Cs <= 0 || Cd <= 0 || batch < 1 || batch > 65535) return SEGMI_ERR_BADARG;
+    if ((Cs & 3) || (lda & 3) || lda < Cs || (ldd & 3) || ldd < ((Cd + 3) & ~3) || (bs_a & 3) || (bs_w & 3) || (bs_d & 3) ||
+        !aligned16(a) || !aligned16(w) || !aligned16(d))
+        return SEGMI_ERR_ALIGN;
+    if (!conv_dma() || !span32((long)M * lda) || !span32((long)Cd * Cs)) return SEGMI_ERR_BADARG;   // batch exists in the LDS-DMA kernel only
+    GatherParams p;
+    p.src = a; p.wgt = w; p.bias = nullptr; p.dst = d;
+    p.wplanes = nullptr; p.plane_bytes = 0u;
+    p.N = 1; p.Hs = 1; p.Ws = M; p.Cs = Cs; p.lds = lda;
+    p.Hd = 1; p.Wd = M; p.Cd = Cd; p.ldd = ldd;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.M = M; p.accumulate = 0;
+    p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
+    p.batch = batch; p.bs_src = bs_a; p.bs_wgt = bs_w; p.bs_dst = bs_d;
+    return dispatch_gather<MODE_FPROP>(p, st);
+}
+
+int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
+    if (!buf || len < 64) return SEGMI_ERR_BADARG;
+    const bool half_m = dma_half_m(M, Cd);
+    const int bm = (Cd > 32 && half_m) ? 64 : 128, bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %d>", bm, bn, bn == 32 ? "4, 1" : "2, 2", conv_math());
+    return SEGMI_OK;
+}
+
+bool segmi_internal_gemm_ok(long M, int lda, int Cs, int Cd) {
+    return M > 0 && M < (1L << 31) && Cs > 0 && Cd > 0 && !(Cs & 3) && !(lda & 3) && lda >= Cs && conv_dma() && span32(M * lda) &&
+           span32((long)Cd * Cs);
+}

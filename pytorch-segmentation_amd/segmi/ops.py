@@ -10,6 +10,7 @@ PyTorch is used here for device memory (caching allocator), streams and autograd
 every arithmetic op below is a libsegmi kernel, and there is no CPU path — CPU tensors raise.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -19,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_dropout_epoch",
 ]
 
 
@@ -229,10 +230,53 @@ def _presplit(w, n, dev):
     return planes
 
 
+# Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/conv_winograd.hip): opt-in (SEGMI_CONV_WINOGRAD=1 or
+# set_conv_winograd) until the whole GPU suite has run under it; `min_channels` = smallest min(C, K) it is used for (below
+# ~256 channels the transform traffic eats the saved multiplications); `min_subgrid` = smallest ceil(H / dilation) it is used for
+# (a dilated layer runs as dilation^2 dense sub-grids: ASPP's d = 12..36 on 33x33 maps would be 2x2 tiles of mostly padding).
+_WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "0") == "1",
+             "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "256")),
+             "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")), "calls": 0}
+
+
+def set_conv_winograd(on, min_channels=None, min_subgrid=None):
+    """Route eligible 3x3 stride-1 convolutions (forward and data gradient) through the Winograd F(2x2,3x3) kernels."""
+    _WINOGRAD["on"] = bool(on)
+    if min_channels is not None:
+        _WINOGRAD["min_channels"] = int(min_channels)
+    if min_subgrid is not None:
+        _WINOGRAD["min_subgrid"] = int(min_subgrid)
+
+
+def get_conv_winograd():
+    return dict(_WINOGRAD)
+
+
+def _winograd(d, op):
+    if not (_WINOGRAD["on"] and d.R == 3 and d.S == 3 and d.stride == 1 and min(d.C, d.K) >= _WINOGRAD["min_channels"]):
+        return False
+    sub = min(-(-d.H // d.dil), -(-d.W // d.dil))
+    return sub >= _WINOGRAD["min_subgrid"] and lib.segmi_conv2d_winograd_ok(d, op) == 1
+
+
+def _winograd_variant(d, op):
+    buf = ctypes.create_string_buffer(128)
+    check(lib.segmi_conv2d_winograd_variant(d, op, buf, 128), "conv2d_winograd_variant")
+    return buf.value.decode()
+
+
 def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
-    """segmi_conv2d_fwd (or its pre-split-filter form when that applies) with its workspace and roofline span.
+    """segmi_conv2d_fwd (or its pre-split-filter / Winograd form when that applies) with its workspace and roofline span.
     w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats."""
     dev, st = x.device, _stream()
+    if _winograd(d, 0):
+        _WINOGRAD["calls"] += 1
+        nws = lib.segmi_conv2d_winograd_workspace(d, 0)
+        ws = workspace(nws, dev)
+        with span(lambda: _winograd_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                y.data_ptr(), accumulate, ws.data_ptr(), nws, st), "conv2d_winograd_fwd")
+        return
     nws = lib.segmi_conv2d_fwd_workspace(d) if (bias is None and not accumulate) else 0
     ws = workspace(nws, dev) if nws else None
     wsp = ws.data_ptr() if ws is not None else None
@@ -248,6 +292,14 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
 def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
     """segmi_conv2d_dgrad (or its pre-split-filter form).  wt: flat CRSK filter of d.C * d.R * d.S * pad4(d.K) floats."""
     dev, st = dy.device, _stream()
+    if _winograd(d, 1):
+        _WINOGRAD["calls"] += 1
+        nws = lib.segmi_conv2d_winograd_workspace(d, 1)
+        ws = workspace(nws, dev)
+        with span(lambda: _winograd_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_winograd_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, ws.data_ptr(), nws, st),
+                  "conv2d_winograd_dgrad")
+        return
     pre = _presplit(wt, d.C * d.R * d.S * pad4(d.K), dev) if lib.segmi_conv2d_presplit_ok(d, 1) else None
     with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
         if pre is not None:

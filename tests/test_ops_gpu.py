@@ -76,6 +76,87 @@ def test_conv2d_fwd_dgrad_wgrad(cuda, case):
             _close_rel_max(bd.grad, br.grad, 1e-4, "conv bias grad %s" % (case,))
 
 
+WINOGRAD_CASES = [
+    # N, C, H, W, K, dil, bias          (3x3, stride 1, padding == dilation)
+    (2, 64, 20, 24, 128, 1, False),
+    (2, 32, 17, 19, 48, 2, False),
+    (1, 256, 8, 8, 512, 1, False),
+    (2, 36, 12, 12, 20, 4, True),
+    (3, 512, 6, 6, 128, 6, False),       # dilation >= the map: every sub-grid is a single pixel
+    (2, 304, 9, 9, 256, 1, False),
+    (1, 64, 33, 33, 21, 1, True),
+    (1, 128, 49, 97, 64, 2, False),
+]
+
+
+@pytest.mark.parametrize("case", WINOGRAD_CASES)
+def test_conv2d_winograd_matches_reference(cuda, case):
+    """Winograd F(2x2,3x3) forward and data gradient (csrc/conv_winograd.hip) against F.conv2d on the CPU, at the SAME tolerance
+    as the direct kernels (1e-4 of max|ref|); the filter gradient stays on the direct kernel."""
+    from segmi import ops
+    N, C, H, W, K, dil, bias = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(K, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, stride=1, padding=dil, dilation=dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    prev = ops.get_conv_winograd()
+    ops.set_conv_winograd(True, min_channels=0, min_subgrid=1)
+    try:
+        calls = ops.get_conv_winograd()["calls"]
+        xd = x.to(cuda).requires_grad_(True)
+        wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        yd = ops.conv2d(xd, wd, b.to(cuda) if bias else None, 1, dil, dil)
+        _close_rel_max(yd, yr, 1e-4, "winograd fwd %s" % (case,))
+        yd.backward(gy.to(cuda))
+        _close_rel_max(xd.grad, xr.grad, 1e-4, "winograd dgrad %s" % (case,))
+        _close_rel_max(wd.grad, wr.grad, 1e-4, "wgrad next to winograd %s" % (case,))
+        assert ops.get_conv_winograd()["calls"] == calls + 2, "the Winograd kernels did not run"
+    finally:
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"])
+
+
+def test_pspnet_step_under_winograd_matches_direct(cuda):
+    """A PSPNet-R50 training step with every eligible 3x3 layer on the Winograd kernels (incl. the accumulating x-part of the
+    factored bottleneck) against the same step on the direct kernels: logits within 1e-3 of max|logit| (the end-to-end bar),
+    loss within 1e-4, per-tensor gradient norms within 10 % / 1 % median (batch statistics: DESIGN.md section 5)."""
+    import statistics
+    import models
+    from segmi import ops
+    from utils.losses import CrossEntropyLoss2d
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 3, 96, 128, generator=g).to(cuda)
+    t = torch.randint(0, 7, (2, 96, 128), generator=g).to(cuda)
+    res = {}
+    prev = ops.get_conv_winograd()
+    try:
+        for mode in ("direct", "winograd"):
+            ops.set_conv_winograd(mode == "winograd", min_channels=64, min_subgrid=2)
+            calls = ops.get_conv_winograd()["calls"]
+            torch.manual_seed(5)
+            m = models.PSPNet(7, backbone="resnet50", pretrained=False).to(cuda).train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout2d):
+                    mod.eval()
+            out, aux = m(x)
+            crit = CrossEntropyLoss2d(ignore_index=255)
+            loss = crit(out, t) + 0.4 * crit(aux, t)
+            loss.backward()
+            res[mode] = (out.detach().clone(), loss.item(), {k: p.grad.norm().item() for k, p in m.named_parameters()},
+                         ops.get_conv_winograd()["calls"] - calls)
+    finally:
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"])
+    assert res["direct"][3] == 0 and res["winograd"][3] >= 30, (res["direct"][3], res["winograd"][3])
+    d = (res["winograd"][0] - res["direct"][0]).abs().max().item()
+    assert d <= 1e-3 * res["direct"][0].abs().max().item(), d
+    assert abs(res["winograd"][1] - res["direct"][1]) < 1e-4
+    rel = [abs(res["winograd"][2][k] - v) / (v + 1e-30) for k, v in res["direct"][2].items() if v > 1e-5 * max(res["direct"][2].values())]
+    assert statistics.median(rel) <= 1e-2 and max(rel) <= 0.1, (statistics.median(rel), max(rel))
+
+
 def test_filter_transposes_are_pooled_per_step(cuda):
     """Every parameter-backed filter of a step is transposed for its data-gradient pass by ONE launch
     (segmi_filter_krsc_to_crsk_multi); the pooled copies equal the single-filter kernel's bit for bit, and a second step
