@@ -111,6 +111,53 @@ def test_conv_math_switch_and_variant_names():
     ops.set_conv_math(prev)
 
 
+def test_winograd_planning_and_dispatch_rules():
+    """Host side of the Winograd F(2x2,3x3) path (include/segmi.h segmi_conv2d_winograd_*; no GPU): which problems it accepts,
+    its workspace = transformed filter + 16 input planes + 16 product planes over T = N * dil^2 * ceil(ceil(H/dil)/2) *
+    ceil(ceil(W/dil)/2) tiles, the kernel name it reports, and the opt-in dispatch rule of segmi.ops (off by default; >= 256
+    channels and sub-grids of >= 8 pixels when on)."""
+    import ctypes
+    from segmi import lib, ops
+    from segmi._lib import ConvDesc
+
+    def desc(N, H, C, K, R, stride, pad, dil):
+        P = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        return ConvDesc(N, H, H, C, K, R, R, P, P, stride, pad, dil, C, (K + 3) & ~3)
+
+    d = desc(8, 64, 512, 512, 3, 1, 4, 4)
+    assert lib.segmi_conv2d_winograd_ok(d, 0) == 1 and lib.segmi_conv2d_winograd_ok(d, 1) == 1
+    T = 8 * 16 * 8 * 8
+    al = lambda b: (b + 255) & ~255
+    assert lib.segmi_conv2d_winograd_workspace(d, 0) == al(16 * 512 * 512 * 4) + al(16 * T * 512 * 4) + al(16 * T * 512 * 4)
+    buf = ctypes.create_string_buffer(128)
+    assert lib.segmi_conv2d_winograd_variant(d, 0, buf, 128) == 0 and buf.value.decode().startswith("winograd_f2x2_3x3 fwd: 16 x conv_dma_kernel<")
+    # odd maps: 97x97 with dilation 2 -> sub-grids of 49 / 48 rows, 25 tile rows each
+    d97 = desc(4, 97, 256, 256, 3, 1, 2, 2)
+    assert lib.segmi_conv2d_winograd_workspace(d97, 0) == al(16 * 256 * 256 * 4) + 2 * al(16 * (4 * 4 * 25 * 25) * 256 * 4)
+    # K = 21 classes: the product planes are padded to 24 columns; the data gradient contracts over the padded K
+    d21 = desc(2, 33, 64, 21, 3, 1, 1, 1)
+    T21 = 2 * 17 * 17
+    assert lib.segmi_conv2d_winograd_workspace(d21, 0) == al(16 * 21 * 64 * 4) + al(16 * T21 * 64 * 4) + al(16 * T21 * 24 * 4)
+    assert lib.segmi_conv2d_winograd_workspace(d21, 1) == al(16 * 64 * 24 * 4) + al(16 * T21 * 24 * 4) + al(16 * T21 * 64 * 4)
+    # not Winograd problems: 1x1, stride 2, padding != dilation, channels not padded to 4, unknown pass
+    for bad in (desc(8, 64, 512, 512, 1, 1, 0, 1), desc(8, 64, 512, 512, 3, 2, 1, 1), desc(8, 64, 512, 512, 3, 1, 0, 1),
+                desc(8, 64, 510, 512, 3, 1, 1, 1)):
+        assert lib.segmi_conv2d_winograd_ok(bad, 0) == 0 and lib.segmi_conv2d_winograd_workspace(bad, 0) == 0
+    assert lib.segmi_conv2d_winograd_ok(d, 2) == 0
+    # dispatch rule
+    prev = ops.get_conv_winograd()
+    try:
+        ops.set_conv_winograd(False)
+        assert not ops._winograd(d, 0)
+        ops.set_conv_winograd(True, min_channels=256, min_subgrid=8)
+        assert ops._winograd(d, 0) and ops._winograd(d, 1) and ops._winograd(d97, 0)
+        assert not ops._winograd(desc(8, 128, 128, 128, 3, 1, 1, 1), 0)            # too few channels
+        assert not ops._winograd(desc(16, 33, 2048, 256, 3, 1, 12, 12), 0)          # ASPP: sub-grids of 3 pixels
+        assert not ops._winograd(desc(8, 64, 512, 512, 3, 2, 1, 1), 0)
+    finally:
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"])
+
+
 def test_conv_kernels_are_compiled_without_scratch(tmp_path):
     """Every LDS-DMA convolution instantiation (both arithmetics) is present in the gfx950 code object, none spills
     (a spilling matrix loop would silently run at a fraction of the modelled rate) and all leave room for two workgroups

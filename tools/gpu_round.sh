@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, per-layer conv table, rocprof kernel stats.
-# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [bench] [layers] [prof] [pmc] [x3] [x3prof] [x3pmc] [graph]
+# Outputs under gpurun_out/.   usage: tools/gpu_round.sh [tests] [testswino] [bench] [layers] [prof] [pmc] [x3] [x3prof] [x3pmc] [graph]
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -76,6 +76,11 @@ testsx3)
   ( SEGMI_CONV_MATH=bf16x3 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_bf16x3.log
   ( SEGMI_CONV_MATH=bf16x3 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_bf16x3.log
   cat gpurun_out/pytest_gpu_bf16x3.log ;;
+testswino)
+  # acceptance run of Winograd F(2x2,3x3) as the algorithm of the eligible 3x3 layers: the ENTIRE gpu suite at unchanged tolerances
+  ( SEGMI_CONV_WINOGRAD=1 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_winograd.log
+  ( SEGMI_CONV_WINOGRAD=1 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_winograd.log
+  cat gpurun_out/pytest_gpu_winograd.log ;;
 testsf32)
   ( SEGMI_CONV_MATH=f32 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_f32.log
   ( SEGMI_CONV_MATH=f32 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_f32.log
