@@ -54,21 +54,13 @@ def wino_conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if dl == 1:
         y = _wino_dense(x, w)
     else:
-        N, C, H, W = x.shape
-        y = x.new_empty(N, w.shape[0], H, W)
-        parts = {}
+        # dilation d = d*d dense problems on the sub-grids (h % d, w % d); assembled out of place so that autograd sees plain adds
+        y = torch.zeros(x.shape[0], w.shape[0], x.shape[2], x.shape[3], dtype=x.dtype)
         for i in range(dl):
             for j in range(dl):
-                parts[(i, j)] = _wino_dense(x[:, :, i::dl, j::dl], w)
-        y = torch.zeros(N, w.shape[0], H, W, dtype=x.dtype)
-        rows = []
-        # scatter without in-place writes on a leaf (keeps autograd simple): build by index_put through a list
-        out = torch.zeros_like(y)
-        for (i, j), p in parts.items():
-            pad = torch.zeros_like(y)
-            pad[:, :, i::dl, j::dl] = p
-            out = out + pad
-        y = out
+                part = torch.zeros_like(y)
+                part[:, :, i::dl, j::dl] = _wino_dense(x[:, :, i::dl, j::dl], w)
+                y = y + part
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
