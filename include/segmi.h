@@ -106,6 +106,13 @@ int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const fl
 int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                                 void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
+/* Filter gradient of the same layers in the Winograd domain: dw = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G, the 16
+ * contractions over the tiles on the direct filter-gradient kernel (1x1 problems, deterministic split).  Replaces the wgrad
+ * half of convolution_backward at the sites listed above; same operands as segmi_conv2d_wgrad. */
+int segmi_conv2d_winograd_wgrad_ok(const segmi_conv_desc* d);
+size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d);
+int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
+                                size_t workspace_bytes, segmi_stream_t stream);
 /* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
  *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
  *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and

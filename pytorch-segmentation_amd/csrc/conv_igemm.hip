@@ -1153,12 +1153,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * EP + lrow32] = acc[i][j][e];
         const int c = c0 + wn0 + j * 32 + ec;
+        // all of the wave's rows first, pinned in straight-line code, then the predicated stores back to back (a store block that
+        // waits for its own LDS operand with s_waitcnt vmcnt(0) also waits for the previous store: see the fprop epilogue)
+        float4 v[TM * 4];
 #pragma unroll
         for (int q = 0; q < TM * 4; ++q) {
-            const int row = q * 8 + er;
-            const int k = k0 + wm0 + row;
-            const float4 v = ld4(stage + row * EP + ec);
-            if (c < (p.pack4 ? RS * 4 : p.C) && k < p.K) st4(out + ((long)k * RS + tap) * p.C + c, v);   // pack4: tap == 0, c runs over tap*4 + ch
+            v[q] = ld4(stage + (q * 8 + er) * EP + ec);
+            asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+        }
+#pragma unroll
+        for (int q = 0; q < TM * 4; ++q) {
+            const int k = k0 + wm0 + q * 8 + er;
+            if (c < (p.pack4 ? RS * 4 : p.C) && k < p.K) st4(out + ((long)k * RS + tap) * p.C + c, v[q]);   // pack4: tap == 0, c runs over tap*4 + ch
         }
     }
 }
@@ -1390,7 +1396,7 @@ int dispatch_gather(GatherParams& p, hipStream_t st) {
     unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
     if (p.wplanes) wb = 3u * p.plane_bytes;                                    // three bf16 planes (presplit_ok bounded them)
     if (conv_dma() && sb && wb) {
-        const bool half_m = dma_half_m(p.M, p.Cd);
+        const bool half_m = p.batch > 1 ? false : dma_half_m(p.M, p.Cd);   // a batched launch has batch x the tiles: full 128-row tiles
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
         if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
         return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, st);
@@ -1783,8 +1789,8 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
 
 int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
     if (!buf || len < 64) return SEGMI_ERR_BADARG;
-    const bool half_m = dma_half_m(M, Cd);
-    const int bm = (Cd > 32 && half_m) ? 64 : 128, bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    const int bm = 128, bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);           // batched launches always take 128-row tiles
+    (void)M;
     snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %d>", bm, bn, bn == 32 ? "4, 1" : "2, 2", conv_math());
     return SEGMI_OK;
 }

@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 }
 
 // V[xi][t][c] = (B^T d B)[xi], d = the 4x4 input patch of tile t (zero outside the image)
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, WinoGeom g, float* __restrict__ V) {
+// (planes hold Tpad >= T rows; rows T..Tpad-1 are written as zeros: the filter-gradient contraction walks whole 32-row chunks)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, WinoGeom g, long Tpad, float* __restrict__ V) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 * 4 >= C) return;
-    const long plane = g.T * (long)C;
-    for (long t = (long)blockIdx.y * blockDim.y + threadIdx.y; t < g.T; t += (long)gridDim.y * blockDim.y) {
+    const long plane = Tpad * (long)C;
+    for (long t = (long)blockIdx.y * blockDim.y + threadIdx.y; t < Tpad; t += (long)gridDim.y * blockDim.y) {
+        if (t >= g.T) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) st4(V + xi * plane + t * C + c4 * 4, zero4());
+            continue;
+        }
         const TileIdx q = tile_of(t, g);
         float4 r[4][4];
 #pragma unroll
@@ -151,6 +157,74 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// W[xi][t][k] = (A dy A^T)[xi], dy = the 2x2 output-gradient tile t (zero outside the image); rows T..Tpad-1 zero
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int lddy, int Kp, WinoGeom g, long Tpad, float* __restrict__ Wt) {
+    const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k4 * 4 >= Kp) return;
+    const long plane = Tpad * (long)Kp;
+    for (long t = (long)blockIdx.y * blockDim.y + threadIdx.y; t < Tpad; t += (long)gridDim.y * blockDim.y) {
+        float* o = Wt + t * Kp + k4 * 4;
+        if (t >= g.T) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) st4(o + xi * plane, zero4());
+            continue;
+        }
+        const TileIdx q = tile_of(t, g);
+        float4 e[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int h = (2 * q.ty + a) * g.d + q.i, w = (2 * q.tx + b) * g.d + q.j;
+                e[a][b] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.n * g.H + h) * g.W + w) * lddy + k4 * 4) : zero4();
+            }
+        // r = A e (4x2), A = [[1,0],[1,1],[1,-1],[0,-1]]
+        float4 r[4][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            r[0][b] = e[0][b];
+            r[1][b] = add4(e[0][b], e[1][b]);
+            r[2][b] = sub4(e[0][b], e[1][b]);
+            r[3][b] = sub4(zero4(), e[1][b]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            st4(o + (u * 4 + 0) * plane, r[u][0]);
+            st4(o + (u * 4 + 1) * plane, add4(r[u][0], r[u][1]));
+            st4(o + (u * 4 + 2) * plane, sub4(r[u][0], r[u][1]));
+            st4(o + (u * 4 + 3) * plane, sub4(zero4(), r[u][1]));
+        }
+    }
+}
+
+// dg[k][r][s][c] = (G^T dU[:, k, c] G)[r][s]
+__global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __restrict__ dU, int K, int C, float* __restrict__ dg) {
+    const long n = (long)K * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const long k = idx / C;
+        const int c = (int)(idx - k * C);
+        float u[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[a][b] = dU[(a * 4 + b) * n + idx];
+        float t[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+            t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+            t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float* o = dg + ((k * 3 + r) * 3) * C + c;
+            o[0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[C] = 0.5f * (t[r][1] - t[r][2]);
+            o[2 * (long)C] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
 bool wino_geom(int N, int H, int W, int d, WinoGeom* g) {
     if (N <= 0 || H <= 0 || W <= 0 || d <= 0) return false;
     g->N = N; g->H = H; g->W = W; g->d = d;
@@ -196,7 +270,7 @@ int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, i
     }
     {
         RowGeom rg = row_geom(T, pl.Cin, 1, SEGMI_MAX_GRID * 4);
-        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, src, lds, pl.Cin, pl.g, V);
+        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, src, lds, pl.Cin, pl.g, T, V);
     }
     const int rc = segmi_internal_gemm_batched(V, pl.Cin, U, Mm, pl.ldm, (int)T, pl.Cin, pl.Cout, 16, T * pl.Cin, (long)pl.Cout * pl.Cin,
                                                T * pl.ldm, st);
@@ -243,6 +317,74 @@ int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const
         ((uintptr_t)dx & 15))
         return SEGMI_ERR_ALIGN;
     return wino_run(pl, dy, d->ldy, w_crsk, 1, nullptr, dx, d->ldx, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- filter gradient: dg = G^T [ sum_tiles (A dy A^T) (.) (B^T d B) ] G; the 16 contractions over the tiles are 1x1 filter
+// gradients (x := V_xi [T, C], dy := W_xi [T, Kp]) and run on the direct filter-gradient kernel with its deterministic split
+struct WinoWgradPlan { WinoGeom g; long Tpad; int C, K, Kp; segmi_conv_desc gd; size_t v_bytes, w_bytes, u_bytes, s_bytes; };
+
+static bool wino_wgrad_plan(const segmi_conv_desc* d, WinoWgradPlan* pl) {
+    WinoPlan f;
+    if (!wino_plan(d, 0, &f)) return false;
+    pl->g = f.g;
+    pl->Tpad = (f.g.T + 31) & ~31L;
+    pl->C = d->C; pl->K = d->K; pl->Kp = (d->K + 3) & ~3;
+    if (pl->Tpad >= (1L << 31) || pl->Tpad * pl->C * 4 >= 0xFFFFFF00L || pl->Tpad * pl->Kp * 4 >= 0xFFFFFF00L) return false;
+    segmi_conv_desc& q = pl->gd;                       // one transform-domain contraction as a 1x1 filter gradient over a 1 x Tpad "image"
+    q.N = 1; q.H = 1; q.W = (int)pl->Tpad; q.C = pl->C; q.K = pl->K; q.R = 1; q.S = 1; q.P = 1; q.Q = (int)pl->Tpad;
+    q.stride = 1; q.pad = 0; q.dil = 1; q.ldx = pl->C; q.ldy = pl->Kp;
+    pl->v_bytes = align256((size_t)16 * pl->Tpad * pl->C * sizeof(float));
+    pl->w_bytes = align256((size_t)16 * pl->Tpad * pl->Kp * sizeof(float));
+    pl->u_bytes = align256((size_t)16 * pl->K * pl->C * sizeof(float));
+    pl->s_bytes = align256(segmi_conv2d_wgrad_workspace(&pl->gd));
+    return true;
+}
+
+int segmi_conv2d_winograd_wgrad_ok(const segmi_conv_desc* d) {
+    WinoWgradPlan pl;
+    return wino_wgrad_plan(d, &pl) ? 1 : 0;
+}
+
+size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d) {
+    WinoWgradPlan pl;
+    if (!wino_wgrad_plan(d, &pl)) return 0;
+    return pl.v_bytes + pl.w_bytes + pl.u_bytes + pl.s_bytes;
+}
+
+int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
+                                size_t workspace_bytes, segmi_stream_t stream) {
+    WinoWgradPlan pl;
+    if (!x || !dy || !dw_krsc || !wino_wgrad_plan(d, &pl)) return SEGMI_ERR_BADARG;
+    if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.Kp || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
+        ((uintptr_t)dw_krsc & 15))
+        return SEGMI_ERR_ALIGN;
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.v_bytes + pl.w_bytes + pl.u_bytes + pl.s_bytes)
+        return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* V = (float*)workspace;
+    float* Wt = (float*)((char*)workspace + pl.v_bytes);
+    float* dU = (float*)((char*)workspace + pl.v_bytes + pl.w_bytes);
+    void* sk = (char*)workspace + pl.v_bytes + pl.w_bytes + pl.u_bytes;
+    {
+        RowGeom rg = row_geom(pl.Tpad, pl.C, 1, SEGMI_MAX_GRID * 4);
+        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, x, d->ldx, pl.C, pl.g, pl.Tpad, V);
+    }
+    {
+        RowGeom rg = row_geom(pl.Tpad, pl.Kp, 1, SEGMI_MAX_GRID * 4);
+        hipLaunchKernelGGL(wino_dy_kernel, rg.grid, rg.block, 0, st, dy, d->ldy, pl.Kp, pl.g, pl.Tpad, Wt);
+    }
+    for (int xi = 0; xi < 16; ++xi) {
+        const int rc = segmi_conv2d_wgrad(&pl.gd, V + (long)xi * pl.Tpad * pl.C, Wt + (long)xi * pl.Tpad * pl.Kp, dU + (long)xi * pl.K * pl.C,
+                                          pl.s_bytes ? sk : nullptr, pl.s_bytes, stream);
+        if (rc != SEGMI_OK) return rc;
+    }
+    {
+        const long n = (long)pl.K * pl.C;
+        long nb = (n + 255) / 256;
+        if (nb > SEGMI_MAX_GRID * 4) nb = SEGMI_MAX_GRID * 4;
+        hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, pl.K, pl.C, dw_krsc);
+    }
+    return segmi_launch_status();
 }
 
 int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len) {

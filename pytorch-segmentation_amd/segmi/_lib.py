@@ -48,6 +48,9 @@ SIGNATURES = {
     "segmi_conv2d_winograd_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_conv2d_winograd_dgrad": (i32, [PD, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_conv2d_winograd_variant": (i32, [PD, i32, C.c_char_p, sz]),
+    "segmi_conv2d_winograd_wgrad_ok": (i32, [PD]),
+    "segmi_conv2d_winograd_wgrad_workspace": (sz, [PD]),
+    "segmi_conv2d_winograd_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_filter_tx_tiles": (i64, [i32, i32, i32, i32, i32]),
     "segmi_filter_krsc_to_crsk_multi": (i32, [vp, i32, i64, vp]),
     "segmi_conv_set_presplit": (i32, [i32]),

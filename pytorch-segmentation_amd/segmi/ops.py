@@ -236,12 +236,16 @@ def _presplit(w, n, dev):
 # (a dilated layer runs as dilation^2 dense sub-grids: ASPP's d = 12..36 on 33x33 maps would be 2x2 tiles of mostly padding).
 _WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "0") == "1",
              "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "256")),
-             "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")), "calls": 0}
+             "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")),
+             "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "0") == "1", "calls": 0}
 
 
-def set_conv_winograd(on, min_channels=None, min_subgrid=None):
-    """Route eligible 3x3 stride-1 convolutions (forward and data gradient) through the Winograd F(2x2,3x3) kernels."""
+def set_conv_winograd(on, min_channels=None, min_subgrid=None, wgrad=None):
+    """Route eligible 3x3 stride-1 convolutions (forward and data gradient; with wgrad=True also the filter gradient) through
+    the Winograd F(2x2,3x3) kernels."""
     _WINOGRAD["on"] = bool(on)
+    if wgrad is not None:
+        _WINOGRAD["wgrad"] = bool(wgrad)
     if min_channels is not None:
         _WINOGRAD["min_channels"] = int(min_channels)
     if min_subgrid is not None:
@@ -287,6 +291,23 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
             check(lib.segmi_conv2d_fwd_presplit(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
         else:
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
+
+
+def _conv_wgrad(d, C, x, dy, dwb):
+    """segmi_conv2d_wgrad (or its Winograd form when that applies) into the flat KRSC buffer dwb, with workspace and span."""
+    dev, st = x.device, _stream()
+    if _WINOGRAD["wgrad"] and _winograd(d, 0) and lib.segmi_conv2d_winograd_wgrad_ok(d) == 1:
+        _WINOGRAD["calls"] += 1
+        nws = lib.segmi_conv2d_winograd_wgrad_workspace(d)
+        ws = workspace(nws, dev)
+        with span(lambda: "winograd_f2x2_3x3 wgrad: 16 x " + conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            check(lib.segmi_conv2d_winograd_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr(), nws, st), "conv2d_winograd_wgrad")
+        return
+    nws = lib.segmi_conv2d_wgrad_workspace(d)
+    ws = workspace(nws, dev) if nws else None
+    with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st),
+              "conv2d_wgrad")
 
 
 def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
@@ -423,12 +444,8 @@ class _Conv2dFn(torch.autograd.Function):
             _conv_dgrad(d, C, dy, wt, dx)
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
-            nws = lib.segmi_conv2d_wgrad_workspace(d)
-            ws = workspace(nws, x.device) if nws else None
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-                check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
-                                             ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
+            _conv_wgrad(d, C, x, dy, dwb)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             rows = N * P * Q
@@ -476,12 +493,8 @@ class _Conv2dSkipFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
-            nws = lib.segmi_conv2d_wgrad_workspace(d)
-            ws = workspace(nws, x.device) if nws else None
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-                check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(),
-                                             ws.data_ptr() if ws is not None else None, nws, st), "conv2d_wgrad")
+            _conv_wgrad(d, C, x, dy, dwb)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         return dskip, dw, None, None, None
 
@@ -946,10 +959,8 @@ class _PyramidBottleneckFn(torch.autograd.Function):
             d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(dx), ld_of(dy))
             _conv_dgrad(d, Cx, dy, wt, dx)
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(dy))
-        nws = lib.segmi_conv2d_wgrad_workspace(d)
-        ws = workspace(nws, dev) if nws else None
         dfx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
-        _conv_call(2, d, Cx, x.data_ptr(), dy.data_ptr(), dfx.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st)
+        _conv_wgrad(d, Cx, x, dy, dfx)
         check(lib.segmi_filter_unslice(dfx.data_ptr(), K, 9, Ct, 0, Cx, 0, dwb.data_ptr(), st), "filter_unslice")
         # ---- pyramid branches: G_l = dT_l by the transposed interpolation, then the 1x1 convolution's dgrad / wgrad
         Gs = [torch.empty((N, b, b2, 9 * K), device=dev, dtype=torch.float32) for b, b2 in bins]

@@ -144,6 +144,14 @@ def test_winograd_planning_and_dispatch_rules():
                 desc(8, 64, 510, 512, 3, 1, 1, 1)):
         assert lib.segmi_conv2d_winograd_ok(bad, 0) == 0 and lib.segmi_conv2d_winograd_workspace(bad, 0) == 0
     assert lib.segmi_conv2d_winograd_ok(d, 2) == 0
+    # filter gradient in the Winograd domain: both transformed operands (tile rows padded to whole 32-row chunks), 16 product
+    # planes and the split-K scratch of ONE 1x1 contraction (the 16 run one after the other)
+    assert lib.segmi_conv2d_winograd_wgrad_ok(d) == 1 and lib.segmi_conv2d_winograd_wgrad_ok(desc(8, 64, 512, 512, 3, 2, 1, 1)) == 0
+    one = ConvDesc(1, 1, T, 512, 512, 1, 1, 1, T, 1, 0, 1, 512, 512)
+    assert lib.segmi_conv2d_winograd_wgrad_workspace(d) == 2 * al(16 * T * 512 * 4) + al(16 * 512 * 512 * 4) + al(lib.segmi_conv2d_wgrad_workspace(one))
+    T97 = (4 * 4 * 25 * 25 + 31) & ~31
+    one97 = ConvDesc(1, 1, T97, 256, 256, 1, 1, 1, T97, 1, 0, 1, 256, 256)
+    assert lib.segmi_conv2d_winograd_wgrad_workspace(d97) == 2 * al(16 * T97 * 256 * 4) + al(16 * 256 * 256 * 4) + al(lib.segmi_conv2d_wgrad_workspace(one97))
     # dispatch rule
     prev = ops.get_conv_winograd()
     try:
@@ -155,7 +163,7 @@ def test_winograd_planning_and_dispatch_rules():
         assert not ops._winograd(desc(16, 33, 2048, 256, 3, 1, 12, 12), 0)          # ASPP: sub-grids of 3 pixels
         assert not ops._winograd(desc(8, 64, 512, 512, 3, 2, 1, 1), 0)
     finally:
-        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"])
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"])
 
 
 def test_conv_kernels_are_compiled_without_scratch(tmp_path):

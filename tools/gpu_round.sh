@@ -76,9 +76,19 @@ testsx3)
   ( SEGMI_CONV_MATH=bf16x3 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_bf16x3.log
   ( SEGMI_CONV_MATH=bf16x3 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_bf16x3.log
   cat gpurun_out/pytest_gpu_bf16x3.log ;;
+wino)
+  # first hardware run of the branch: Winograd tests (fwd / dgrad / wgrad), then A/B of the per-layer table and the bench line
+  ( timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "winograd or conv2d_fwd_dgrad_wgrad or filter_transposes" 2>&1 | tail -15 ) > gpurun_out/wino_tests.log
+  cat gpurun_out/wino_tests.log
+  for wg in 0 1; do
+    ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=$wg timeout 200 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/conv_layers_winograd_wgrad$wg.txt
+    tail -1 gpurun_out/conv_layers_winograd_wgrad$wg.txt
+    ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=$wg timeout 300 python bench.py --no-cpu --no-alt 2>&1 | tail -1 | cut -c1-220 ) > gpurun_out/bench_winograd_wgrad$wg.log
+    cat gpurun_out/bench_winograd_wgrad$wg.log
+  done ;;
 testswino)
   # acceptance run of Winograd F(2x2,3x3) as the algorithm of the eligible 3x3 layers: the ENTIRE gpu suite at unchanged tolerances
-  ( SEGMI_CONV_WINOGRAD=1 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_winograd.log
+  ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=1 timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/pytest_gpu_winograd.log
   ( SEGMI_CONV_WINOGRAD=1 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) >> gpurun_out/pytest_gpu_winograd.log
   cat gpurun_out/pytest_gpu_winograd.log ;;
 testsf32)

@@ -1,7 +1,6 @@
 """CPU twin of csrc/conv_winograd.hip: the kernels' tile decode (dilation as sub-grids, odd maps), input / output-gradient /
 filter transforms and the 16 contractions restated line by line in numpy loops (fp64), checked against F.conv2d for the forward
-pass, the data gradient (180-degree rotated [C,3,3,K] filter) and the filter gradient (the latter's kernels live on the
-branch wip/r3-winograd-wgrad).  This is what was run BEFORE any GPU
+pass, the data gradient (180-degree rotated [C,3,3,K] filter) and the filter gradient.  This is what was run BEFORE any GPU
 time was spent on the kernels: every printed number must be ~1e-15."""
 import numpy as np, torch, torch.nn.functional as F
 def cdiv(a,b): return (a+b-1)//b
