@@ -21,11 +21,15 @@ Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
                  committed rocprofv3 PMC passes (null when no profile knows the kernel by its current name); `all_conv` holds
                  the same quantities over ALL conv launches of the step.
   cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on this host's cores on a
-                 bounded sample: the FULL batch of the same workload, one warm-up + timed steps within a 75 s cap (N = 1 only).
+                 bounded sample: the FULL batch of the same workload, one untimed warm-up step, a one-step sweep over
+                 {16, 32, 64, all} threads, then >= 3 timed steps at the best count within a 240 s cap (N = 1 only).
   alt          : the same K steps with the convolutions on the bf16x3 arithmetic (fp32 products as three-plane bf16 splits on
-                 the bf16 matrix pipe), its own roofline object priced against BOTH ceilings.  Never the headline.
-  alt_winograd : the same K steps in fp32 with the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels (opt-in:
-                 SEGMI_CONV_WINOGRAD=1).  Never the headline until the whole GPU suite has run under it.
+                 the bf16 matrix pipe), its own roofline object priced against BOTH ceilings.  Never the headline.  N = 1 only.
+  alt_direct   : the same K steps in fp32 with Winograd OFF (every layer on the direct implicit-GEMM kernels).  The headline
+                 runs the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels — the default since the whole GPU
+                 suite runs under both algorithms at the same tolerances (tests/conftest.py).  N = 1 only.
+`roofline.achieved/frac` count EXECUTED FLOPs (a Winograd contraction executes 16/36 of the direct convolution's), `effective`
+the direct-convolution FLOPs the launches stand for; `executed_step_frac` / `effective_step_frac` are the same pair for the step.
 """
 import argparse
 import json
@@ -77,11 +81,13 @@ def synth_batch(name, device, rank):
     return x.to(device), t.to(device)
 
 
-def cpu_baseline(name, seconds_cap=75.0):
+def cpu_baseline(name, seconds_cap=240.0):
     """Oracle leg: same model family / loss / optimizer on torch-CPU (the reference's own path: Python on ATen CPU kernels),
-    at the bench line's FULL batch so that oneDNN is not thread-starved (round 1 timed batch 2 on 128 threads and came out
-    slower than an 8-vCPU probe).  Bounded: one warm-up step (lazy oneDNN primitives, allocator growth) + timed steps until
-    `seconds_cap` is spent; if only the warm-up fits, that step is the sample and the field says so."""
+    at the bench line's FULL batch.  Protocol: one untimed warm-up step on all threads (lazy oneDNN primitives,
+    allocator growth), a one-step sweep over {16, 32, 64, all} torch threads, then timed steps at the best thread count until
+    three post-warm-up samples exist at it (the sweep step counts as one) or `seconds_cap` is spent.  `value` is the best
+    (minimum-time) step, the median is reported beside it.  kind = "port": /root/reference does not exist on the GPU box and
+    nothing here may read it at run time, so the leg is the bit-exact restatement (oracle/pspnet_ref.py), not the trainer."""
     from oracle import losses_ref, pspnet_ref
     import models
     arch, kw, classes, n, h, w = CONFIGS[name][:6]
@@ -97,26 +103,47 @@ def cpu_baseline(name, seconds_cap=75.0):
     x = torch.randn(nb, 3, h, w, generator=g)
     t = torch.randint(0, classes, (nb, h, w), generator=g)
     t[:, : h // 20, :] = 255
-    cores = torch.get_num_threads()
-    times = []
+    all_threads = torch.get_num_threads()
     t_begin = time.perf_counter()
-    for _ in range(4):
+
+    def one_step():
         t0 = time.perf_counter()
         opt.zero_grad()
         out, aux = pspnet_ref.pspnet_forward(ref, x, training=True, backbone=kw["backbone"])
         loss = losses_ref.cross_entropy(out, t) + 0.4 * losses_ref.cross_entropy(aux, t)
         loss.backward()
         opt.step()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_begin + times[-1] > seconds_cap:
-            break
-    timed = times[1:] or times
-    best = min(timed)
-    return {"value": round(nb / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "%d timed train step(s)%s of the FULL batch %d x 3x%dx%d (same model/loss/SGD as the GPU leg) on %d torch threads, "
-                      "best step %.2f s (all: %s)"
-                      % (len(timed), " after 1 warm-up step" if len(times) > 1 else " (the warm-up step itself: the time cap allowed no second one)",
-                         nb, h, w, cores, best, ", ".join("%.1f" % v for v in times))}
+        return time.perf_counter() - t0
+
+    def spent():
+        return time.perf_counter() - t_begin
+
+    warm = one_step()
+    samples = {}                                   # threads -> [seconds per step]
+    cands = sorted({c for c in (16, 32, 64, all_threads) if c <= all_threads}, reverse=True)
+    try:
+        for c in cands:
+            if samples and spent() + min(min(v) for v in samples.values()) * 1.5 > seconds_cap:
+                break
+            torch.set_num_threads(c)
+            samples[c] = [one_step()]
+        if not samples:                            # the warm-up alone exhausted the cap
+            samples[all_threads] = [warm]
+        best_c = min(samples, key=lambda c: min(samples[c]))
+        torch.set_num_threads(best_c)
+        while len(samples[best_c]) < 3 and spent() + min(samples[best_c]) * 1.2 < seconds_cap:
+            samples[best_c].append(one_step())
+    finally:
+        torch.set_num_threads(all_threads)
+    ts = sorted(samples[best_c])
+    best, med = ts[0], ts[len(ts) // 2]
+    return {"value": round(nb / best, 4), "median": round(nb / med, 4), "unit": "img/s", "cores": best_c, "kind": "port",
+            "timed_steps": len(ts), "step_seconds": [round(v, 2) for v in samples[best_c]],
+            "thread_sweep": {str(c): round(nb / min(v), 4) for c, v in sorted(samples.items())},
+            "sample": "%d timed train step(s) of the FULL batch %d x 3x%dx%d (same model/loss/SGD as the GPU leg) on %d of %d torch "
+                      "threads (best of a one-step sweep over %s) after 1 untimed warm-up step (%.1f s); value = best step, median beside it; "
+                      "%.0f s of CPU time in total (cap %.0f s)"
+                      % (len(ts), nb, h, w, best_c, all_threads, "/".join(str(c) for c in sorted(samples)), warm, spent(), seconds_cap)}
 
 
 def free_port():
@@ -245,12 +272,19 @@ def main():
     def roofline_of(math, value):
         """Instrumented extra step (HIP events around every conv launch on the launch stream) -> the `roofline` object."""
         peak = PEAK_FP32_MFMA_TFLOPS if math == "f32" else PEAK_BF16X3_EQUIV_TFLOPS
-        with KernelTimer() as kt:      # every rank runs the instrumented step (it contains collectives)
-            step()
+        side = segmi_ops.get_wgrad_stream()["on"]
+        segmi_ops.set_wgrad_stream(False)      # per-kernel durations are taken with every launch in order on ONE stream
+        try:
+            with KernelTimer() as kt:      # every rank runs the instrumented step (it contains collectives)
+                step()
+        finally:
+            segmi_ops.set_wgrad_stream(side)
         summ = kt.summary()
         tot_ms = sum(r["total_ms"] for r in summ.values())
-        tot_fl = sum(r["flops"] for r in summ.values())
-        top_name, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        tot_fl = sum(r["flops"] for r in summ.values())              # EXECUTED (Winograd: transform-domain) FLOPs
+        tot_eff = sum(r["eff_flops"] for r in summ.values())         # algorithmic FLOPs of the direct convolutions they stand for
+        # dominant kernel = the matrix kernel with the largest total time (the HBM-bound "winograd transforms" rows carry no FLOPs)
+        top_name, top = max(((k, r) for k, r in summ.items() if r["flops"] > 0), key=lambda kv: kv[1]["total_ms"])
         all_ach = tot_fl / (tot_ms * 1e-3) / 1e12
         ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
         # HBM traffic cannot be measured live (PMC passes need rocprofv3): the committed summary of the offline FETCH_SIZE /
@@ -259,35 +293,46 @@ def main():
         # kernel was renamed / re-tiled yields null and a note, never a stale number.
         traffic = step_traffic = None
         tnote = "no PMC profile for this config/arithmetic under profiles/"
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_cfg2_conv_traffic_%s.json" % math))
+        tag = math + ("" if wino_default else "_direct")
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_cfg2_conv_traffic_%s.json" % tag))
         if args.config == "cfg2" and cands:
             tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
             rec = tj.get("per_kernel", {}).get(top_name.split(" splitk=")[0])
-            if rec is None:
-                tnote = "profiles/%s does not know kernel %r (stale profile: re-run tools/gpu_round.sh pmc)" % (cands[-1], top_name)
+            if rec is None or tj.get("conv_winograd", False) != bool(wino_default):
+                tnote = "profiles/%s does not describe kernel %r under the current conv algorithm (stale profile: re-run tools/gpu_round.sh pmc)" % (cands[-1], top_name)
             else:
                 traffic, step_traffic = rec["traffic_bytes_per_launch"], tj["traffic_bytes_per_step"]
                 tnote = "HBM+MALL bytes per launch from the rocprofv3 PMC passes (profiles/%s)" % cands[-1]
+        step_s = nb * world / value                                   # seconds per step of the timed loop
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "effective": round(top["eff_flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
                 "peak_note": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if math == "f32" else
                               "fp32-equivalent ceiling of the bf16x3 scheme = dense bf16 MFMA peak 2516.6 / 6 plane products; "
                               "achieved/frac count ALGORITHMIC fp32 FLOPs (the fp32 MFMA peak is %.1f)" % PEAK_FP32_MFMA_TFLOPS),
                 "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
                 "flops_per_launch": top["flops"] // top["launches"], "algorithmic_bytes_per_launch": top["bytes"] // top["launches"],
-                "scope": "dominant kernel = the conv implicit-GEMM variant with the largest total time in one step; HIP events per launch "
-                         "on the launch stream; traffic: " + tnote,
+                "scope": "dominant kernel = the matrix kernel with the largest total time in one step; HIP events per launch on the launch "
+                         "stream (for a Winograd pass: the event pair the library records around its ONE batched contraction launch); "
+                         "achieved/frac = EXECUTED FLOPs (the 16 transform-domain contractions of a Winograd launch, 2*16*T*C*K), "
+                         "effective = the direct-convolution FLOPs those launches stand for; traffic: " + tnote,
                 "all_conv": {"achieved": round(all_ach, 2), "frac": round(all_ach / peak, 4),
+                             "effective": round(tot_eff / (tot_ms * 1e-3) / 1e12, 2),
                              "launches": sum(r["launches"] for r in summ.values()), "ms_per_step": round(tot_ms, 2),
-                             "flops_per_step": tot_fl, "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
+                             "flops_per_step": tot_fl, "effective_flops_per_step": tot_eff,
+                             "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
                              "traffic_bytes_per_step": step_traffic},
-                # step_frac prices the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as
-                # written) against the peak; the factored PSP bottleneck executes fewer (all_conv.flops_per_step is what ran)
-                "step_frac": round(value / world * flops_img / 1e12 / peak, 4),
+                # executed_step_frac: FLOPs the matrix kernels actually executed in one step / step time / peak (a utilisation);
+                # effective_step_frac: the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as
+                # written) / step time / peak — an effective-throughput figure that may exceed what any fp32 kernel can execute
+                "executed_step_frac": round(tot_fl / step_s / 1e12 / peak, 4),
+                "effective_step_frac": round(value / world * flops_img / 1e12 / peak, 4),
                 "reference_formulation_flops_per_step": flops_img * nb,
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
-                                 "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
+                                 "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1),
+                                 "effective_tflops": round(r["eff_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
 
+    wino_default = segmi_ops.get_conv_winograd()["on"]
     run = step
     if args.graph:
         from segmi.graph import GraphedStep
@@ -310,7 +355,8 @@ def main():
     # products evaluated as three-plane bf16 splits on the bf16 matrix pipe (csrc/conv_igemm.hip).  Reported
     # beside the headline, never as it: the headline line is the fp32-MFMA parity path.
     alt = None
-    if args.conv_math == "f32" and not args.no_alt and not args.graph:
+    run_alt = args.conv_math == "f32" and not args.no_alt and not args.graph and world == 1   # N > 1: the headline only (no 3x collectives)
+    if run_alt:
         segmi_ops.set_conv_math("bf16x3")
         try:
             adt, aloss = timed(step)
@@ -319,32 +365,32 @@ def main():
                    "steps": args.steps, "warmup": args.warmup, "final_loss": round(aloss, 5),
                    "dtype": "f32 storage / LDS / accumulate; every conv product a*b evaluated as six bf16 plane products of the exact "
                             "three-way split a = h+m+l (per-product error <= 2^-24, i.e. one fp32 rounding)",
-                   "parity": "same GPU suite and BASELINE-shape audits as the headline arithmetic, run under SEGMI_CONV_MATH=bf16x3 "
-                             "(profiles/r02_gpu_suite_bf16x3.txt: logit distance from the fp64 oracle and argmax mismatch counts "
-                             "statistically equal to the fp32-MFMA path)",
+                   "parity": "NOT the parity path: the round-2 run of the GPU suite under SEGMI_CONV_MATH=bf16x3 ended 209 passed / 1 failed "
+                             "(profiles/r02_gpu_suite_bf16x3.txt: one two-process test, a packed-fp32 nondeterminism without a minimal "
+                             "reproducer) and one UNet gradient criterion had to be relaxed for it; logit distance from the fp64 oracle "
+                             "and argmax mismatch counts at the BASELINE shapes were statistically equal to the fp32-MFMA path",
                    "roofline": None if args.no_roofline else roofline_of("bf16x3", aval)}
         finally:
             segmi_ops.set_conv_math("f32")
-    # `alt_winograd`: the same K steps, fp32 arithmetic, with the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels
-    # (csrc/conv_winograd.hip): an ALGORITHM change in the same arithmetic.  Opt-in until the whole GPU suite has
-    # run under it (its own tests and the four BASELINE-shape audits have), so it is reported beside the headline, not as it.
-    alt_wino = None
-    wino_default = segmi_ops.get_conv_winograd()["on"]
-    if args.conv_math == "f32" and not args.no_alt and not args.graph and not wino_default:
-        segmi_ops.set_conv_winograd(True)
+    # `alt_direct`: the same K steps, fp32 arithmetic, with Winograd OFF — every layer on the direct implicit-GEMM kernels (the
+    # round-2 headline path; csrc/conv_winograd.hip is an ALGORITHM change in the same arithmetic).  When the
+    # process runs with SEGMI_CONV_WINOGRAD=0 the roles swap (`alt_winograd`).
+    alt_algo = None
+    if run_alt:
+        wst = segmi_ops.get_conv_winograd()
+        segmi_ops.set_conv_winograd(not wino_default, wgrad=not wino_default)
         try:
             wdt, wloss = timed(step)
             wval = world * nb * args.steps / wdt
-            alt_wino = {"conv_algorithm": "winograd_f2x2_3x3 for the 3x3 stride-1 layers with >= %d channels (forward and data gradient), "
-                                          "direct implicit GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"],
+            alt_algo = {"conv_algorithm": ("direct implicit GEMM for every layer" if wino_default else
+                                           "winograd_f2x2_3x3 for the 3x3 stride-1 layers with >= %d channels (all three passes), direct "
+                                           "implicit GEMM elsewhere" % wst["min_channels"]),
                         "conv_math": "f32", "value": round(wval, 2), "unit": "img/s", "ms_per_step": round(1e3 * wdt / args.steps, 2),
                         "steps": args.steps, "warmup": args.warmup, "final_loss": round(wloss, 5),
-                        "parity": "tests/test_ops_gpu.py::test_conv2d_winograd_matches_reference (8 shapes, same 1e-4 bar as the direct "
-                                  "kernels), ::test_pspnet_step_under_winograd_matches_direct, and the four BASELINE-shape audits run under "
-                                  "SEGMI_CONV_WINOGRAD=1 (profiles/r02_fullsize_audit_winograd.txt: cfg2 400 tie-level mismatches vs 404 "
-                                  "direct, max|dlogit| 3.63e-4 vs 3.64e-4)"}
+                        "parity": "the model-level GPU tests, the generic convolution test and the four BASELINE-shape audits run once per "
+                                  "algorithm at the same tolerances (tests/conftest.py: conv_algorithm)"}
         finally:
-            segmi_ops.set_conv_winograd(False)
+            segmi_ops.set_conv_winograd(wst["on"], wgrad=wst["wgrad"])
     if ddp:
         dist.barrier()
 
@@ -367,9 +413,12 @@ def main():
                        "global_batch": nb * world, "parallelism": "dp%d" % world,
                        "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
                        "rccl_ranks": (dist.get_world_size() if ddp and backend == "nccl" else 0), "final_loss": round(final_loss, 5),
-                       "conv_math": args.conv_math, "conv_winograd": bool(wino_default), "hip_graph": bool(args.graph),
+                       "conv_math": args.conv_math, "conv_winograd": bool(wino_default),
+                       "conv_algorithm": ("winograd_f2x2_3x3 (fwd, dgrad, wgrad) for the 3x3 stride-1 layers with >= %d channels, direct implicit "
+                                          "GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"]) if wino_default else "direct implicit GEMM",
+                       "hip_graph": bool(args.graph), "wgrad_side_stream": bool(segmi_ops.get_wgrad_stream()["on"]),
                        "syncbn_collectives_per_step": syncbn_per_step},
-            "roofline": roof, "cpu_baseline": cpu, "alt": alt, "alt_winograd": alt_wino,
+            "roofline": roof, "cpu_baseline": cpu, "alt": alt, ("alt_direct" if wino_default else "alt_winograd"): alt_algo,
         }
         print(json.dumps(line), flush=True)
     if ddp:

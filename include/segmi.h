@@ -107,12 +107,21 @@ int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const
                                 void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
 /* Filter gradient of the same layers in the Winograd domain: dw = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G, the 16
- * contractions over the tiles on the direct filter-gradient kernel (1x1 problems, deterministic split).  Replaces the wgrad
- * half of convolution_backward at the sites listed above; same operands as segmi_conv2d_wgrad. */
+ * contractions over the tiles as ONE batched launch of the direct filter-gradient kernel (1x1 problems, one deterministic
+ * pixel split planned for all 16); the split reduction is folded into the G^T . G pass.  Replaces the wgrad half of
+ * convolution_backward at the sites listed above; same operands as segmi_conv2d_wgrad.  `workspace` holds both transformed
+ * operands and the partial sums [nsplit][16][K][C] (nsplit = the "splitk=" of segmi_conv2d_winograd_wgrad_variant). */
 int segmi_conv2d_winograd_wgrad_ok(const segmi_conv_desc* d);
 size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d);
 int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
                                 size_t workspace_bytes, segmi_stream_t stream);
+int segmi_conv2d_winograd_wgrad_variant(const segmi_conv_desc* d, char* buf, size_t len);
+/* Measurement hooks for the three Winograd passes (bench.py's roofline leg, segmi/profile.py): _tiles() = number of 2x2 output
+ * tiles T (the 16 contractions are [T x Cin] x [Cin x Cout], i.e. 32*T*Cin*Cout executed FLOPs); _trace() hands over two
+ * caller-owned hipEvent_t that the NEXT Winograd call of this thread records on its stream right before / after its contraction
+ * launch (one-shot; NULL, NULL cancels), so the MFMA-bound kernel is timed apart from the HBM-bound transforms around it. */
+long segmi_conv2d_winograd_tiles(const segmi_conv_desc* d);
+int segmi_conv2d_winograd_trace(void* ev_begin, void* ev_end);
 /* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
  *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
  *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and

@@ -40,11 +40,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 FULL = {
     "cfg2": ("PSPNet", dict(backbone="resnet50"), 21, 8, 512, 512, "CrossEntropyLoss2d", 255, 8, 0, 1234,
              ("initial.0.1.running_mean", "layer4.2.bn3.running_var", "master_branch.0.bottleneck.1.running_mean")),
-    "cfg3": ("DeepLab", dict(backbone="resnet101", output_stride=16), 19, 2, 513, 513, "CrossEntropyLoss2d", 255, 8, 2, 555,
+    "cfg3": ("DeepLab", dict(backbone="resnet101", output_stride=16), 19, int(os.environ.get("SEGMI_GOLDEN_CFG3_BATCH", "16")), 513, 513, "CrossEntropyLoss2d", 255, 9, 2, 555,
              ("backbone.layer4.2.bn3.running_var", "decoder.bn1.running_mean")),
     "cfg4": ("PSPNet", dict(backbone="resnet50"), 19, 4, 769, 769, "CrossEntropyLoss2d", 255, 12, 0, 4321,
              ("initial.0.1.running_mean", "layer4.2.bn3.running_var", "master_branch.0.bottleneck.1.running_mean")),
-    "cfg5": ("DeepLab", dict(backbone="xception", output_stride=16), 150, 2, 512, 512, "LovaszSoftmax", -1, 16, 2, 777,
+    "cfg5": ("DeepLab", dict(backbone="xception", output_stride=16), 150, 8, 512, 512, "LovaszSoftmax", -1, 16, 2, 777,
              ("ASSP.aspp4.1.running_var", "decoder.bn1.running_mean")),
 }
 

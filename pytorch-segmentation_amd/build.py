@@ -23,7 +23,8 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 # per-file additions (see DESIGN.md §4.1b "packed-fp32 results next to another process's bf16 MFMA kernels")
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("pool_resize.hip", "conv_winograd.hip", "bn.hip", "loss.hip", "misc.hip", "optim.hip",
-                                                    "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip", "augment.hip")}
+                                                    "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip")}
+# (augment.hip is off the timed path and held to oracle/augment_ref.py at "one uint8 level": it keeps the default flags it was pinned with)
 
 
 def _sources():

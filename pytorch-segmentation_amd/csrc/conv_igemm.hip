@@ -769,6 +769,10 @@ struct WgradParams {
     int chunks_per_split;  // in units of BKP pixels
     long split_stride;     // K*R*S*C
     int pack4;             // C == 4: the N axis of the GEMM is j = tap*4 + c (all taps in one tile) instead of one tile per tap
+    // batch > 1 (LDS-DMA kernel): blockIdx.z selects one of `batch` independent problems of identical shape whose operands /
+    // results lie bs_x / bs_dy / bs_out floats apart (the 16 transform-domain contractions of a Winograd filter gradient)
+    int batch;
+    long bs_x, bs_dy, bs_out;
 };
 
 template <int BM, int BN, int BKP, int WM, int WN>
@@ -938,8 +942,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     const int mend = min(p.M, mbeg + p.chunks_per_split * BKP);
     const int PQ = p.P * p.Q;
 
-    const i32x4 dy_rsrc = make_rsrc(p.dy, dy_bytes);
-    const i32x4 x_rsrc = make_rsrc(p.x, x_bytes);
+    const long bat = p.batch > 1 ? (long)blockIdx.z : 0;
+    const i32x4 dy_rsrc = make_rsrc(p.dy + bat * p.bs_dy, dy_bytes);
+    const i32x4 x_rsrc = make_rsrc(p.x + bat * p.bs_x, x_bytes);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
 
     // DMA roles: A (dy) row = (i*4 + wave)*A_RPI + lane/A_LPR, channel group lane%A_LPR; same for B (x)
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     }
 
     // epilogue through LDS like the fprop kernel: 16-byte stores of 4 consecutive input channels
-    float* out = p.out + (long)split * p.split_stride;
+    float* out = p.out + (long)split * p.split_stride + bat * p.bs_out;
     const int RS = p.R * p.S;
     constexpr int EP = 36;
     float* stage = smem + wave * (TM * 32 * EP);
@@ -1421,7 +1426,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 struct WgradPlan { int bm, bn, tiles_k, tiles_c, nsplit, chunks_per_split, pack4; };
 constexpr int WG_BKP = 32;
 bool wgrad_dma_desc(const segmi_conv_desc* d);
-WgradPlan plan_wgrad(const segmi_conv_desc* d) {
+WgradPlan plan_wgrad(const segmi_conv_desc* d, int batch = 1) {
     WgradPlan pl;
     pl.pack4 = (d->C == 4 && d->R * d->S > 1 && wgrad_dma_desc(d)) ? 1 : 0;   // RGB stems: fold the taps into the N axis
     const int Cv = pl.pack4 ? d->R * d->S * 4 : d->C;
@@ -1429,7 +1434,7 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d) {
     pl.bn = Cv > 64 ? 128 : 64;
     pl.tiles_k = segmi_cdiv(d->K, pl.bm);
     pl.tiles_c = segmi_cdiv(Cv, pl.bn);
-    const long tiles = (long)pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : d->R * d->S);
+    const long tiles = (long)pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : d->R * d->S) * batch;
     const long M = (long)d->N * d->P * d->Q;
     const long chunks = (M + WG_BKP - 1) / WG_BKP;
     // Split the pixel reduction until the grid is >= 8 "rounds" of the 512 resident workgroups (two 64 KB-LDS workgroups
@@ -1505,8 +1510,9 @@ bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
 template <int BM, int BN>
 int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
-    dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : p.R * p.S)), (unsigned)pl.nsplit);
+    dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : p.R * p.S)), (unsigned)pl.nsplit, (unsigned)(p.batch > 1 ? p.batch : 1));
     unsigned xb, dyb;
+    if (p.batch > 1 && !wgrad_dma(p, &xb, &dyb)) return SEGMI_ERR_BADARG;     // batch exists in the LDS-DMA kernel only
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
 #define SEGMI_LAUNCH_WGRAD(ROWQV, MATHV) \
@@ -1681,6 +1687,7 @@ int segmi_conv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy
     p.M = d->N * d->P * d->Q;
     p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c; p.chunks_per_split = pl.chunks_per_split; p.pack4 = pl.pack4;
     p.split_stride = (long)d->K * d->R * d->S * d->C;
+    p.batch = 1; p.bs_x = p.bs_dy = p.bs_out = 0;
     int rc;
     if (pl.bm == 128 && pl.bn == 128) rc = launch_wgrad<128, 128>(p, pl, st);
     else if (pl.bm == 128) rc = launch_wgrad<128, 64>(p, pl, st);
@@ -1792,6 +1799,48 @@ int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
     const int bm = 128, bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);           // batched launches always take 128-row tiles
     (void)M;
     snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %d>", bm, bn, bn == 32 ? "4, 1" : "2, 2", conv_math());
+    return SEGMI_OK;
+}
+
+// dW_b[K, C] = sum_m DY_b[m, K]^T X_b[m, C] for b < batch (1x1 filter gradients over M rows, M % 32 == 0), ONE launch of the LDS-DMA
+// filter-gradient kernel (blockIdx.z = b) with ONE pixel split planned for batch x the tiles; partial sums go to
+// ws[nsplit][batch][K][C] (the caller reduces them: conv_winograd.hip folds that into its filter-gradient transform).
+static segmi_conv_desc wgrad_batched_desc(int M, int C, int K) {
+    segmi_conv_desc q;
+    q.N = 1; q.H = 1; q.W = M; q.C = C; q.K = K; q.R = 1; q.S = 1; q.P = 1; q.Q = M;
+    q.stride = 1; q.pad = 0; q.dil = 1; q.ldx = C; q.ldy = (K + 3) & ~3;
+    return q;
+}
+int segmi_internal_wgrad_batched_splits(int M, int C, int K, int batch) {
+    if (M <= 0 || (M % WG_BKP) || C <= 0 || (C & 3) || K <= 0 || batch < 1 || batch > 65535) return 0;
+    const segmi_conv_desc q = wgrad_batched_desc(M, C, K);
+    if (!wgrad_dma_desc(&q)) return 0;
+    return plan_wgrad(&q, batch).nsplit;
+}
+int segmi_internal_wgrad_batched(const float* x, const float* dy, float* ws, int M, int C, int K, int batch, hipStream_t st) {
+    const int nsplit = segmi_internal_wgrad_batched_splits(M, C, K, batch);
+    if (!x || !dy || !ws || nsplit < 1) return SEGMI_ERR_BADARG;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(ws)) return SEGMI_ERR_ALIGN;
+    const segmi_conv_desc q = wgrad_batched_desc(M, C, K);
+    const WgradPlan pl = plan_wgrad(&q, batch);
+    WgradParams p;
+    p.x = x; p.dy = dy; p.out = ws;
+    p.N = 1; p.H = 1; p.W = M; p.C = C; p.ldx = q.ldx;
+    p.P = 1; p.Q = M; p.K = K; p.ldy = q.ldy;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.M = M;
+    p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c; p.chunks_per_split = pl.chunks_per_split; p.pack4 = 0;
+    p.batch = batch; p.bs_x = (long)M * q.ldx; p.bs_dy = (long)M * q.ldy; p.bs_out = (long)K * C;
+    p.split_stride = (long)batch * K * C;
+    if (pl.bm == 128 && pl.bn == 128) return launch_wgrad<128, 128>(p, pl, st);
+    if (pl.bm == 128) return launch_wgrad<128, 64>(p, pl, st);
+    if (pl.bn == 128) return launch_wgrad<64, 128>(p, pl, st);
+    return launch_wgrad<64, 64>(p, pl, st);
+}
+int segmi_internal_wgrad_batched_variant(int M, int C, int K, int batch, char* buf, size_t len) {
+    const int nsplit = segmi_internal_wgrad_batched_splits(M, C, K, batch);
+    if (!buf || len < 64 || nsplit < 1) return SEGMI_ERR_BADARG;
+    snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, true, %d> splitk=%d", K > 64 ? 128 : 64, C > 64 ? 128 : 64, conv_math(), nsplit);
     return SEGMI_OK;
 }
 

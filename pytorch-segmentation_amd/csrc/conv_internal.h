@@ -11,3 +11,11 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
 int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len);
 // Whether segmi_internal_gemm_batched can run this shape (LDS-DMA kernels enabled, operands within 32-bit buffer offsets).
 bool segmi_internal_gemm_ok(long M, int lda, int Cs, int Cd);
+
+// dW_b[K, C] = DY_b[M, K]^T x X_b[M, C] for b < batch: the batched 1x1 filter gradient (M % 32 == 0; x planes M*C floats apart,
+// dy planes M*round_up(K,4) apart), ONE launch of the LDS-DMA filter-gradient kernel with blockIdx.z = b.  The pixel axis is
+// split `segmi_internal_wgrad_batched_splits` ways (0: shape not supported) and the partial sums land in
+// ws[nsplit][batch][K][C]; the caller reduces them in slice order.
+int segmi_internal_wgrad_batched_splits(int M, int C, int K, int batch);
+int segmi_internal_wgrad_batched(const float* x, const float* dy, float* ws, int M, int C, int K, int batch, hipStream_t st);
+int segmi_internal_wgrad_batched_variant(int M, int C, int K, int batch, char* buf, size_t len);

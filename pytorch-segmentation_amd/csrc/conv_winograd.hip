@@ -197,9 +197,11 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     }
 }
 
-// dg[k][r][s][c] = (G^T dU[:, k, c] G)[r][s]
-__global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __restrict__ dU, int K, int C, float* __restrict__ dg) {
+// dg[k][r][s][c] = (G^T dU[:, k, c] G)[r][s],  dU = the sum of the nsplit partial slices ws[s][xi][k][c] in slice order
+// (deterministic): the split-K reduction of the 16 batched contractions and the filter-gradient transform in ONE pass
+__global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __restrict__ ws, int nsplit, int K, int C, float* __restrict__ dg) {
     const long n = (long)K * C;
+    const long slice = 16 * n;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const long k = idx / C;
         const int c = (int)(idx - k * C);
@@ -207,7 +209,14 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __re
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) u[a][b] = dU[(a * 4 + b) * n + idx];
+            for (int b = 0; b < 4; ++b) u[a][b] = ws[(a * 4 + b) * n + idx];
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float* w = ws + sp * slice + idx;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) u[a][b] += w[(a * 4 + b) * n];
+        }
         float t[3][4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -235,6 +244,19 @@ bool wino_geom(int N, int H, int W, int d, WinoGeom* g) {
 }
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Measurement hook (segmi_conv2d_winograd_trace): a pair of caller-owned HIP events recorded around the CONTRACTION launch of the
+// next Winograd call of this thread, so that a profiler bracketing the whole call can separate the MFMA-bound batched GEMM from
+// the HBM-bound transforms around it.  One-shot: consumed (cleared) by the call that uses it.
+thread_local hipEvent_t g_trace_begin = nullptr, g_trace_end = nullptr;
+struct TraceScope {
+    hipStream_t st; hipEvent_t e;
+    explicit TraceScope(hipStream_t s) : st(s), e(g_trace_end) {
+        if (g_trace_begin) hipEventRecord(g_trace_begin, st);
+        g_trace_begin = g_trace_end = nullptr;
+    }
+    ~TraceScope() { if (e) hipEventRecord(e, st); }
+};
 
 struct WinoPlan { WinoGeom g; int Cin, Cout, ldm; size_t u_bytes, v_bytes, m_bytes; };
 
@@ -272,8 +294,11 @@ int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, i
         RowGeom rg = row_geom(T, pl.Cin, 1, SEGMI_MAX_GRID * 4);
         hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, src, lds, pl.Cin, pl.g, T, V);
     }
-    const int rc = segmi_internal_gemm_batched(V, pl.Cin, U, Mm, pl.ldm, (int)T, pl.Cin, pl.Cout, 16, T * pl.Cin, (long)pl.Cout * pl.Cin,
-                                               T * pl.ldm, st);
+    int rc;
+    {
+        TraceScope tr(st);
+        rc = segmi_internal_gemm_batched(V, pl.Cin, U, Mm, pl.ldm, (int)T, pl.Cin, pl.Cout, 16, T * pl.Cin, (long)pl.Cout * pl.Cin, T * pl.ldm, st);
+    }
     if (rc != SEGMI_OK) return rc;
     {
         RowGeom rg = row_geom(T, pl.ldm, 1, SEGMI_MAX_GRID * 4);
@@ -320,8 +345,9 @@ int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const
 }
 
 // ---- filter gradient: dg = G^T [ sum_tiles (A dy A^T) (.) (B^T d B) ] G; the 16 contractions over the tiles are 1x1 filter
-// gradients (x := V_xi [T, C], dy := W_xi [T, Kp]) and run on the direct filter-gradient kernel with its deterministic split
-struct WinoWgradPlan { WinoGeom g; long Tpad; int C, K, Kp; segmi_conv_desc gd; size_t v_bytes, w_bytes, u_bytes, s_bytes; };
+// gradients (x := V_xi [T, C], dy := W_xi [T, Kp]) and run as ONE batched launch of the direct filter-gradient kernel
+// (blockIdx.z = xi, one deterministic pixel split planned for 16x the tiles); the split reduction is folded into the G^T . G pass
+struct WinoWgradPlan { WinoGeom g; long Tpad; int C, K, Kp, nsplit; size_t v_bytes, w_bytes, s_bytes; };
 
 static bool wino_wgrad_plan(const segmi_conv_desc* d, WinoWgradPlan* pl) {
     WinoPlan f;
@@ -330,13 +356,11 @@ static bool wino_wgrad_plan(const segmi_conv_desc* d, WinoWgradPlan* pl) {
     pl->Tpad = (f.g.T + 31) & ~31L;
     pl->C = d->C; pl->K = d->K; pl->Kp = (d->K + 3) & ~3;
     if (pl->Tpad >= (1L << 31) || pl->Tpad * pl->C * 4 >= 0xFFFFFF00L || pl->Tpad * pl->Kp * 4 >= 0xFFFFFF00L) return false;
-    segmi_conv_desc& q = pl->gd;                       // one transform-domain contraction as a 1x1 filter gradient over a 1 x Tpad "image"
-    q.N = 1; q.H = 1; q.W = (int)pl->Tpad; q.C = pl->C; q.K = pl->K; q.R = 1; q.S = 1; q.P = 1; q.Q = (int)pl->Tpad;
-    q.stride = 1; q.pad = 0; q.dil = 1; q.ldx = pl->C; q.ldy = pl->Kp;
+    pl->nsplit = segmi_internal_wgrad_batched_splits((int)pl->Tpad, pl->C, pl->K, 16);
+    if (pl->nsplit < 1) return false;
     pl->v_bytes = align256((size_t)16 * pl->Tpad * pl->C * sizeof(float));
     pl->w_bytes = align256((size_t)16 * pl->Tpad * pl->Kp * sizeof(float));
-    pl->u_bytes = align256((size_t)16 * pl->K * pl->C * sizeof(float));
-    pl->s_bytes = align256(segmi_conv2d_wgrad_workspace(&pl->gd));
+    pl->s_bytes = align256((size_t)pl->nsplit * 16 * pl->K * pl->C * sizeof(float));
     return true;
 }
 
@@ -348,7 +372,7 @@ int segmi_conv2d_winograd_wgrad_ok(const segmi_conv_desc* d) {
 size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d) {
     WinoWgradPlan pl;
     if (!wino_wgrad_plan(d, &pl)) return 0;
-    return pl.v_bytes + pl.w_bytes + pl.u_bytes + pl.s_bytes;
+    return pl.v_bytes + pl.w_bytes + pl.s_bytes;
 }
 
 int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
@@ -358,13 +382,12 @@ int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const 
     if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.Kp || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
         ((uintptr_t)dw_krsc & 15))
         return SEGMI_ERR_ALIGN;
-    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.v_bytes + pl.w_bytes + pl.u_bytes + pl.s_bytes)
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.v_bytes + pl.w_bytes + pl.s_bytes)
         return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* V = (float*)workspace;
     float* Wt = (float*)((char*)workspace + pl.v_bytes);
-    float* dU = (float*)((char*)workspace + pl.v_bytes + pl.w_bytes);
-    void* sk = (char*)workspace + pl.v_bytes + pl.w_bytes + pl.u_bytes;
+    float* sk = (float*)((char*)workspace + pl.v_bytes + pl.w_bytes);
     {
         RowGeom rg = row_geom(pl.Tpad, pl.C, 1, SEGMI_MAX_GRID * 4);
         hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, x, d->ldx, pl.C, pl.g, pl.Tpad, V);
@@ -373,18 +396,39 @@ int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const 
         RowGeom rg = row_geom(pl.Tpad, pl.Kp, 1, SEGMI_MAX_GRID * 4);
         hipLaunchKernelGGL(wino_dy_kernel, rg.grid, rg.block, 0, st, dy, d->ldy, pl.Kp, pl.g, pl.Tpad, Wt);
     }
-    for (int xi = 0; xi < 16; ++xi) {
-        const int rc = segmi_conv2d_wgrad(&pl.gd, V + (long)xi * pl.Tpad * pl.C, Wt + (long)xi * pl.Tpad * pl.Kp, dU + (long)xi * pl.K * pl.C,
-                                          pl.s_bytes ? sk : nullptr, pl.s_bytes, stream);
-        if (rc != SEGMI_OK) return rc;
+    int rc;
+    {
+        TraceScope tr(st);
+        rc = segmi_internal_wgrad_batched(V, Wt, sk, (int)pl.Tpad, pl.C, pl.K, 16, st);
     }
+    if (rc != SEGMI_OK) return rc;
     {
         const long n = (long)pl.K * pl.C;
         long nb = (n + 255) / 256;
         if (nb > SEGMI_MAX_GRID * 4) nb = SEGMI_MAX_GRID * 4;
-        hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, pl.K, pl.C, dw_krsc);
+        hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)sk, pl.nsplit, pl.K, pl.C, dw_krsc);
     }
     return segmi_launch_status();
+}
+
+int segmi_conv2d_winograd_wgrad_variant(const segmi_conv_desc* d, char* buf, size_t len) {
+    WinoWgradPlan pl;
+    if (!buf || len < 112 || !wino_wgrad_plan(d, &pl)) return SEGMI_ERR_BADARG;
+    char k[80];
+    if (segmi_internal_wgrad_batched_variant((int)pl.Tpad, pl.C, pl.K, 16, k, sizeof k) != SEGMI_OK) return SEGMI_ERR_BADARG;
+    snprintf(buf, len, "winograd_f2x2_3x3 wgrad: 16 x %s", k);
+    return SEGMI_OK;
+}
+
+int segmi_conv2d_winograd_trace(void* ev_begin, void* ev_end) {
+    g_trace_begin = (hipEvent_t)ev_begin;
+    g_trace_end = (hipEvent_t)ev_end;
+    return SEGMI_OK;
+}
+
+long segmi_conv2d_winograd_tiles(const segmi_conv_desc* d) {
+    WinoPlan pl;
+    return wino_plan(d, 0, &pl) ? pl.g.T : 0;
 }
 
 int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len) {

@@ -51,6 +51,9 @@ SIGNATURES = {
     "segmi_conv2d_winograd_wgrad_ok": (i32, [PD]),
     "segmi_conv2d_winograd_wgrad_workspace": (sz, [PD]),
     "segmi_conv2d_winograd_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
+    "segmi_conv2d_winograd_wgrad_variant": (i32, [PD, C.c_char_p, sz]),
+    "segmi_conv2d_winograd_tiles": (i64, [PD]),
+    "segmi_conv2d_winograd_trace": (i32, [vp, vp]),
     "segmi_filter_tx_tiles": (i64, [i32, i32, i32, i32, i32]),
     "segmi_filter_krsc_to_crsk_multi": (i32, [vp, i32, i64, vp]),
     "segmi_conv_set_presplit": (i32, [i32]),

@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_dropout_epoch",
 ]
 
 
@@ -230,14 +230,15 @@ def _presplit(w, n, dev):
     return planes
 
 
-# Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/conv_winograd.hip): opt-in (SEGMI_CONV_WINOGRAD=1 or
-# set_conv_winograd) until the whole GPU suite has run under it; `min_channels` = smallest min(C, K) it is used for (below
+# Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/conv_winograd.hip): the DEFAULT algorithm of the eligible layers for
+# all three passes since round 3 (the whole GPU suite runs under it; SEGMI_CONV_WINOGRAD=0 / set_conv_winograd(False) selects the
+# direct implicit-GEMM kernels everywhere); `min_channels` = smallest min(C, K) it is used for (below
 # ~256 channels the transform traffic eats the saved multiplications); `min_subgrid` = smallest ceil(H / dilation) it is used for
 # (a dilated layer runs as dilation^2 dense sub-grids: ASPP's d = 12..36 on 33x33 maps would be 2x2 tiles of mostly padding).
-_WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "0") == "1",
+_WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "1") == "1",
              "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "256")),
              "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")),
-             "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "0") == "1", "calls": 0}
+             "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "1") == "1", "calls": 0}
 
 
 def set_conv_winograd(on, min_channels=None, min_subgrid=None, wgrad=None):
@@ -269,6 +270,19 @@ def _winograd_variant(d, op):
     return buf.value.decode()
 
 
+def _winograd_inner(d, C):
+    """(executed FLOPs, operand bytes) of the 16 transform-domain contractions of one Winograd pass (any of the three passes:
+    [T x C] x [C x K] per plane with the true channel counts)."""
+    T = lib.segmi_conv2d_winograd_tiles(d)
+    return 32 * T * C * d.K, 64 * (T * C + C * d.K + T * d.K)
+
+
+def _winograd_wgrad_variant(d):
+    buf = ctypes.create_string_buffer(128)
+    check(lib.segmi_conv2d_winograd_wgrad_variant(d, buf, 128), "conv2d_winograd_wgrad_variant")
+    return buf.value.decode()
+
+
 def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
     """segmi_conv2d_fwd (or its pre-split-filter / Winograd form when that applies) with its workspace and roofline span.
     w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats."""
@@ -277,7 +291,7 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
         _WINOGRAD["calls"] += 1
         nws = lib.segmi_conv2d_winograd_workspace(d, 0)
         ws = workspace(nws, dev)
-        with span(lambda: _winograd_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        with span(lambda: _winograd_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
             check(lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                 y.data_ptr(), accumulate, ws.data_ptr(), nws, st), "conv2d_winograd_fwd")
         return
@@ -300,7 +314,7 @@ def _conv_wgrad(d, C, x, dy, dwb):
         _WINOGRAD["calls"] += 1
         nws = lib.segmi_conv2d_winograd_wgrad_workspace(d)
         ws = workspace(nws, dev)
-        with span(lambda: "winograd_f2x2_3x3 wgrad: 16 x " + conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        with span(lambda: _winograd_wgrad_variant(d), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
             check(lib.segmi_conv2d_winograd_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr(), nws, st), "conv2d_winograd_wgrad")
         return
     nws = lib.segmi_conv2d_wgrad_workspace(d)
@@ -310,6 +324,54 @@ def _conv_wgrad(d, C, x, dy, dwb):
               "conv2d_wgrad")
 
 
+# Filter gradients on a side HIP stream (SEGMI_WGRAD_STREAM=1 / set_wgrad_stream): nothing in the backward pass consumes dW —
+# only the optimizer (or the gradient all-reduce) does — so the wgrad launch of a layer may run concurrently with the data-gradient
+# chain of the layers below it.  The wgrad kernels leave most of a CU's register file and 32 KB of LDS free (116 VGPRs x 2 waves per
+# SIMD), so the HBM-bound BN-backward / transform kernels of the main stream co-reside with them instead of queueing behind them.
+# Rules that keep it exact: the side stream first waits for the main stream (dy is complete), x / dy / dW are record_stream()ed so the
+# caching allocator does not recycle them early, the main stream re-joins at the END of the backward pass (autograd engine
+# callback), and the path is only taken when the parameter has no gradient yet (AccumulateGrad then adopts the tensor without
+# launching anything; an accumulating or bucket-view gradient keeps the in-order path).
+_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "0") == "1", "streams": {}, "armed": False, "launches": 0}
+
+
+def set_wgrad_stream(on):
+    _WGRAD_SIDE["on"] = bool(on)
+
+
+def get_wgrad_stream():
+    return {"on": _WGRAD_SIDE["on"], "launches": _WGRAD_SIDE["launches"]}
+
+
+def _join_wgrad_stream():
+    _WGRAD_SIDE["armed"] = False
+    for side in _WGRAD_SIDE["streams"].values():
+        torch.cuda.current_stream(side.device).wait_stream(side)
+
+
+def _conv_wgrad_param(weight, d, C, x, dy, dwb):
+    """_conv_wgrad for a parameter's filter gradient: on the side stream when enabled and safe, in order otherwise."""
+    if not (_WGRAD_SIDE["on"] and weight.grad is None and weight.is_leaf and torch.is_grad_enabled() is False):
+        return _conv_wgrad(d, C, x, dy, dwb)
+    dev = x.device
+    side = _WGRAD_SIDE["streams"].get(dev.index)
+    if side is None:
+        side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _conv_wgrad(d, C, x, dy, dwb)
+    for t in (x, dy, dwb):
+        t.record_stream(side)
+    _WGRAD_SIDE["launches"] += 1
+    if not _WGRAD_SIDE["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_stream)
+            _WGRAD_SIDE["armed"] = True
+        except RuntimeError:               # not inside an engine-driven backward pass: join right away
+            _join_wgrad_stream()
+
+
 def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
     """segmi_conv2d_dgrad (or its pre-split-filter form).  wt: flat CRSK filter of d.C * d.R * d.S * pad4(d.K) floats."""
     dev, st = dy.device, _stream()
@@ -317,7 +379,7 @@ def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
         _WINOGRAD["calls"] += 1
         nws = lib.segmi_conv2d_winograd_workspace(d, 1)
         ws = workspace(nws, dev)
-        with span(lambda: _winograd_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        with span(lambda: _winograd_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
             check(lib.segmi_conv2d_winograd_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, ws.data_ptr(), nws, st),
                   "conv2d_winograd_dgrad")
         return
@@ -445,7 +507,10 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
-            _conv_wgrad(d, C, x, dy, dwb)
+            if dw_owned is not None:
+                _conv_wgrad_param(weight, d, C, x, dy, dwb)
+            else:
+                _conv_wgrad(d, C, x, dy, dwb)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             rows = N * P * Q
@@ -494,7 +559,10 @@ class _Conv2dSkipFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
-            _conv_wgrad(d, C, x, dy, dwb)
+            if dw_owned is not None:
+                _conv_wgrad_param(weight, d, C, x, dy, dwb)
+            else:
+                _conv_wgrad(d, C, x, dy, dwb)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         return dskip, dw, None, None, None
 

@@ -50,8 +50,7 @@ MEMBOUND_BYTES = {
 
 class KernelTimer:
     def __init__(self, membound=False):
-        self.spans = []   # (name, flops, bytes, start_event, end_event)
-        self.details = []
+        self.spans = []   # {"name", "flops", "bytes", "a", "b", "detail", "inner"}
         self.membound = membound
         self._patched = {}
 
@@ -80,43 +79,77 @@ class KernelTimer:
             self._patched = {}
 
     @contextlib.contextmanager
-    def _span(self, name, flops, nbytes, detail=None):
+    def _span(self, name, flops, nbytes, detail=None, inner=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rec = {"name": name, "flops": flops, "bytes": nbytes, "a": a, "b": b, "detail": detail, "inner": None}
+        if inner is not None:
+            # composite call (a Winograd pass = transforms + ONE batched contraction launch): the library records a second
+            # event pair right around the contraction (segmi_conv2d_winograd_trace), so the MFMA-bound kernel is timed apart
+            # from the HBM-bound transforms.  The events must exist before their handles can be handed over: record once here.
+            from ._lib import lib
+            ia, ib = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ia.record()
+            ib.record()
+            lib.segmi_conv2d_winograd_trace(ia.cuda_event, ib.cuda_event)
+            rec["inner"] = {"flops": inner[0], "bytes": inner[1], "a": ia, "b": ib}
         a.record()
         yield
         b.record()
-        self.spans.append((name, flops, nbytes, a, b))
-        self.details.append(detail)
+        self.spans.append(rec)
 
     def by_detail(self):
-        """[(name, detail, launches, total_ms, flops, bytes)] grouped by (name, detail), slowest first (synchronises)."""
+        """[(name, detail, launches, total_ms, flops, bytes)] grouped by (name, detail), slowest first (synchronises).  Composite
+        (Winograd) calls are ONE row each: whole-call time against the ALGORITHMIC (direct-convolution) FLOPs."""
         torch.cuda.synchronize()
         acc = {}
-        for (name, flops, nbytes, a, b), det in zip(self.spans, self.details):
-            r = acc.setdefault((name, det), [0, 0.0, 0, 0])
+        for s in self.spans:
+            r = acc.setdefault((s["name"], s["detail"]), [0, 0.0, 0, 0])
             r[0] += 1
-            r[1] += a.elapsed_time(b)
-            r[2] += flops
-            r[3] += nbytes
+            r[1] += s["a"].elapsed_time(s["b"])
+            r[2] += s["flops"]
+            r[3] += s["bytes"]
         return sorted(((k[0], k[1], v[0], v[1], v[2], v[3]) for k, v in acc.items()), key=lambda t: -t[3])
 
     def summary(self):
-        """{name: {"launches", "total_ms", "avg_us", "flops", "bytes"}} (synchronises)."""
+        """{kernel name: {"launches", "total_ms", "avg_us", "flops", "eff_flops", "bytes"}} (synchronises).
+
+        `flops` are EXECUTED FLOPs, `eff_flops` the algorithmic FLOPs of the direct convolution the launch stands for (equal
+        for the direct kernels).  A composite Winograd call contributes two rows: its contraction under the name of the kernel
+        that runs it (the batched implicit-GEMM / filter-gradient kernel, executed = 32*T*C*K transform-domain FLOPs, timed by the
+        inner event pair) and "winograd transforms" (whole call minus contraction, 0 FLOPs)."""
         torch.cuda.synchronize()
-        out = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0, "bytes": 0})
-        for name, flops, nbytes, a, b in self.spans:
-            r = out[name]
+        out = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0, "eff_flops": 0, "bytes": 0})
+        for s in self.spans:
+            whole = s["a"].elapsed_time(s["b"])
+            if s["inner"] is None:
+                r = out[s["name"]]
+                r["launches"] += 1
+                r["total_ms"] += whole
+                r["flops"] += s["flops"]
+                r["eff_flops"] += s["flops"]
+                r["bytes"] += s["bytes"]
+                continue
+            inn = s["inner"]
+            core = min(whole, inn["a"].elapsed_time(inn["b"]))
+            r = out[s["name"].split(": 16 x ", 1)[-1]]
             r["launches"] += 1
-            r["total_ms"] += a.elapsed_time(b)
-            r["flops"] += flops
-            r["bytes"] += nbytes
+            r["total_ms"] += core
+            r["flops"] += inn["flops"]
+            r["eff_flops"] += s["flops"]
+            r["bytes"] += inn["bytes"]
+            t = out["winograd transforms (" + s["name"].split(":", 1)[0].split()[-1] + ")"]
+            t["launches"] += 1
+            t["total_ms"] += whole - core
+            t["bytes"] += s["bytes"]
         for r in out.values():
             r["avg_us"] = 1e3 * r["total_ms"] / r["launches"]
         return dict(out)
 
 
-def span(name, flops=0, nbytes=0, detail=None):
-    """Context manager around one C-ABI launch; `name`/`detail` may be callables evaluated only when timing."""
+def span(name, flops=0, nbytes=0, detail=None, inner=None):
+    """Context manager around one C-ABI launch; `name`/`detail`/`inner` may be callables evaluated only when timing.
+    inner = (executed FLOPs, operand bytes) of the contraction inside a composite Winograd call (see KernelTimer._span)."""
     if _ACTIVE is None:
         return _NULL
-    return _ACTIVE._span(name() if callable(name) else name, flops, nbytes, detail() if callable(detail) else detail)
+    return _ACTIVE._span(name() if callable(name) else name, flops, nbytes, detail() if callable(detail) else detail,
+                         inner() if callable(inner) else inner)

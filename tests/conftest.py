@@ -31,3 +31,42 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+# ---- both convolution algorithms under the same tolerances -------------------------------------------------------------------
+# Winograd F(2x2,3x3) is the default algorithm of the eligible 3x3 stride-1 layers (segmi/ops.py); the direct implicit-GEMM
+# kernels serve every other layer and stay selectable (SEGMI_CONV_WINOGRAD=0).  The model-level GPU tests and the generic
+# convolution test run once per algorithm, with NO algorithm-specific tolerance: "winograd" = the shipped default thresholds,
+# "winograd_all" = every 3x3 stride-1 pad==dil problem regardless of size (op-level test), "direct" = Winograd off.
+_ALGO_MODULES = {"test_pspnet_gpu", "test_unet_gpu", "test_deeplab_gpu", "test_fullsize_golden_gpu", "test_trainer_gpu"}
+_ALGO_FUNCTIONS = {("test_ops_gpu", "test_conv2d_fwd_dgrad_wgrad"): ["winograd_all", "direct"],
+                   ("test_fullsize_properties_gpu", "test_conv_adjoint_identities_and_definition_at_full_size"): ["winograd", "direct"]}
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.rsplit(".", 1)[-1]
+    modes = _ALGO_FUNCTIONS.get((mod, metafunc.function.__name__))
+    if modes is None and mod in _ALGO_MODULES and "cuda" in metafunc.fixturenames:
+        modes = ["winograd", "direct"]
+    if modes and "conv_algorithm" in metafunc.fixturenames:
+        metafunc.parametrize("conv_algorithm", modes, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def conv_algorithm(request):
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    from segmi import ops
+    prev = ops.get_conv_winograd()
+    if mode == "direct":
+        ops.set_conv_winograd(False, wgrad=False)
+    elif mode == "winograd_all":
+        ops.set_conv_winograd(True, min_channels=0, min_subgrid=1, wgrad=True)
+    else:
+        ops.set_conv_winograd(True, wgrad=True)
+    try:
+        yield mode
+    finally:
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"])

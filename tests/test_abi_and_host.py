@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 5
+    assert lib.segmi_abi_version() == 6
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
@@ -144,14 +144,23 @@ def test_winograd_planning_and_dispatch_rules():
                 desc(8, 64, 510, 512, 3, 1, 1, 1)):
         assert lib.segmi_conv2d_winograd_ok(bad, 0) == 0 and lib.segmi_conv2d_winograd_workspace(bad, 0) == 0
     assert lib.segmi_conv2d_winograd_ok(d, 2) == 0
-    # filter gradient in the Winograd domain: both transformed operands (tile rows padded to whole 32-row chunks), 16 product
-    # planes and the split-K scratch of ONE 1x1 contraction (the 16 run one after the other)
+    # filter gradient in the Winograd domain: both transformed operands (tile rows padded to whole 32-row chunks) and the
+    # partial sums [nsplit][16][K][C] of the ONE batched contraction launch (nsplit = the "splitk=" of the variant name)
+    import ctypes
+
+    def wg_splits(dd):
+        buf = ctypes.create_string_buffer(128)
+        assert lib.segmi_conv2d_winograd_wgrad_variant(dd, buf, 128) == 0
+        name = buf.value.decode()
+        assert name.startswith("winograd_f2x2_3x3 wgrad: 16 x conv_wgrad_dma_kernel<"), name
+        return int(name.rsplit("splitk=", 1)[1])
     assert lib.segmi_conv2d_winograd_wgrad_ok(d) == 1 and lib.segmi_conv2d_winograd_wgrad_ok(desc(8, 64, 512, 512, 3, 2, 1, 1)) == 0
-    one = ConvDesc(1, 1, T, 512, 512, 1, 1, 1, T, 1, 0, 1, 512, 512)
-    assert lib.segmi_conv2d_winograd_wgrad_workspace(d) == 2 * al(16 * T * 512 * 4) + al(16 * 512 * 512 * 4) + al(lib.segmi_conv2d_wgrad_workspace(one))
+    ns = wg_splits(d)
+    assert 1 <= ns <= 64
+    assert lib.segmi_conv2d_winograd_wgrad_workspace(d) == 2 * al(16 * T * 512 * 4) + al(ns * 16 * 512 * 512 * 4)
     T97 = (4 * 4 * 25 * 25 + 31) & ~31
-    one97 = ConvDesc(1, 1, T97, 256, 256, 1, 1, 1, T97, 1, 0, 1, 256, 256)
-    assert lib.segmi_conv2d_winograd_wgrad_workspace(d97) == 2 * al(16 * T97 * 256 * 4) + al(16 * 256 * 256 * 4) + al(lib.segmi_conv2d_wgrad_workspace(one97))
+    ns97 = wg_splits(d97)
+    assert lib.segmi_conv2d_winograd_wgrad_workspace(d97) == 2 * al(16 * T97 * 256 * 4) + al(ns97 * 16 * 256 * 256 * 4)
     # dispatch rule
     prev = ops.get_conv_winograd()
     try:

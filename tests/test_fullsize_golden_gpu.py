@@ -19,7 +19,13 @@ and asserts
              attainable between two fp32 summation orders (torch-CPU NCHW vs channels_last already differ on 341 of 1 M
              pixels); every remaining mismatch is a numerical tie, and the count is printed
   * loss  :  |d| < 1e-4
-  * gradients (BN batch statistics => ill conditioned): per-tensor norm within 10 %, median within 1 %.
+  * gradients (BN batch statistics => ill conditioned): per-tensor norm within 10 %, median within 1 %; AND the
+             stored per-tensor digests (64 strided samples + the first 8 values of every parameter gradient, oracle/gen_golden.py
+             `_grad_digest`): relative L2 distance of the sampled values per tensor, median <= 5 %, max <= 50 % — a permuted,
+             sign-flipped or zeroed slice with the right norm scores 141 % / 200 % / 100 % and fails, rounding noise of two fp32
+             evaluations of a batch-statistics network does not (the measured values are printed).
+Batches: cfg2 8 (= BASELINE), cfg3 the batch stored in the fixture (16 = BASELINE when the build container could hold it), cfg4 one
+shard of 4 (= BASELINE per GPU), cfg5 8 (= BASELINE per GPU); the test id carries the batch.
 The same file is the acceptance test of any alternative conv arithmetic (SEGMI_CONV_MATH): identical tolerances.
 """
 import os
@@ -78,29 +84,65 @@ def run_fullsize_audit(name, device):
         res["max_abs_daux"] = (aux.detach()[:, :, ::2 * s, ::2 * s].cpu() - rec["aux"]).abs().max().item()
         res["aux_absmax"] = rec["aux"].abs().max().item()
     named = dict(m.named_parameters())
-    rel = []
+    rel, srel = [], []
     for k, dg in rec["grads"].items():
         g = named[k].grad.detach().reshape(-1)
         rel.append((abs(g.norm().item() - dg["norm"]) / (dg["norm"] + 1e-30), k, dg["norm"]))
+        step = max(1, g.numel() // 64)
+        got = torch.cat([g[::step][:64], g[:8]]).cpu().double()
+        ref = torch.cat([dg["sample"], dg["head"]]).double()
+        srel.append(((got - ref).norm().item() / (ref.norm().item() + 1e-30), k, dg["norm"]))
     res["grad_norm_rel_err_median"] = statistics.median(r[0] for r in rel)
     floor = 1e-5 * max(r[2] for r in rel)        # analytically-zero gradients (BN bias in front of a batch-stat BN) are rounding noise
     res["grad_norm_rel_err_max"], res["grad_norm_worst"] = max(((r[0], r[1]) for r in rel if r[2] > floor), default=(0.0, ""))
+    res["grad_sample_rel_err_median"] = statistics.median(r[0] for r in srel)
+    res["grad_sample_rel_err_max"], res["grad_sample_worst"] = max(((r[0], r[1]) for r in srel if r[2] > floor), default=(0.0, ""))
+    res["batch"] = N
     sd_after = m.state_dict()
     res["running_ok"] = all(torch.allclose(sd_after[k].cpu().float(), v.float(), rtol=1e-4, atol=1e-5) for k, v in rec["running"].items())
     return res
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
-def test_fullsize_step_matches_reference_golden(cuda, name):
+def _fixture_batch(name):
+    # (the id is computed at collection time from the fixture header: the batch is part of the numerics under batch-statistics BN)
+    try:
+        return torch.load(os.path.join(GOLD, "full_%s.pt" % name), weights_only=False)["input_shape"][0]
+    except Exception:
+        return 0
+
+
+def audit_line(r, algo):
     from segmi import ops
+    return ("[fullsize %s batch %d, conv math %s, %s] pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
+            "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
+            "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s) | "
+            "grad-sample rel-L2 median %.2e max %.2e (%s)"
+            % (r["config"], r["batch"], ops.get_conv_math(), algo, r["pixels"], r["mismatches"], r["max_margin_among_mismatches"],
+               r["max_abs_dlogit"], r["logit_absmax"], r["hip_err_f64"], r["ref_err_f64"], r["mismatches_outside_margin"],
+               r["near_ties_in_oracle(margin<2d)"], r["loss"], r["loss_ref"], r["grad_norm_rel_err_median"], r["grad_norm_rel_err_max"],
+               r["grad_norm_worst"], r["grad_sample_rel_err_median"], r["grad_sample_rel_err_max"], r["grad_sample_worst"]))
+
+
+def record_audit(r, algo):
+    """Append the audit to gpurun_out/audit.json (independent of pytest's output capture) and return its one-line form."""
+    import json
+    from segmi import ops
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "audit.json")
+        doc = json.load(open(path)) if os.path.exists(path) else {}
+        doc["%s/%s/%s" % (r["config"], ops.get_conv_math(), algo)] = {k: v for k, v in r.items() if isinstance(v, (int, float, str, bool))}
+        json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return audit_line(r, algo)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"], ids=lambda n: "%s-batch%d" % (n, _fixture_batch(n)))
+def test_fullsize_step_matches_reference_golden(cuda, name, conv_algorithm):
     r = run_fullsize_audit(name, cuda)
-    print("\n[fullsize %s, conv math %s] pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
-          "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
-          "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s)"
-          % (name, ops.get_conv_math(), r["pixels"], r["mismatches"], r["max_margin_among_mismatches"], r["max_abs_dlogit"],
-             r["logit_absmax"], r["hip_err_f64"], r["ref_err_f64"], r["mismatches_outside_margin"], r["near_ties_in_oracle(margin<2d)"],
-             r["loss"], r["loss_ref"],
-             r["grad_norm_rel_err_median"], r["grad_norm_rel_err_max"], r["grad_norm_worst"]))
+    print("\n" + record_audit(r, conv_algorithm or "default"))
     if r["ref_err_f64"] <= 5e-4 * r["logit_absmax"]:
         assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
     else:                                     # the reference's own fp32 rounding noise is already ~1e-3 of the logit scale here
@@ -110,4 +152,5 @@ def test_fullsize_step_matches_reference_golden(cuda, name):
         assert r["max_abs_daux"] <= 1e-3 * r["aux_absmax"], r
     assert abs(r["loss"] - r["loss_ref"]) < 1e-4, r
     assert r["grad_norm_rel_err_median"] <= 1e-2 and r["grad_norm_rel_err_max"] <= 0.1, r
+    assert r["grad_sample_rel_err_median"] <= 5e-2 and r["grad_sample_rel_err_max"] <= 0.5, r
     assert r["running_ok"], r

@@ -223,3 +223,37 @@ def test_pspnet_factored_and_unfactored_paths_agree(cuda, monkeypatch):
     for k in g0:
         e = (g0[k] - g1[k]).norm().item() / (g0[k].norm().item() + 1e-30)
         assert e <= 1e-3, (k, e)
+
+
+def test_wgrad_side_stream_is_bit_identical(cuda):
+    """Filter gradients launched on the side HIP stream (segmi.ops.set_wgrad_stream) run the SAME kernels on the same operands:
+    logits, loss and every parameter gradient of two consecutive training steps must equal the in-order run bit for bit, and
+    the side stream must actually have been used."""
+    from segmi import ops
+    gold = _gold()
+    classes = 7
+    x, t = synth_batch(2, 3, 96, 96, classes, ignore_index=255, seed=3)
+    res = {}
+    prev = ops.get_wgrad_stream()["on"]
+    try:
+        for mode in (False, True):
+            ops.set_wgrad_stream(mode)
+            before = ops.get_wgrad_stream()["launches"]
+            m, _ = _build(cuda, _manifest(gold, classes), classes, seed=1)
+            opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+            outs = []
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                out, _aux, loss = _step(m, x, t, cuda)
+                opt.step()
+                outs.append((out.detach().clone(), float(loss)))
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+            res[mode] = (outs, grads, ops.get_wgrad_stream()["launches"] - before)
+    finally:
+        ops.set_wgrad_stream(prev)
+    assert res[False][2] == 0 and res[True][2] >= 100, (res[False][2], res[True][2])
+    for (oa, la), (ob, lb) in zip(res[False][0], res[True][0]):
+        assert torch.equal(oa, ob) and la == lb
+    assert res[False][1].keys() == res[True][1].keys()
+    for k, g in res[False][1].items():
+        assert torch.equal(g, res[True][1][k]), k

@@ -112,5 +112,29 @@ quick)
 spawn)
   # the self-launching multi-GPU bench on a 1-GPU box: two ranks share cuda:0 (gloo on device tensors; RCCL needs one GPU per rank)
   ( timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -4 ) > gpurun_out/spawn.log; cat gpurun_out/spawn.log ;;
+r3a)
+  # round 3, call 1: first hardware run of the merged Winograd branch (filter gradient, batch-aware tiles, wgrad epilogue pinning)
+  ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=1 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_pspnet_gpu.py tests/test_unet_gpu.py -m gpu -q -rf 2>&1 | tail -40 ) > gpurun_out/r3a_wino_tests.log
+  cat gpurun_out/r3a_wino_tests.log
+  ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3a_bench_direct.log
+  ( SEGMI_CONV_WINOGRAD=1 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3a_bench_wino.log
+  ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=1 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3a_bench_winowg.log
+  for f in direct wino winowg; do python -c "import json,sys; d=json.loads(open('gpurun_out/r3a_bench_$f.log').read()); print('$f', d['value'], d['ms_per_step'], d['roofline']['all_conv'])" 2>&1 | tail -1; done
+  ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=1 timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r3a_conv_layers_winowg.txt; tail -2 gpurun_out/r3a_conv_layers_winowg.txt
+  ( SEGMI_CONV_WINOGRAD=1 SEGMI_CONV_WINOGRAD_WGRAD=1 timeout 1200 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/r3a_pytest_gpu_winowg.log
+  cat gpurun_out/r3a_pytest_gpu_winowg.log ;;
+r3b)
+  # round 3, call 2: Winograd default (batched filter gradient), both-algorithm suite, bench + experiments, profiles
+  ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_pspnet_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -x 2>&1 | tail -30 ) > gpurun_out/r3b_quick_tests.log
+  tail -5 gpurun_out/r3b_quick_tests.log
+  ( timeout 400 python bench.py --no-cpu 2>&1 | tail -1 ) > gpurun_out/r3b_bench.log
+  ( SEGMI_WGRAD_STREAM=1 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3b_bench_side.log
+  ( SEGMI_CONV_WINOGRAD_MIN_CHANNELS=128 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3b_bench_min128.log
+  ( SEGMI_CONV_WINOGRAD_MIN_CHANNELS=64 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3b_bench_min64.log
+  for f in bench bench_side bench_min128 bench_min64; do python -c "import json,sys; d=json.loads(open('gpurun_out/r3b_$f.log').read()); r=d['roofline']; print('$f', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['frac'], r['executed_step_frac'], r['all_conv']['ms_per_step'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1; done
+  ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r3b_conv_layers.txt; tail -1 gpurun_out/r3b_conv_layers.txt
+  ( timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/r3b_pytest_gpu.log
+  cat gpurun_out/r3b_pytest_gpu.log
+  ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3b_smoke.log; cat gpurun_out/r3b_smoke.log ;;
 esac
 done

@@ -15,7 +15,8 @@ import sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_cfg2_conv_traffic_f32.json"
 STEPS = 2.0
-CONV = ("conv_dma_kernel", "conv_wgrad_dma_kernel", "splitk_reduce_kernel", "conv_gather_kernel", "conv_wgrad_kernel")
+CONV = ("conv_dma_kernel", "conv_wgrad_dma_kernel", "splitk_reduce_kernel", "conv_gather_kernel", "conv_wgrad_kernel",
+        "wino_input_kernel", "wino_output_kernel", "wino_filter_kernel", "wino_dy_kernel", "wino_filter_grad_kernel")
 
 
 def short(n):
@@ -45,7 +46,8 @@ cw = sum(v for k, v in write.items() if k.startswith(CONV)) * 1024.0
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 "
               "--warmup 1 --no-cpu --no-roofline; MI355X (tools/gpu_round.sh pmc + tools/traffic_json.py)",
-    "scope": "all conv implicit-GEMM launches (conv_dma_kernel*, conv_wgrad_dma_kernel*, splitk_reduce_kernel) of ONE cfg2 training step",
+    "scope": "all conv launches (conv_dma_kernel*, conv_wgrad_dma_kernel*, splitk_reduce_kernel, the Winograd transforms wino_*) of ONE cfg2 training step",
+    "conv_winograd": any(k.startswith("wino_") for k in fetch),
     "fetch_bytes_raw": cf,
     "fetch_bytes_corrected": 2 * cf,
     "write_bytes": cw,
