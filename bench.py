@@ -391,7 +391,17 @@ def main():
                                   "algorithm at the same tolerances (tests/conftest.py: conv_algorithm)"}
         finally:
             segmi_ops.set_conv_winograd(wst["on"], wgrad=wst["wgrad"])
+    # ranks that actually took part in an RCCL collective on this communicator (an all-reduce of ones over the device tensors),
+    # not dist.get_world_size(): a rank that fell back to another transport or never joined the communicator shows up here
+    rccl_ranks = 0
     if ddp:
+        if backend == "nccl":
+            ones = torch.ones(1, device=device)
+            dist.all_reduce(ones)
+            rccl_ranks = int(ones.item())
+            pgb = dist.distributed_c10d._get_default_group()._get_backend(device)
+            if hasattr(pgb, "_is_initialized") and not pgb._is_initialized():
+                rccl_ranks = 0
         dist.barrier()
 
     cpu = None
@@ -412,7 +422,7 @@ def main():
                                                                       " (SyncBN)" if args.sync_bn and ddp else ""),
                        "global_batch": nb * world, "parallelism": "dp%d" % world,
                        "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
-                       "rccl_ranks": (dist.get_world_size() if ddp and backend == "nccl" else 0), "final_loss": round(final_loss, 5),
+                       "rccl_ranks": rccl_ranks, "final_loss": round(final_loss, 5),
                        "conv_math": args.conv_math, "conv_winograd": bool(wino_default),
                        "conv_algorithm": ("winograd_f2x2_3x3 (fwd, dgrad, wgrad) for the 3x3 stride-1 layers with >= %d channels, direct implicit "
                                           "GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"]) if wino_default else "direct implicit GEMM",

@@ -48,9 +48,10 @@ class _TVBasicBlock(nn.Module):
         if self.downsample is None:
             out, identity = self.conv1(x, with_skip=True)
         else:
-            out, identity = self.conv1(x), self.downsample(x)
+            # (SyncBN: bn2 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
+            out, identity = self.conv1(x), (None if snn.sync_tail(self.bn2, self.downsample) else self.downsample(x))
         out = self.bn1(out, relu=True)
-        return self.bn2(self.conv2(out), residual=identity, relu=True)
+        return snn.residual_out(self.conv2(out), self.bn2, self.downsample, x, identity)
 
 
 class _TVBottleneck(nn.Module):
@@ -72,10 +73,11 @@ class _TVBottleneck(nn.Module):
         if self.downsample is None:
             out, identity = self.conv1(x, with_skip=True)     # the skip gradient is accumulated by conv1's dgrad, no autograd add
         else:
-            out, identity = self.conv1(x), self.downsample(x)
+            # (SyncBN: bn3 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
+            out, identity = self.conv1(x), (None if snn.sync_tail(self.bn3, self.downsample) else self.downsample(x))
         out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=identity, relu=True)
+        return snn.residual_out(self.conv3(out), self.bn3, self.downsample, x, identity)
 
 
 _TV_LAYERS = {"resnet18": (_TVBasicBlock, (2, 2, 2, 2)), "resnet34": (_TVBasicBlock, (3, 4, 6, 3)),

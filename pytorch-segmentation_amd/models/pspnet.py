@@ -44,7 +44,12 @@ class _PSPModule(nn.Module):
         # all pyramid levels pooled in ONE pass over the feature map (and one gradient write in backward); the
         # AdaptiveAvgPool2d modules stay in `stages` so checkpoint keys / indices are the reference's
         pooled = ops.pyramid_pool(features, bins) if fused else [stage[0](features) for stage in self.stages]
-        branches = [snn.run_fused(list(stage)[1:], p) for stage, p in zip(self.stages, pooled)]      # [N, C/4, b, b] each
+        if all(len(stage) == 4 and isinstance(stage[2], snn.BatchNorm2d) and isinstance(stage[3], nn.ReLU) for stage in self.stages):
+            # conv of every level first, then the four BN+ReLU as one group: SyncBN layers share one all-gather / one all-reduce
+            # (ops.sync_batch_norm_group; local BN: exactly the layer-by-layer calls)
+            branches = ops.sync_batch_norm_group([stage[1](p) for stage, p in zip(self.stages, pooled)], [stage[2] for stage in self.stages])
+        else:
+            branches = [snn.run_fused(list(stage)[1:], p) for stage, p in zip(self.stages, pooled)]  # [N, C/4, b, b] each
         conv = self.bottleneck[0]
         if self.factored and self._factorable(conv, features, branches):
             # concat + 3x3 convolution in factored form: the convolution runs over the feature channels only, the (linear)

@@ -37,9 +37,10 @@ class BasicBlock(nn.Module):
         if self.downsample is None:
             out, identity = self.conv1(x, with_skip=True)
         else:
-            out, identity = self.conv1(x), self.downsample(x)
+            # (SyncBN: bn2 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
+            out, identity = self.conv1(x), (None if snn.sync_tail(self.bn2, self.downsample) else self.downsample(x))
         out = self.bn1(out, relu=True)
-        return self.bn2(self.conv2(out), residual=identity, relu=True)
+        return snn.residual_out(self.conv2(out), self.bn2, self.downsample, x, identity)
 
 
 class Bottleneck(nn.Module):
@@ -62,10 +63,11 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             out, identity = self.conv1(x, with_skip=True)     # the skip gradient is accumulated by conv1's dgrad, no autograd add
         else:
-            out, identity = self.conv1(x), self.downsample(x)
+            # (SyncBN: bn3 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
+            out, identity = self.conv1(x), (None if snn.sync_tail(self.bn3, self.downsample) else self.downsample(x))
         out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=identity, relu=True)
+        return snn.residual_out(self.conv3(out), self.bn3, self.downsample, x, identity)
 
 
 class ResNet(nn.Module):

@@ -18,6 +18,8 @@ while still leaving the first bucket's transfer overlapped with ~3/4 of backward
 Everything here is device-agnostic torch.distributed code (tests run it on CPU with gloo, world 2);
 on the GPU box backend "nccl" IS RCCL.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -80,7 +82,18 @@ class GradAllReducer:
             cur_bytes += nb
         if cur:
             self._make_bucket(cur)
+        # Convolution filters on the GPU: the filter-gradient kernels write straight into the bucket slot (segmi.ops._GRAD_SLOTS), so
+        # their .grad is left None at zero_grad() and autograd ADOPTS the slot alias the kernel filled — no in-place add, no copy.
+        self._slot_params = [p for p in self.params if p.device.type == "cuda" and p.dim() == 4]
+        self._ops = None
+        if self._slot_params:
+            from . import ops as _ops
+            self._ops = _ops
+            _ops.register_grad_slots({p: self._where[id(p)][1] for p in self._slot_params})
+            for p in self._slot_params:
+                p.grad = None
         self._fired = set()        # id(param) of the parameters whose gradient arrived in the current iteration
+        self.check_unused = os.environ.get("SEGMI_DDP_CHECK_UNUSED", "0") == "1"
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _make_bucket(self, params):
@@ -104,6 +117,10 @@ class GradAllReducer:
             b["pending"], b["launched"], b["work"] = len(b["params"]), False, None
         for p in self.params:
             p.grad = self._where[id(p)][1]
+        for p in self._slot_params:
+            p.grad = None                 # adopted from the slot alias the wgrad kernel writes (see __init__)
+        if self._ops is not None:
+            self._ops.reset_grad_slots(self._slot_params)
         self._fired.clear()
 
     def _on_grad(self, p):
@@ -126,6 +143,8 @@ class GradAllReducer:
             return
         op = dist.ReduceOp.SUM
         if self.side is not None:
+            if self._ops is not None:
+                self._ops.wgrad_stream_join()     # filter gradients launched on the wgrad side stream belong to this bucket too
             ev = torch.cuda.Event()
             ev.record()                       # gradients of this bucket are complete on the compute stream
             self.side.wait_event(ev)
@@ -159,9 +178,12 @@ class GradAllReducer:
         # executed path): the reference leaves their .grad None, so torch.optim.SGD skips them — no weight decay, no momentum
         # update.  Their bucket slots take part in the reduction as zeros (all ranks agree); the view is hidden from the
         # optimizer until zero_grad() re-attaches it for the next iteration.
+        if self.check_unused and self.collective:
+            self._assert_fired_consistent()
         for p in self.params:
             if id(p) not in self._fired:
                 p.grad = None
+        self._fired.clear()               # (also cleared by zero_grad(); a caller using optimizer.zero_grad() must not see stale marks)
         for i, b in enumerate(self.buckets):
             w = b["work"]
             if w is not None:
@@ -176,6 +198,19 @@ class GradAllReducer:
             for i in range(len(self.buckets), optimizer.num_segments):
                 optimizer.step_segment(i)     # parameters the reducer does not own (none for a whole-model reducer)
 
+    def _assert_fired_consistent(self):
+        """Debug check (SEGMI_DDP_CHECK_UNUSED=1): the set of parameters that received a gradient must be the same on every rank —
+        the decision to hide a parameter from the optimizer is rank-local, and ranks that disagree (a data-dependent branch, an
+        aux head skipped on one rank) would apply weight decay / momentum differently and let the replicas drift apart."""
+        flags = torch.tensor([1.0 if id(p) in self._fired else 0.0 for p in self.params], device=self.device)
+        lo, hi = flags.clone(), flags.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        bad = torch.nonzero(lo != hi).flatten().tolist()
+        if bad:
+            raise RuntimeError("GradAllReducer: ranks disagree on which parameters received gradients this iteration "
+                               "(parameter indices %s): unused-parameter handling would let the replicas diverge" % bad[:8])
+
     def segments(self):
         """Parameter lists per bucket, in completion order — the layout `segmi.optim.SGD.set_segments` wants."""
         return [list(b["params"]) for b in self.buckets]
@@ -184,6 +219,8 @@ class GradAllReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._ops is not None:
+            self._ops.register_grad_slots({p: None for p in self._slot_params})
 
 
 class SyncBNContext:
@@ -201,6 +238,7 @@ class SyncBNContext:
         self.group = process_group
         self.clamp_mode = clamp_mode
         self.collectives = 0          # issued by this layer so far (bench.py --sync-bn reports the per-step total)
+        self.force_group = False      # tests: take the batched-collective code path in a single-rank group too
 
     @property
     def world(self):
@@ -218,6 +256,38 @@ class SyncBNContext:
         dist.all_gather_into_tensor(out, part.contiguous(), group=self.group)
         self.collectives += 1
         return out, w
+
+    def gather_stats_many(self, parts):
+        """gather_stats for several layers whose partials exist at the same time (parallel branches), as ONE all-gather of the
+        concatenated partials: [(all partials of layer i as [world*3*C_i], world)].  Values are exactly those of per-layer calls."""
+        w = self.world
+        if w == 1:
+            return [(p, 1) for p in parts]
+        flat = torch.cat([p.reshape(-1) for p in parts])
+        out = torch.empty(w * flat.numel(), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat, group=self.group)
+        self.collectives += 1
+        out = out.view(w, -1)
+        res, off = [], 0
+        for p in parts:
+            n = p.numel()
+            res.append((out[:, off:off + n].contiguous().view(-1), w))
+            off += n
+        return res
+
+    def reduce_sums_many(self, sums_list):
+        """reduce_sums for several layers in ONE all-reduce of the concatenated sums (new tensors; inputs untouched)."""
+        if self.world == 1:
+            return list(sums_list)
+        flat = torch.cat([s.reshape(-1) for s in sums_list])
+        dist.all_reduce(flat, group=self.group)
+        self.collectives += 1
+        res, off = [], 0
+        for s in sums_list:
+            n = s.numel()
+            res.append(flat[off:off + n])
+            off += n
+        return res
 
     def reduce_sums(self, sums):
         """[2*C] local {sum dy, sum dy*xhat} -> global sums (new tensor; the local ones remain the

@@ -101,6 +101,20 @@ class Dropout(nn.Dropout):
         return ops.dropout(x, self.p, self.training, channelwise=False)
 
 
+def sync_tail(bn, downsample):
+    """True when `bn` and the BN of a projection shortcut `downsample` = Sequential(conv, BN) are SyncBN layers that can share
+    their collectives (ops.sync_batch_norm_residual_tail): the block then evaluates relu(bn(.) + BN(conv(x))) as one node."""
+    return (downsample is not None and len(downsample) == 2 and isinstance(downsample[1], BatchNorm2d) and isinstance(bn, BatchNorm2d)
+            and ops.sync_groupable([bn, downsample[1]]))
+
+
+def residual_out(x_last, bn, downsample, x, identity):
+    """Last step of a residual block: relu(bn(x_last) + identity), or — identity is None: see sync_tail — the fused SyncBN tail."""
+    if identity is None:
+        return ops.sync_batch_norm_residual_tail(x_last, bn, downsample[0](x), downsample[1])
+    return bn(x_last, residual=identity, relu=True)
+
+
 def run_fused(modules, x):
     """Run a module chain, fusing BatchNorm2d -> ReLU pairs into one apply pass."""
     mods = list(modules)

@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -154,12 +154,48 @@ def _filter_krsc(w, Ce):
     return out
 
 
+# Gradient slots: a data-parallel reducer (segmi.distributed.GradAllReducer) keeps every parameter's gradient as a view into a
+# flat all-reduce bucket.  When it registers those views here, the filter-gradient kernels write STRAIGHT into the bucket: the
+# tensor handed to autograd is a fresh alias of the slot (its own TensorImpl, so AccumulateGrad adopts it without a clone or an
+# in-place add) and the reducer's hook finds the gradient already in place — no per-parameter copy in the N > 1 path.
+# A slot is handed out once per iteration (a filter used twice in one graph accumulates through the ordinary path).
+_GRAD_SLOTS = {}          # id(parameter) -> [view into the bucket, taken this iteration]
+
+
+def register_grad_slots(views):
+    """views: {parameter: gradient view with the parameter's shape and strides, or None to unregister that parameter}."""
+    for p, v in views.items():
+        if v is None:
+            _GRAD_SLOTS.pop(id(p), None)
+        else:
+            _GRAD_SLOTS[id(p)] = [v, False]
+
+
+def reset_grad_slots(params=None):
+    """Start of an iteration: every slot (of `params`, or all) may be handed out again."""
+    for e in (_GRAD_SLOTS.values() if params is None else (_GRAD_SLOTS[id(p)] for p in params if id(p) in _GRAD_SLOTS)):
+        e[1] = False
+
+
+def _take_grad_slot(w):
+    e = _GRAD_SLOTS.get(id(w))
+    if e is None or e[1] or w.grad is not None or e[0].shape != w.shape or e[0].stride() != w.stride() or (e[0].data_ptr() & 15):
+        return None
+    e[1] = True
+    v = e[0]
+    return v.as_strided(v.shape, v.stride(), v.storage_offset())
+
+
 def _filter_grad_buffer(w, Ce):
     """(flat KRSC buffer for the wgrad kernel, gradient tensor or None).  When the filter itself is KRSC in memory and needs no
     channel padding, the buffer IS the gradient tensor with the parameter's own (dense) strides — an owning tensor, not a view,
-    so autograd's AccumulateGrad adopts it instead of cloning it (44 device copies per PSPNet-R50 step otherwise)."""
+    so autograd's AccumulateGrad adopts it instead of cloning it (44 device copies per PSPNet-R50 step otherwise) — or, under a
+    data-parallel reducer, a fresh alias of the parameter's slot in the all-reduce bucket (see _GRAD_SLOTS)."""
     K, C, R, S = w.shape
     if Ce == C and _filter_is_krsc(w):
+        dw = _take_grad_slot(w) if _GRAD_SLOTS else None
+        if dw is not None:
+            return dw, dw
         mf = torch.channels_last if (R > 1 or S > 1 or not w.is_contiguous()) else torch.contiguous_format
         dw = torch.empty((K, C, R, S), device=w.device, dtype=torch.float32, memory_format=mf)
         return dw, dw
@@ -347,6 +383,14 @@ def _join_wgrad_stream():
     _WGRAD_SIDE["armed"] = False
     for side in _WGRAD_SIDE["streams"].values():
         torch.cuda.current_stream(side.device).wait_stream(side)
+
+
+def wgrad_stream_join():
+    """Make the current stream wait for every filter gradient launched on the side stream so far (a gradient bucket is about to
+    be all-reduced in the middle of the backward pass).  No-op when the side stream is off."""
+    if _WGRAD_SIDE["streams"]:
+        for side in _WGRAD_SIDE["streams"].values():
+            torch.cuda.current_stream(side.device).wait_stream(side)
 
 
 def _conv_wgrad_param(weight, d, C, x, dy, dwb):
@@ -798,6 +842,184 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracke
                                  bool(training), float(momentum), float(eps), bool(relu), sync)
 
 
+# --------------------------------------------------------------------------- SyncBN layers that share their collectives
+# Exact SyncBN needs a layer's GLOBAL statistics before the layer can be applied, so its two collectives (all-gather of the
+# Welford partials forward, all-reduce of {sum dy, sum dy*xhat} backward) cannot be deferred — but layers whose INPUTS are ready
+# together can share them: the four pyramid-stage BNs of _PSPModule (models/pspnet.py:25-31) and, in every residual block with a
+# projection, bn3 + the downsample BN (models/resnet.py:137-145).  The second pair is possible in backward as well because the
+# gradient that reaches the projection branch is dy * [y > 0] — it does not depend on bn3's statistics — so both reductions run
+# before the ONE all-reduce.  Same kernels, same operands, same summation order as the one-layer path: results are bit-identical
+# to it (tests/test_distributed_gpu.py); 122 -> 108 collectives per PSPNet-R50 step (reference: one master/slave exchange per
+# layer and direction, utils/sync_batchnorm/batchnorm.py:105-126).
+def _bn_member_stats(x):
+    N, C, H, W = x.shape
+    rows, dev = N * H * W, x.device
+    nws = lib.segmi_bn_stats_workspace(rows, C)
+    ws = workspace(nws, dev)
+    part = torch.empty(3 * C, device=dev, dtype=torch.float32)
+    check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, _stream()), "bn_stats")
+    return part
+
+
+def _bn_member_finalize(parts, nparts, C, gamma, beta, rm, rv, nbt, eps, momentum, clamp_mode, dev):
+    coef = torch.empty(4 * C + 4, device=dev, dtype=torch.float32)    # mean | invstd | scale | shift | global count
+    check(lib.segmi_bn_finalize(parts.data_ptr(), nparts, C, gamma.data_ptr() if gamma is not None else None,
+                                beta.data_ptr() if beta is not None else None, eps, momentum, clamp_mode,
+                                rm.data_ptr() if rm is not None else None, rv.data_ptr() if rv is not None else None,
+                                nbt.data_ptr() if nbt is not None else None, coef.data_ptr(), coef.data_ptr() + 4 * C,
+                                coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, coef.data_ptr() + 16 * C, _stream()), "bn_finalize")
+    return coef
+
+
+def _bn_member_apply(x, residual, coef, relu):
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, H, W, x.device)
+    check(lib.segmi_bn_apply(x.data_ptr(), ld_of(x), residual.data_ptr() if residual is not None else None,
+                             ld_of(residual) if residual is not None else 0, y.data_ptr(), ld_of(y), N * H * W, C,
+                             coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0, _stream()), "bn_apply")
+    return y
+
+
+def _bn_member_bwd_reduce(dy, x, y, coef, relu):
+    N, C, H, W = x.shape
+    rows, dev = N * H * W, x.device
+    sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+    nws = lib.segmi_bn_bwd_reduce_workspace(rows, C)
+    ws = workspace(nws, dev)
+    yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
+    check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C, coef.data_ptr(),
+                                  coef.data_ptr() + 4 * C, coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0,
+                                  sums.data_ptr(), ws.data_ptr(), nws, _stream()), "bn_bwd_reduce")
+    return sums
+
+
+def _bn_member_bwd_apply(dy, x, y, coef, gsums, relu, want_dres):
+    N, C, H, W = x.shape
+    dev = x.device
+    dx = empty_nhwc(N, C, H, W, dev)
+    dres = empty_nhwc(N, C, H, W, dev) if want_dres else None
+    yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
+    check(lib.segmi_bn_bwd_apply(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, N * H * W, C, coef.data_ptr(),
+                                 coef.data_ptr() + 4 * C, coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, gsums.data_ptr(),
+                                 0.0, coef.data_ptr() + 16 * C, 1 if relu else 0, 1, dx.data_ptr(), ld_of(dx),
+                                 dres.data_ptr() if dres is not None else None, ld_of(dres) if dres is not None else 0, _stream()),
+          "bn_bwd_apply")
+    return dx, dres
+
+
+class _SyncBNGroupFn(torch.autograd.Function):
+    """G independent SyncBN(+ReLU) layers, training mode, ONE all-gather forward and ONE all-reduce backward for all of them.
+    args: hyper = [(eps, momentum, relu, sync)] * G, then per member x, gamma, beta, running_mean, running_var, num_batches_tracked."""
+
+    @staticmethod
+    def forward(ctx, hyper, *args):
+        G = len(hyper)
+        mem = [args[6 * i:6 * i + 6] for i in range(G)]
+        xs = [to_nhwc(m[0], "sync_bn_group") for m in mem]
+        for x in xs:
+            if x.shape[1] & 3:
+                raise SegmiError("batch_norm: channel count must be a multiple of 4 (got %d)" % x.shape[1])
+        parts = [_bn_member_stats(x) for x in xs]
+        gathered = hyper[0][3].gather_stats_many(parts)
+        coefs, ys = [], []
+        for x, (_, g, b, rm, rv, nbt), (eps, mom, relu, sync), (pall, npart) in zip(xs, mem, hyper, gathered):
+            coef = _bn_member_finalize(pall, npart, x.shape[1], g, b, rm, rv, nbt, eps, mom, sync.clamp_mode, x.device)
+            coefs.append(coef)
+            ys.append(_bn_member_apply(x, None, coef, relu))
+        ctx.save_for_backward(*xs, *coefs)
+        ctx.hyper = hyper
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        hyper = ctx.hyper
+        G = len(hyper)
+        xs, coefs = ctx.saved_tensors[:G], ctx.saved_tensors[G:]
+        dys = [to_nhwc(dy, "sync_bn_group.backward") for dy in dys]
+        sums = [_bn_member_bwd_reduce(dy, x, None, coef, h[2]) for dy, x, coef, h in zip(dys, xs, coefs, hyper)]
+        gsums = hyper[0][3].reduce_sums_many(sums)
+        out = [None]
+        for i, (dy, x, coef, h, s, gs) in enumerate(zip(dys, xs, coefs, hyper, sums, gsums)):
+            C = x.shape[1]
+            dx = _bn_member_bwd_apply(dy, x, None, coef, gs, h[2], False)[0] if ctx.needs_input_grad[1 + 6 * i] else None
+            out += [dx, s[C:2 * C] if ctx.needs_input_grad[2 + 6 * i] else None, s[0:C] if ctx.needs_input_grad[3 + 6 * i] else None,
+                    None, None, None]
+        return tuple(out)
+
+
+class _SyncBNResidualTailFn(torch.autograd.Function):
+    """y = relu(bn_main(x_main) + bn_proj(x_proj)): the tail of a residual block with a projection shortcut
+    (models/resnet.py:137-145: bn3(conv3(.)) + downsample(x)), both SyncBN layers sharing one all-gather and one all-reduce.
+    args: hyper = [(eps, momentum, sync)] * 2 (main, proj), then x, gamma, beta, rm, rv, nbt for main and for proj."""
+
+    @staticmethod
+    def forward(ctx, hyper, *args):
+        mem = [args[0:6], args[6:12]]
+        xm, xp = to_nhwc(mem[0][0], "sync_bn_tail"), to_nhwc(mem[1][0], "sync_bn_tail")
+        if xm.shape != xp.shape or (xm.shape[1] & 3):
+            raise SegmiError("sync_bn_tail: main and projection branch must have the same shape, channels a multiple of 4")
+        parts = [_bn_member_stats(xm), _bn_member_stats(xp)]
+        gathered = hyper[0][2].gather_stats_many(parts)
+        coefs = []
+        for x, (_, g, b, rm, rv, nbt), (eps, mom, sync), (pall, npart) in zip((xm, xp), mem, hyper, gathered):
+            coefs.append(_bn_member_finalize(pall, npart, x.shape[1], g, b, rm, rv, nbt, eps, mom, sync.clamp_mode, x.device))
+        ident = _bn_member_apply(xp, None, coefs[1], False)
+        y = _bn_member_apply(xm, ident, coefs[0], True)
+        ctx.save_for_backward(xm, xp, y, coefs[0], coefs[1])
+        ctx.hyper = hyper
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, xp, y, cm, cp = ctx.saved_tensors
+        hyper = ctx.hyper
+        dy = to_nhwc(dy, "sync_bn_tail.backward")
+        C = xm.shape[1]
+        # the gradient reaching the projection branch is dy * [y > 0] whatever bn_main's statistics are: both reductions (the
+        # projection's with the ReLU mask of the block output) run before the one all-reduce
+        sm = _bn_member_bwd_reduce(dy, xm, y, cm, True)
+        sp = _bn_member_bwd_reduce(dy, xp, y, cp, True)
+        gm, gp = hyper[0][2].reduce_sums_many([sm, sp])
+        dxm, dres = _bn_member_bwd_apply(dy, xm, y, cm, gm, True, True)
+        dxp = _bn_member_bwd_apply(dres, xp, None, cp, gp, False, False)[0]
+        ni = ctx.needs_input_grad
+        return (None, dxm if ni[1] else None, sm[C:2 * C] if ni[2] else None, sm[0:C] if ni[3] else None, None, None, None,
+                dxp if ni[7] else None, sp[C:2 * C] if ni[8] else None, sp[0:C] if ni[9] else None, None, None, None)
+
+
+def sync_groupable(bns):
+    """All layers are SyncBN layers in training mode of one multi-rank process group (else the one-layer path applies)."""
+    first = getattr(bns[0], "sync", None)
+    if first is None or (first.world <= 1 and not first.force_group):
+        return False
+    return all(getattr(b, "sync", None) is not None and b.sync.group is first.group and b.training and b.track_running_stats
+               and b.momentum is not None for b in bns)
+
+
+def sync_batch_norm_group(xs, bns, relu=True):
+    """[bn(x) (+ReLU) for x, bn in zip(xs, bns)] with the SyncBN collectives of all layers batched into one all-gather (forward)
+    and one all-reduce (backward); falls back to layer-by-layer calls when the layers are not synchronized."""
+    if not sync_groupable(bns):
+        return [bn(x, relu=relu) for x, bn in zip(xs, bns)]
+    hyper = [(float(b.eps), float(b.momentum), bool(relu), b.sync) for b in bns]
+    args = []
+    for x, b in zip(xs, bns):
+        args += [x, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked]
+    return list(_SyncBNGroupFn.apply(hyper, *args))
+
+
+def sync_batch_norm_residual_tail(x_main, bn_main, x_proj, bn_proj):
+    """relu(bn_main(x_main) + bn_proj(x_proj)) — one all-gather / one all-reduce for the two SyncBN layers; None when the layers
+    are not synchronized (the caller then takes the one-layer path)."""
+    if not sync_groupable([bn_main, bn_proj]):
+        return None
+    hyper = [(float(b.eps), float(b.momentum), b.sync) for b in (bn_main, bn_proj)]
+    args = []
+    for x, b in ((x_main, bn_main), (x_proj, bn_proj)):
+        args += [x, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked]
+    return _SyncBNResidualTailFn.apply(hyper, *args)
+
+
 # --------------------------------------------------------------------------- relu / add
 class _ReluFn(torch.autograd.Function):
     @staticmethod
@@ -1100,14 +1322,15 @@ def interpolate_bilinear(x, size, align_corners=False):
     read them) but never read by the loss, and their gradient never exists."""
     y = _BilinearFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
     if x.dim() == 4 and x.shape[1] <= 256 and (int(size[0]) > x.shape[2] or int(size[1]) > x.shape[3]):
-        y._segmi_src = (x, bool(align_corners), y._version)
+        y._segmi_src = (x, bool(align_corners), y._version, x._version)
     return y
 
 
 def upsample_source(t):
-    """(low-resolution tensor, align_corners) if `t` is an unmodified result of interpolate_bilinear, else None."""
+    """(low-resolution tensor, align_corners) if `t` is an unmodified result of interpolate_bilinear of an unmodified source,
+    else None (an in-place edit of either tensor after the interpolation bumps its version counter: the loss then reads `t`)."""
     src = getattr(t, "_segmi_src", None)
-    if src is None or t._version != src[2]:
+    if src is None or t._version != src[2] or src[0]._version != src[3]:
         return None
     return src[0], src[1]
 

@@ -234,3 +234,36 @@ def test_syncbn_plugin_surface():
     dp = DataParallelWithCallback(m2, device_ids=[0])
     assert dp.module is m2 and patch_replication_callback(dp) is dp
     assert all(p.grad is not None for p in m2.parameters())   # bucket views attached
+
+
+def _sync_many_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmi.distributed import SyncBNContext
+        g = torch.Generator().manual_seed(100 + rank)
+        parts = [torch.randn(3 * c, generator=g) for c in (8, 16, 4)]
+        sums = [torch.randn(2 * c, generator=g) for c in (8, 16, 4)]
+        one, many = SyncBNContext(), SyncBNContext()
+        ref_g = [one.gather_stats(p) for p in parts]
+        ref_s = [one.reduce_sums(s) for s in sums]
+        got_g = many.gather_stats_many(parts)
+        got_s = many.reduce_sums_many(sums)
+        ok = all(torch.equal(a[0], b[0]) and a[1] == b[1] == world for a, b in zip(ref_g, got_g))
+        ok = ok and all(torch.equal(a, b) for a, b in zip(ref_s, got_s))
+        ok = ok and all(s.data_ptr() != gs.data_ptr() for s, gs in zip(sums, got_s))      # local sums stay the parameter gradients
+        ret[rank] = (ok, one.collectives, many.collectives)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_collectives_of_parallel_layers_are_batched():
+    """SyncBNContext.gather_stats_many / reduce_sums_many: one all-gather / one all-reduce for several layers' partials, values
+    identical to the per-layer calls (world 2, gloo)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sync_many_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, n_one, n_many = ret[r]
+        assert ok and n_one == 6 and n_many == 2, ret[r]
