@@ -102,7 +102,11 @@ int segmi_filter_krsc_to_crsk_multi(const segmi_filter_tx* table_dev, int n, lon
 int segmi_conv2d_winograd_ok(const segmi_conv_desc* d, int op);
 size_t segmi_conv2d_winograd_workspace(const segmi_conv_desc* d, int op);
 int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
-                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+                              int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+/* v_keep (optional, segmi_conv2d_winograd_v_bytes(d) bytes, 16-byte aligned, caller-owned): the forward pass writes its
+ * transformed input V = B^T x B there instead of into the workspace, so that segmi_conv2d_winograd_wgrad(v_kept = that buffer)
+ * contracts it again without re-reading x and re-writing 4x its size (memory for traffic: 288 GB of HBM per GPU). */
+size_t segmi_conv2d_winograd_v_bytes(const segmi_conv_desc* d);
 int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                                 void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, size_t len);
@@ -113,8 +117,8 @@ int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, s
  * operands and the partial sums [nsplit][16][K][C] (nsplit = the "splitk=" of segmi_conv2d_winograd_wgrad_variant). */
 int segmi_conv2d_winograd_wgrad_ok(const segmi_conv_desc* d);
 size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d);
-int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
-                                size_t workspace_bytes, segmi_stream_t stream);
+int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* v_kept, const float* dy, float* dw_krsc,
+                                void* workspace, size_t workspace_bytes, segmi_stream_t stream);   /* x may be NULL when v_kept is given */
 int segmi_conv2d_winograd_wgrad_variant(const segmi_conv_desc* d, char* buf, size_t len);
 /* Measurement hooks for the three Winograd passes (bench.py's roofline leg, segmi/profile.py): _tiles() = number of 2x2 output
  * tiles T (the 16 contractions are [T x Cin] x [Cin x Cout], i.e. 32*T*Cin*Cout executed FLOPs); _trace() hands over two

@@ -258,7 +258,7 @@ struct TraceScope {
     ~TraceScope() { if (e) hipEventRecord(e, st); }
 };
 
-struct WinoPlan { WinoGeom g; int Cin, Cout, ldm; size_t u_bytes, v_bytes, m_bytes; };
+struct WinoPlan { WinoGeom g; long Tpad; int Cin, Cout, ldm; size_t u_bytes, v_bytes, m_bytes; };
 
 // op 0: y = conv(x, w); op 1: dx = conv^T(dy, w).  Cin/Cout are the contraction / output widths of the pass.
 bool wino_plan(const segmi_conv_desc* d, int op, WinoPlan* pl) {
@@ -270,18 +270,20 @@ bool wino_plan(const segmi_conv_desc* d, int op, WinoPlan* pl) {
     pl->Cout = op == 0 ? d->K : d->C;
     pl->ldm = (pl->Cout + 3) & ~3;
     const long T = pl->g.T;
-    if (T * pl->Cin * 4 >= 0xFFFFFF00L || T * pl->ldm * 4 >= 0xFFFFFF00L || (long)pl->Cout * pl->Cin * 4 >= 0xFFFFFF00L) return false;
+    pl->Tpad = (T + 31) & ~31L;       // V planes hold whole 32-row chunks (zero rows past T): the filter gradient can contract a kept V
+    if (pl->Tpad * pl->Cin * 4 >= 0xFFFFFF00L || T * pl->ldm * 4 >= 0xFFFFFF00L || (long)pl->Cout * pl->Cin * 4 >= 0xFFFFFF00L) return false;
     pl->u_bytes = align256((size_t)16 * pl->Cout * pl->Cin * sizeof(float));
-    pl->v_bytes = align256((size_t)16 * T * pl->Cin * sizeof(float));
+    pl->v_bytes = align256((size_t)16 * pl->Tpad * pl->Cin * sizeof(float));
     pl->m_bytes = align256((size_t)16 * T * pl->ldm * sizeof(float));
     return true;
 }
 
 int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, int flip, const float* bias, float* dst, int ldd,
-             int accumulate, void* workspace, size_t workspace_bytes, hipStream_t st) {
+             int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.u_bytes + pl.v_bytes + pl.m_bytes) return SEGMI_ERR_WORKSPACE;
+    if (v_keep && ((uintptr_t)v_keep & 15)) return SEGMI_ERR_ALIGN;
     float* U = (float*)workspace;
-    float* V = (float*)((char*)workspace + pl.u_bytes);
+    float* V = v_keep ? v_keep : (float*)((char*)workspace + pl.u_bytes);      // caller keeps the transformed input for the filter gradient
     float* Mm = (float*)((char*)workspace + pl.u_bytes + pl.v_bytes);
     const long T = pl.g.T;
     {
@@ -291,13 +293,13 @@ int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, i
         hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)nb), dim3(256), 0, st, filt, pl.Cout, pl.Cin, flip, U);
     }
     {
-        RowGeom rg = row_geom(T, pl.Cin, 1, SEGMI_MAX_GRID * 4);
-        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, src, lds, pl.Cin, pl.g, T, V);
+        RowGeom rg = row_geom(pl.Tpad, pl.Cin, 1, SEGMI_MAX_GRID * 4);
+        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, src, lds, pl.Cin, pl.g, pl.Tpad, V);
     }
     int rc;
     {
         TraceScope tr(st);
-        rc = segmi_internal_gemm_batched(V, pl.Cin, U, Mm, pl.ldm, (int)T, pl.Cin, pl.Cout, 16, T * pl.Cin, (long)pl.Cout * pl.Cin, T * pl.ldm, st);
+        rc = segmi_internal_gemm_batched(V, pl.Cin, U, Mm, pl.ldm, (int)T, pl.Cin, pl.Cout, 16, pl.Tpad * pl.Cin, (long)pl.Cout * pl.Cin, T * pl.ldm, st);
     }
     if (rc != SEGMI_OK) return rc;
     {
@@ -324,14 +326,19 @@ size_t segmi_conv2d_winograd_workspace(const segmi_conv_desc* d, int op) {
     return pl.u_bytes + pl.v_bytes + pl.m_bytes;
 }
 
+size_t segmi_conv2d_winograd_v_bytes(const segmi_conv_desc* d) {
+    WinoPlan pl;
+    return wino_plan(d, 0, &pl) ? (size_t)16 * pl.Tpad * pl.Cin * sizeof(float) : 0;
+}
+
 int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
-                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+                              int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     WinoPlan pl;
     if (!x || !w_krsc || !y || !wino_plan(d, 0, &pl)) return SEGMI_ERR_BADARG;
     if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.ldm || ((uintptr_t)x & 15) || ((uintptr_t)w_krsc & 15) ||
         ((uintptr_t)y & 15))
         return SEGMI_ERR_ALIGN;
-    return wino_run(pl, x, d->ldx, w_krsc, 0, bias, y, d->ldy, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+    return wino_run(pl, x, d->ldx, w_krsc, 0, bias, y, d->ldy, accumulate, v_keep, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
@@ -341,7 +348,7 @@ int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const
     if ((d->ldy & 3) || d->ldy < pl.Cin || (d->ldx & 3) || d->ldx < pl.ldm || ((uintptr_t)dy & 15) || ((uintptr_t)w_crsk & 15) ||
         ((uintptr_t)dx & 15))
         return SEGMI_ERR_ALIGN;
-    return wino_run(pl, dy, d->ldy, w_crsk, 1, nullptr, dx, d->ldx, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+    return wino_run(pl, dy, d->ldy, w_crsk, 1, nullptr, dx, d->ldx, accumulate, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- filter gradient: dg = G^T [ sum_tiles (A dy A^T) (.) (B^T d B) ] G; the 16 contractions over the tiles are 1x1 filter
@@ -375,22 +382,22 @@ size_t segmi_conv2d_winograd_wgrad_workspace(const segmi_conv_desc* d) {
     return pl.v_bytes + pl.w_bytes + pl.s_bytes;
 }
 
-int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_krsc, void* workspace,
-                                size_t workspace_bytes, segmi_stream_t stream) {
+int segmi_conv2d_winograd_wgrad(const segmi_conv_desc* d, const float* x, const float* v_kept, const float* dy, float* dw_krsc,
+                                void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     WinoWgradPlan pl;
-    if (!x || !dy || !dw_krsc || !wino_wgrad_plan(d, &pl)) return SEGMI_ERR_BADARG;
-    if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.Kp || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
-        ((uintptr_t)dw_krsc & 15))
+    if ((!x && !v_kept) || !dy || !dw_krsc || !wino_wgrad_plan(d, &pl)) return SEGMI_ERR_BADARG;
+    if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.Kp || ((uintptr_t)x & 15) || ((uintptr_t)v_kept & 15) ||
+        ((uintptr_t)dy & 15) || ((uintptr_t)dw_krsc & 15))
         return SEGMI_ERR_ALIGN;
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.v_bytes + pl.w_bytes + pl.s_bytes)
         return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* V = (float*)workspace;
+    const float* V = v_kept ? v_kept : (const float*)workspace;    // the forward pass's transformed input (segmi_conv2d_winograd_fwd v_keep)
     float* Wt = (float*)((char*)workspace + pl.v_bytes);
     float* sk = (float*)((char*)workspace + pl.v_bytes + pl.w_bytes);
-    {
+    if (!v_kept) {
         RowGeom rg = row_geom(pl.Tpad, pl.C, 1, SEGMI_MAX_GRID * 4);
-        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, x, d->ldx, pl.C, pl.g, pl.Tpad, V);
+        hipLaunchKernelGGL(wino_input_kernel, rg.grid, rg.block, 0, st, x, d->ldx, pl.C, pl.g, pl.Tpad, (float*)workspace);
     }
     {
         RowGeom rg = row_geom(pl.Tpad, pl.Kp, 1, SEGMI_MAX_GRID * 4);

@@ -45,12 +45,13 @@ SIGNATURES = {
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "segmi_conv2d_winograd_ok": (i32, [PD, i32]),
     "segmi_conv2d_winograd_workspace": (sz, [PD, i32]),
-    "segmi_conv2d_winograd_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "segmi_conv2d_winograd_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_conv2d_winograd_v_bytes": (sz, [PD]),
     "segmi_conv2d_winograd_dgrad": (i32, [PD, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_conv2d_winograd_variant": (i32, [PD, i32, C.c_char_p, sz]),
     "segmi_conv2d_winograd_wgrad_ok": (i32, [PD]),
     "segmi_conv2d_winograd_wgrad_workspace": (sz, [PD]),
-    "segmi_conv2d_winograd_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
+    "segmi_conv2d_winograd_wgrad": (i32, [PD, vp, vp, vp, vp, vp, sz, vp]),
     "segmi_conv2d_winograd_wgrad_variant": (i32, [PD, C.c_char_p, sz]),
     "segmi_conv2d_winograd_tiles": (i64, [PD]),
     "segmi_conv2d_winograd_trace": (i32, [vp, vp]),

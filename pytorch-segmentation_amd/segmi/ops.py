@@ -274,15 +274,20 @@ def _presplit(w, n, dev):
 _WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "1") == "1",
              "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "256")),
              "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")),
-             "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "1") == "1", "calls": 0}
+             "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "1") == "1", "calls": 0,
+             # keep the forward pass's transformed input V (4x the layer input) for the filter gradient instead of transforming x
+             # again in backward: 3.2 GB at the bench shape, one HBM pass of 5x|x| less per eligible layer
+             "keep_v": os.environ.get("SEGMI_CONV_WINOGRAD_KEEP_V", "1") == "1"}
 
 
-def set_conv_winograd(on, min_channels=None, min_subgrid=None, wgrad=None):
+def set_conv_winograd(on, min_channels=None, min_subgrid=None, wgrad=None, keep_v=None):
     """Route eligible 3x3 stride-1 convolutions (forward and data gradient; with wgrad=True also the filter gradient) through
-    the Winograd F(2x2,3x3) kernels."""
+    the Winograd F(2x2,3x3) kernels.  keep_v: keep the forward pass's transformed input for the filter gradient."""
     _WINOGRAD["on"] = bool(on)
     if wgrad is not None:
         _WINOGRAD["wgrad"] = bool(wgrad)
+    if keep_v is not None:
+        _WINOGRAD["keep_v"] = bool(keep_v)
     if min_channels is not None:
         _WINOGRAD["min_channels"] = int(min_channels)
     if min_subgrid is not None:
@@ -319,18 +324,24 @@ def _winograd_wgrad_variant(d):
     return buf.value.decode()
 
 
-def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
+def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False):
     """segmi_conv2d_fwd (or its pre-split-filter / Winograd form when that applies) with its workspace and roofline span.
-    w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats."""
+    w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats.  keep_v: the caller will need this layer's filter gradient —
+    returns the Winograd-transformed input V (a tensor to keep for `_conv_wgrad(v=...)`) when the layer runs on the Winograd
+    kernels with a Winograd filter gradient, else None."""
     dev, st = x.device, _stream()
     if _winograd(d, 0):
         _WINOGRAD["calls"] += 1
         nws = lib.segmi_conv2d_winograd_workspace(d, 0)
         ws = workspace(nws, dev)
+        v = None
+        if keep_v and _WINOGRAD["keep_v"] and _WINOGRAD["wgrad"] and lib.segmi_conv2d_winograd_wgrad_ok(d) == 1:
+            v = torch.empty(lib.segmi_conv2d_winograd_v_bytes(d) // 4, device=dev, dtype=torch.float32)
         with span(lambda: _winograd_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
             check(lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                y.data_ptr(), accumulate, ws.data_ptr(), nws, st), "conv2d_winograd_fwd")
-        return
+                                                y.data_ptr(), accumulate, v.data_ptr() if v is not None else None, ws.data_ptr(), nws, st),
+                  "conv2d_winograd_fwd")
+        return v
     nws = lib.segmi_conv2d_fwd_workspace(d) if (bias is None and not accumulate) else 0
     ws = workspace(nws, dev) if nws else None
     wsp = ws.data_ptr() if ws is not None else None
@@ -343,15 +354,17 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0):
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
 
 
-def _conv_wgrad(d, C, x, dy, dwb):
-    """segmi_conv2d_wgrad (or its Winograd form when that applies) into the flat KRSC buffer dwb, with workspace and span."""
+def _conv_wgrad(d, C, x, dy, dwb, v=None):
+    """segmi_conv2d_wgrad (or its Winograd form when that applies) into the flat KRSC buffer dwb, with workspace and span.
+    v: the transformed input the forward pass kept (`_conv_fwd(keep_v=True)`), or None."""
     dev, st = x.device, _stream()
-    if _WINOGRAD["wgrad"] and _winograd(d, 0) and lib.segmi_conv2d_winograd_wgrad_ok(d) == 1:
+    if v is not None or (_WINOGRAD["wgrad"] and _winograd(d, 0) and lib.segmi_conv2d_winograd_wgrad_ok(d) == 1):
         _WINOGRAD["calls"] += 1
         nws = lib.segmi_conv2d_winograd_wgrad_workspace(d)
         ws = workspace(nws, dev)
         with span(lambda: _winograd_wgrad_variant(d), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
-            check(lib.segmi_conv2d_winograd_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr(), nws, st), "conv2d_winograd_wgrad")
+            check(lib.segmi_conv2d_winograd_wgrad(d, x.data_ptr(), v.data_ptr() if v is not None else None, dy.data_ptr(), dwb.data_ptr(),
+                                                  ws.data_ptr(), nws, st), "conv2d_winograd_wgrad")
         return
     nws = lib.segmi_conv2d_wgrad_workspace(d)
     ws = workspace(nws, dev) if nws else None
@@ -360,7 +373,7 @@ def _conv_wgrad(d, C, x, dy, dwb):
               "conv2d_wgrad")
 
 
-# Filter gradients on a side HIP stream (SEGMI_WGRAD_STREAM=1 / set_wgrad_stream): nothing in the backward pass consumes dW —
+# Filter gradients on a side HIP stream (default on; SEGMI_WGRAD_STREAM=0 / set_wgrad_stream(False) keeps them in order): nothing in the backward pass consumes dW —
 # only the optimizer (or the gradient all-reduce) does — so the wgrad launch of a layer may run concurrently with the data-gradient
 # chain of the layers below it.  The wgrad kernels leave most of a CU's register file and 32 KB of LDS free (116 VGPRs x 2 waves per
 # SIMD), so the HBM-bound BN-backward / transform kernels of the main stream co-reside with them instead of queueing behind them.
@@ -368,7 +381,7 @@ def _conv_wgrad(d, C, x, dy, dwb):
 # caching allocator does not recycle them early, the main stream re-joins at the END of the backward pass (autograd engine
 # callback), and the path is only taken when the parameter has no gradient yet (AccumulateGrad then adopts the tensor without
 # launching anything; an accumulating or bucket-view gradient keeps the in-order path).
-_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "0") == "1", "streams": {}, "armed": False, "launches": 0}
+_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": False, "launches": 0}
 
 
 def set_wgrad_stream(on):
@@ -393,20 +406,22 @@ def wgrad_stream_join():
             torch.cuda.current_stream(side.device).wait_stream(side)
 
 
-def _conv_wgrad_param(weight, d, C, x, dy, dwb):
-    """_conv_wgrad for a parameter's filter gradient: on the side stream when enabled and safe, in order otherwise."""
+def _on_wgrad_stream(weight, tensors, fn):
+    """Run fn() — launches that only produce (part of) `weight`'s gradient from `tensors` — on the filter-gradient side stream
+    when that is enabled and safe (see _WGRAD_SIDE), in order on the current stream otherwise."""
     if not (_WGRAD_SIDE["on"] and weight.grad is None and weight.is_leaf and torch.is_grad_enabled() is False):
-        return _conv_wgrad(d, C, x, dy, dwb)
-    dev = x.device
+        return fn()
+    dev = weight.device
     side = _WGRAD_SIDE["streams"].get(dev.index)
     if side is None:
         side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        _conv_wgrad(d, C, x, dy, dwb)
-    for t in (x, dy, dwb):
-        t.record_stream(side)
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
     _WGRAD_SIDE["launches"] += 1
     if not _WGRAD_SIDE["armed"]:
         try:
@@ -414,6 +429,11 @@ def _conv_wgrad_param(weight, d, C, x, dy, dwb):
             _WGRAD_SIDE["armed"] = True
         except RuntimeError:               # not inside an engine-driven backward pass: join right away
             _join_wgrad_stream()
+
+
+def _conv_wgrad_param(weight, d, C, x, dy, dwb, v=None):
+    """_conv_wgrad for a parameter's filter gradient: on the side stream when enabled and safe, in order otherwise."""
+    _on_wgrad_stream(weight, (x, dy, dwb, v), lambda: _conv_wgrad(d, C, x, dy, dwb, v))
 
 
 def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
@@ -525,17 +545,17 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, K, P, Q, x.device)
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
-        _conv_fwd(d, C, x, w, bias, y)
+        v = _conv_fwd(d, C, x, w, bias, y, keep_v=ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             _filter_transposes.note(weight, w, K, R, S, Ce, pad4(K))
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, v)
         ctx.geom = (N, C, H, W, K, R, S, P, Q, stride, pad, dil)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, v = ctx.saved_tensors
         N, C, H, W, K, R, S, P, Q, stride, pad, dil = ctx.geom
         dy = to_nhwc(dy, "conv2d.backward")
         Ce = pad4(C)
@@ -552,9 +572,9 @@ class _Conv2dFn(torch.autograd.Function):
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
             if dw_owned is not None:
-                _conv_wgrad_param(weight, d, C, x, dy, dwb)
+                _conv_wgrad_param(weight, d, C, x, dy, dwb, v)
             else:
-                _conv_wgrad(d, C, x, dy, dwb)
+                _conv_wgrad(d, C, x, dy, dwb, v)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             rows = N * P * Q
@@ -590,7 +610,7 @@ class _Conv2dSkipFn(torch.autograd.Function):
             if dskip is not None and dx is not None:
                 dx = add(dx, dskip)
             return (dx if dx is not None else dskip), dw, None, None, None
-        x, weight = ctx.saved_tensors
+        x, weight, v = ctx.saved_tensors
         N, C, H, W, K, R, S, P, Q, stride, pad, dil = ctx.geom
         dy = to_nhwc(dy, "conv2d.backward")
         dskip = to_nhwc(dskip, "conv2d.backward")
@@ -604,9 +624,9 @@ class _Conv2dSkipFn(torch.autograd.Function):
             d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
             dwb, dw_owned = _filter_grad_buffer(weight, Ce)
             if dw_owned is not None:
-                _conv_wgrad_param(weight, d, C, x, dy, dwb)
+                _conv_wgrad_param(weight, d, C, x, dy, dwb, v)
             else:
-                _conv_wgrad(d, C, x, dy, dwb)
+                _conv_wgrad(d, C, x, dy, dwb, v)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
         return dskip, dw, None, None, None
 
@@ -1224,14 +1244,16 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         tp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in Ts])
         check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, bh, bw, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(y))
-        _conv_fwd(d, Cx, x, fx, None, y, accumulate=1)                                                # accumulate onto the pyramid part
-        ctx.save_for_backward(x, weight, *ps)
+        v = _conv_fwd(d, Cx, x, fx, None, y, accumulate=1, keep_v=ctx.needs_input_grad[1])             # accumulate onto the pyramid part
+        ctx.has_v = v is not None
+        ctx.save_for_backward(x, weight, *ps, *([v] if v is not None else []))
         ctx.geom = (N, Cx, H, W, K, Ct, tuple(cs), tuple(bins))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, *ps = ctx.saved_tensors
+        v = ps.pop() if ctx.has_v else None
         N, Cx, H, W, K, Ct, cs, bins = ctx.geom
         dy = to_nhwc(dy, "pyramid_bottleneck.backward")
         dev, st = x.device, _stream()
@@ -1250,8 +1272,11 @@ class _PyramidBottleneckFn(torch.autograd.Function):
             _conv_dgrad(d, Cx, dy, wt, dx)
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(dy))
         dfx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
-        _conv_wgrad(d, Cx, x, dy, dfx)
-        check(lib.segmi_filter_unslice(dfx.data_ptr(), K, 9, Ct, 0, Cx, 0, dwb.data_ptr(), st), "filter_unslice")
+
+        def feature_wgrad():               # the largest filter gradient of the model: eligible for the side stream like any conv's
+            _conv_wgrad(d, Cx, x, dy, dfx, v)
+            check(lib.segmi_filter_unslice(dfx.data_ptr(), K, 9, Ct, 0, Cx, 0, dwb.data_ptr(), _stream()), "filter_unslice")
+        _on_wgrad_stream(weight, (x, dy, dfx, dwb, v), feature_wgrad)
         # ---- pyramid branches: G_l = dT_l by the transposed interpolation, then the 1x1 convolution's dgrad / wgrad
         Gs = [torch.empty((N, b, b2, 9 * K), device=dev, dtype=torch.float32) for b, b2 in bins]
         nws = lib.segmi_pyramid_up_workspace(N, H, W, K, nl, bh, bw)

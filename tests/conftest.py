@@ -69,4 +69,4 @@ def conv_algorithm(request):
     try:
         yield mode
     finally:
-        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"])
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"], prev["keep_v"])

@@ -133,12 +133,16 @@ def test_winograd_planning_and_dispatch_rules():
     assert lib.segmi_conv2d_winograd_variant(d, 0, buf, 128) == 0 and buf.value.decode().startswith("winograd_f2x2_3x3 fwd: 16 x conv_dma_kernel<")
     # odd maps: 97x97 with dilation 2 -> sub-grids of 49 / 48 rows, 25 tile rows each
     d97 = desc(4, 97, 256, 256, 3, 1, 2, 2)
-    assert lib.segmi_conv2d_winograd_workspace(d97, 0) == al(16 * 256 * 256 * 4) + 2 * al(16 * (4 * 4 * 25 * 25) * 256 * 4)
+    # the transformed input holds whole 32-row chunks of tiles (zero rows past T) so that the filter gradient can contract a kept V
+    T97a, T97p = 4 * 4 * 25 * 25, (4 * 4 * 25 * 25 + 31) & ~31
+    assert lib.segmi_conv2d_winograd_workspace(d97, 0) == al(16 * 256 * 256 * 4) + al(16 * T97p * 256 * 4) + al(16 * T97a * 256 * 4)
+    assert lib.segmi_conv2d_winograd_v_bytes(d97) == 16 * T97p * 256 * 4 and lib.segmi_conv2d_winograd_v_bytes(d) == 16 * T * 512 * 4
     # K = 21 classes: the product planes are padded to 24 columns; the data gradient contracts over the padded K
     d21 = desc(2, 33, 64, 21, 3, 1, 1, 1)
     T21 = 2 * 17 * 17
-    assert lib.segmi_conv2d_winograd_workspace(d21, 0) == al(16 * 21 * 64 * 4) + al(16 * T21 * 64 * 4) + al(16 * T21 * 24 * 4)
-    assert lib.segmi_conv2d_winograd_workspace(d21, 1) == al(16 * 64 * 24 * 4) + al(16 * T21 * 24 * 4) + al(16 * T21 * 64 * 4)
+    T21p = (T21 + 31) & ~31
+    assert lib.segmi_conv2d_winograd_workspace(d21, 0) == al(16 * 21 * 64 * 4) + al(16 * T21p * 64 * 4) + al(16 * T21 * 24 * 4)
+    assert lib.segmi_conv2d_winograd_workspace(d21, 1) == al(16 * 64 * 24 * 4) + al(16 * T21p * 24 * 4) + al(16 * T21 * 64 * 4)
     # not Winograd problems: 1x1, stride 2, padding != dilation, channels not padded to 4, unknown pass
     for bad in (desc(8, 64, 512, 512, 1, 1, 0, 1), desc(8, 64, 512, 512, 3, 2, 1, 1), desc(8, 64, 512, 512, 3, 1, 0, 1),
                 desc(8, 64, 510, 512, 3, 1, 1, 1)):

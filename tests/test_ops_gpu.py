@@ -92,7 +92,8 @@ WINOGRAD_CASES = [
 @pytest.mark.parametrize("case", WINOGRAD_CASES)
 def test_conv2d_winograd_matches_reference(cuda, case):
     """Winograd F(2x2,3x3) forward and data gradient (csrc/conv_winograd.hip) against F.conv2d on the CPU, at the SAME tolerance
-    as the direct kernels (1e-4 of max|ref|); the filter gradient stays on the direct kernel."""
+    as the direct kernels (1e-4 of max|ref|), all three passes; the filter gradient both from the transformed input the forward
+    pass kept and from a fresh transform of x (bit-identical)."""
     from segmi import ops
     N, C, H, W, K, dil, bias = case
     g = torch.Generator().manual_seed(4321)
@@ -104,19 +105,24 @@ def test_conv2d_winograd_matches_reference(cuda, case):
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
     prev = ops.get_conv_winograd()
-    ops.set_conv_winograd(True, min_channels=0, min_subgrid=1, wgrad=True)
+    got = {}
     try:
-        calls = ops.get_conv_winograd()["calls"]
-        xd = x.to(cuda).requires_grad_(True)
-        wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-        yd = ops.conv2d(xd, wd, b.to(cuda) if bias else None, 1, dil, dil)
-        _close_rel_max(yd, yr, 1e-4, "winograd fwd %s" % (case,))
-        yd.backward(gy.to(cuda))
-        _close_rel_max(xd.grad, xr.grad, 1e-4, "winograd dgrad %s" % (case,))
-        _close_rel_max(wd.grad, wr.grad, 1e-4, "winograd wgrad %s" % (case,))
-        assert ops.get_conv_winograd()["calls"] == calls + 3, "the Winograd kernels did not run"
+        for keep_v in (True, False):      # filter gradient from the forward pass's kept transformed input / from x again
+            ops.set_conv_winograd(True, min_channels=0, min_subgrid=1, wgrad=True, keep_v=keep_v)
+            calls = ops.get_conv_winograd()["calls"]
+            xd = x.to(cuda).requires_grad_(True)
+            wd = w.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            yd = ops.conv2d(xd, wd, b.to(cuda) if bias else None, 1, dil, dil)
+            _close_rel_max(yd, yr, 1e-4, "winograd fwd %s" % (case,))
+            yd.backward(gy.to(cuda))
+            _close_rel_max(xd.grad, xr.grad, 1e-4, "winograd dgrad %s" % (case,))
+            _close_rel_max(wd.grad, wr.grad, 1e-4, "winograd wgrad %s" % (case,))
+            assert ops.get_conv_winograd()["calls"] == calls + 3, "the Winograd kernels did not run"
+            got[keep_v] = (yd.detach().clone(), xd.grad.clone(), wd.grad.clone())
+        for a, b2 in zip(got[True], got[False]):
+            assert torch.equal(a, b2), "kept V and recomputed V must give bit-identical results"
     finally:
-        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"])
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"], prev["keep_v"])
 
 
 def test_pspnet_step_under_winograd_matches_direct(cuda):

@@ -15,6 +15,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from segmi import ops  # noqa: E402
 from segmi.profile import KernelTimer  # noqa: E402
+ops.set_wgrad_stream(False)       # per-launch durations: every launch in order on ONE stream
 import utils.losses as losses_mod  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"

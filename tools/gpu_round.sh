@@ -136,5 +136,29 @@ r3b)
   ( timeout 1500 python -m pytest tests -m gpu -q -rf -s 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert" | tail -70 ) > gpurun_out/r3b_pytest_gpu.log
   cat gpurun_out/r3b_pytest_gpu.log
   ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3b_smoke.log; cat gpurun_out/r3b_smoke.log ;;
+pkrepro)
+  # two-kernel reproducer of the round-2 packed-fp32 observation: victim (packed / asm / scalar) alone, next to an fp32-MFMA process,
+  # next to a bf16-MFMA process (separate PROCESSES sharing the GPU), then the product-level stress at HEAD under bf16x3
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/pk_mfma_repro tools/probes/pk_mfma_repro.hip 2>/dev/null
+  ( for v in pk asm scalar; do
+      echo "== victim $v alone"; /tmp/pk_mfma_repro victim 6 $v
+      echo "== victim $v next to an fp32-MFMA process"; /tmp/pk_mfma_repro aggressor 9 f32 & sleep 1; /tmp/pk_mfma_repro victim 6 $v; wait
+      echo "== victim $v next to a bf16-MFMA process"; /tmp/pk_mfma_repro aggressor 9 bf16 & sleep 1; /tmp/pk_mfma_repro victim 6 $v; wait
+    done ) > gpurun_out/pkrepro.txt 2>&1
+  cat gpurun_out/pkrepro.txt
+  ( SEGMI_CONV_MATH=bf16x3 timeout 300 python tools/stress_determinism.py --procs 2 --iters 150 2>&1 | grep -v amdgpu.ids | tail -12 ) > gpurun_out/stress_bf16x3.txt
+  cat gpurun_out/stress_bf16x3.txt ;;
+r3c)
+  # round 3, call 3: kept Winograd V + side-stream filter gradients (default), grouped SyncBN, DDP bucket slots; bf16x3 status
+  ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_pspnet_gpu.py tests/test_distributed_gpu.py tests/test_graph_gpu.py -m gpu -q -rf -x 2>&1 | tail -30 ) > gpurun_out/r3c_quick_tests.log
+  tail -6 gpurun_out/r3c_quick_tests.log
+  ( timeout 400 python bench.py --no-cpu 2>&1 | tail -1 ) > gpurun_out/r3c_bench.log
+  ( SEGMI_CONV_WINOGRAD_KEEP_V=0 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3c_bench_nokeep.log
+  ( SEGMI_WGRAD_STREAM=0 timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r3c_bench_inorder.log
+  for f in bench bench_nokeep bench_inorder; do python -c "import json,sys; d=json.loads(open('gpurun_out/r3c_$f.log').read()); r=d['roofline']; print('$f', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['frac'], r['executed_step_frac'], r['all_conv']['ms_per_step'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1; done
+  ( timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu --no-roofline 2>&1 | tail -2 ) > gpurun_out/r3c_spawn2.log; cat gpurun_out/r3c_spawn2.log
+  bash tools/gpu_round.sh pkrepro
+  ( SEGMI_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_unet_gpu.py tests/test_conv_bf16x3_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad" | tail -40 ) > gpurun_out/r3c_pytest_gpu_bf16x3_subset.log
+  cat gpurun_out/r3c_pytest_gpu_bf16x3_subset.log ;;
 esac
 done

@@ -15,7 +15,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+from segmi import ops as _ops  # noqa: E402
 from segmi.profile import KernelTimer  # noqa: E402
+_ops.set_wgrad_stream(False)      # per-launch durations: every launch in order on ONE stream
 import utils.losses as losses_mod  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
