@@ -148,6 +148,8 @@ pkrepro)
   cat gpurun_out/pkrepro.txt
   ( SEGMI_CONV_MATH=bf16x3 timeout 300 python tools/stress_determinism.py --procs 2 --iters 150 2>&1 | grep -v amdgpu.ids | tail -12 ) > gpurun_out/stress_bf16x3.txt
   cat gpurun_out/stress_bf16x3.txt ;;
+pk2)
+  ( timeout 400 python tools/probes/pk_two_process.py --seconds 10 2>&1 | grep -v amdgpu.ids ) > gpurun_out/pk_two_process.txt; cat gpurun_out/pk_two_process.txt ;;
 r3c)
   # round 3, call 3: kept Winograd V + side-stream filter gradients (default), grouped SyncBN, DDP bucket slots; bf16x3 status
   ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_pspnet_gpu.py tests/test_distributed_gpu.py tests/test_graph_gpu.py -m gpu -q -rf -x 2>&1 | tail -30 ) > gpurun_out/r3c_quick_tests.log
