@@ -162,5 +162,27 @@ r3c)
   bash tools/gpu_round.sh pkrepro
   ( SEGMI_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_unet_gpu.py tests/test_conv_bf16x3_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad" | tail -40 ) > gpurun_out/r3c_pytest_gpu_bf16x3_subset.log
   cat gpurun_out/r3c_pytest_gpu_bf16x3_subset.log ;;
+r3final)
+  # round 3, evidence run of the final tree: whole suite, smoke, full bench line, rocprof stats, PMC traffic, tables, other configs
+  ( timeout 1500 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad" | tail -70 ) > gpurun_out/r3f_pytest_gpu.log
+  tail -4 gpurun_out/r3f_pytest_gpu.log
+  ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3f_smoke.log; tail -2 gpurun_out/r3f_smoke.log | cut -c1-200
+  ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/r3f_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r3f_bench.log').read()); r=d['roofline']; print('bench', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['executed_step_frac'], d['cpu_baseline'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1
+  rm -rf gpurun_out/prof
+  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r3f_kernel_stats_f32.csv
+  rm -rf gpurun_out/pmc_f32
+  ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f32/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/pmc_f32.log
+  ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_f32/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) >> gpurun_out/pmc_f32.log
+  for d in fetch write; do f=$(find gpurun_out/pmc_f32/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_f32/$d/r_counter_collection.csv 2>/dev/null; done
+  python tools/traffic_json.py gpurun_out/pmc_f32 gpurun_out/r3f_cfg2_conv_traffic_f32.json
+  find gpurun_out/pmc_f32 -name "*kernel_trace*" -delete; find gpurun_out/pmc_f32 -name "*.csv" -size +8M -delete
+  ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r3f_conv_layers.txt; tail -1 gpurun_out/r3f_conv_layers.txt
+  ( timeout 300 python tools/membound_ops.py cfg2 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r3f_membound_ops.txt; tail -3 gpurun_out/r3f_membound_ops.txt
+  ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -20 ) > gpurun_out/r3f_stray_aten.txt
+  for c in cfg1 cfg3 cfg4 cfg5; do ( timeout 400 python bench.py --config $c --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3f_bench_$c.log; python -c "import json; d=json.loads(open('gpurun_out/r3f_bench_$c.log').read()); print('$c', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done
+  bash tools/gpu_round.sh pk2 ;;
 esac
 done
