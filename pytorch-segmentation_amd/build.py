@@ -21,8 +21,11 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
-# per-file additions (see DESIGN.md §4.1b "packed-fp32 results next to another process's bf16 MFMA kernels")
-EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("pool_resize.hip", "conv_winograd.hip", "bn.hip", "loss.hip", "misc.hip", "optim.hip",
+# per-file additions: no compiler-formed packed-fp32 arithmetic (v_pk_mul/fma/add_f32) in the HBM-bound kernels.  The SLP-packed
+# form of bilinear_fwd_kernel returns wrong high halves while a bf16x3 convolution kernel of ANOTHER process shares the GPU
+# (tools/probes/pk_two_process.py reproduces it with exactly these two kernels; profiles/r03_pk_two_process.txt);
+# the scalar form never does.  These kernels are HBM-bound: no cost.
+EXTRA_FLAGS = {f: ["-fno-slp-vectorize", "-fno-vectorize"] for f in ("pool_resize.hip", "conv_winograd.hip", "bn.hip", "loss.hip", "misc.hip", "optim.hip",
                                                     "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip")}
 # (augment.hip is off the timed path and held to oracle/augment_ref.py at "one uint8 level": it keeps the default flags it was pinned with)
 

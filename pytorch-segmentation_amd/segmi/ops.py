@@ -381,7 +381,7 @@ def _conv_wgrad(d, C, x, dy, dwb, v=None):
 # caching allocator does not recycle them early, the main stream re-joins at the END of the backward pass (autograd engine
 # callback), and the path is only taken when the parameter has no gradient yet (AccumulateGrad then adopts the tensor without
 # launching anything; an accumulating or bucket-view gradient keeps the in-order path).
-_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": False, "launches": 0}
+_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": None, "launches": 0}
 
 
 def set_wgrad_stream(on):
@@ -393,7 +393,7 @@ def get_wgrad_stream():
 
 
 def _join_wgrad_stream():
-    _WGRAD_SIDE["armed"] = False
+    _WGRAD_SIDE["armed"] = None
     for side in _WGRAD_SIDE["streams"].values():
         torch.cuda.current_stream(side.device).wait_stream(side)
 
@@ -423,12 +423,14 @@ def _on_wgrad_stream(weight, tensors, fn):
         if t is not None:
             t.record_stream(side)
     _WGRAD_SIDE["launches"] += 1
-    if not _WGRAD_SIDE["armed"]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_stream)
-            _WGRAD_SIDE["armed"] = True
-        except RuntimeError:               # not inside an engine-driven backward pass: join right away
-            _join_wgrad_stream()
+    # one join per backward pass, keyed by the engine's graph-task id (a pass that died with an exception never ran its
+    # callback: the next pass has a new id and arms again)
+    task = torch._C._current_graph_task_id()
+    if task < 0:                           # not inside an engine-driven backward pass: join right away
+        _join_wgrad_stream()
+    elif _WGRAD_SIDE["armed"] != task:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_stream)
+        _WGRAD_SIDE["armed"] = task
 
 
 def _conv_wgrad_param(weight, d, C, x, dy, dwb, v=None):

@@ -115,55 +115,82 @@ def test_bf16x3_training_step_matches_f32_path(cuda):
     assert ((g1 - g3).norm() / g1.norm()).item() <= 1e-3
 
 
-def test_bf16x3_network_level_accuracy_over_seeds(cuda):
-    """The statistical form of the parity argument: over several weight / input seeds, a PSPNet-R50 training step
-    (BN batch statistics, 2x3x96x96) under bf16x3 is as close to the fp64 oracle as under the fp32 MFMA chain — logits and
-    parameter gradients.  Single seeds differ either way (one ReLU flip moves a gradient tensor by ~1e-3: chaos, not arithmetic);
-    the logit means over seeds must agree within 1.5x, and both paths must stay within 3x of the torch-CPU fp32 oracle's own
-    distance from fp64 for logits AND gradients (per-seed numbers are printed)."""
+_FAMILIES = {
+    # name: (arch, kwargs, classes, input shape, seeds)
+    "pspnet_r50": ("PSPNet", dict(backbone="resnet50"), 7, (2, 3, 96, 96), 5),
+    "deeplab_r50": ("DeepLab", dict(backbone="resnet50", output_stride=16), 6, (2, 3, 97, 97), 5),
+    "deeplab_xception": ("DeepLab", dict(backbone="xception", output_stride=16), 9, (2, 3, 96, 96), 5),
+    "unet": ("UNet", dict(), 3, (2, 3, 64, 64), 5),
+}
+
+
+@pytest.mark.parametrize("family", sorted(_FAMILIES))
+def test_network_level_accuracy_over_seeds(cuda, family):
+    """The statistical form of the parity argument, for BOTH convolution arithmetics and all four model families:
+    over five weight / input seeds, one training step (BN batch statistics) on the HIP path is as close to the fp64 oracle as the
+    torch-CPU fp32 oracle is — logits and parameter gradients.  Single seeds differ either way (one ReLU flip moves a gradient
+    tensor by ~1e-3: chaos, not arithmetic); asserted on the means over seeds: the bf16x3 logits within 1.5x of the fp32-MFMA
+    path's, and both paths within 3x of the CPU fp32 oracle's own distance from fp64 for logits AND gradients.  Per-seed numbers
+    are printed.  The convolution algorithm is the process default (Winograd F(2x2,3x3) for the eligible layers)."""
     import statistics
     import models
-    from oracle import losses_ref, pspnet_ref
+    from oracle import deeplab_ref, losses_ref, pspnet_ref, unet_ref
     from oracle.weights import synth_batch, synth_state_dict
     from segmi import ops
     from utils.losses import CrossEntropyLoss2d
-    classes, shape = 7, (2, 3, 96, 96)
-    tmpl = models.PSPNet(classes, backbone="resnet50", pretrained=False)
+    arch, kw, classes, shape, nseeds = _FAMILIES[family]
+    tmpl = getattr(models, arch)(classes, pretrained=False, **kw) if arch != "UNet" else models.UNet(classes)
     man = [(k, tuple(v.shape)) for k, v in tmpl.state_dict().items()]
+
+    def oracle_loss(ref, x, t):
+        if arch == "PSPNet":
+            ro, ra = pspnet_ref.pspnet_forward(ref, x, training=True, backbone=kw["backbone"])
+            return ro, losses_ref.cross_entropy(ro, t) + 0.4 * losses_ref.cross_entropy(ra, t)
+        if arch == "DeepLab":
+            ro = deeplab_ref.deeplab_forward(ref, x, kw["backbone"], kw["output_stride"], training=True)
+        else:
+            ro = unet_ref.unet_forward(ref, x, training=True)
+        return ro, losses_ref.cross_entropy(ro, t)
+
     prev = ops.get_conv_math()
     rows = {"f32": [], "bf16x3": [], "cpu32": []}
     try:
-        for seed in range(5):
+        for seed in range(nseeds):
             sd = synth_state_dict(man, seed=100 + seed)
             x, t = synth_batch(shape[0], 3, shape[2], shape[3], classes, seed=200 + seed)
             runs = {}
             for name, dt in (("cpu32", torch.float32), ("f64", torch.float64)):
                 ref = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()})
-                ro, ra = pspnet_ref.pspnet_forward(ref, x.to(dt), training=True)
-                (losses_ref.cross_entropy(ro, t) + 0.4 * losses_ref.cross_entropy(ra, t)).backward()
+                ro, loss = oracle_loss(ref, x.to(dt), t)
+                loss.backward()
                 runs[name] = (ro.detach().double(), {k: v.grad.double() for k, v in ref.items() if v.grad is not None})
             for math in ("f32", "bf16x3"):
                 ops.set_conv_math(math)
-                m = models.PSPNet(classes, backbone="resnet50", pretrained=False)
+                m = getattr(models, arch)(classes, pretrained=False, **kw) if arch != "UNet" else models.UNet(classes)
                 m.load_state_dict(sd)
                 m.to(cuda).train()
                 for mod in m.modules():
-                    if isinstance(mod, torch.nn.Dropout2d):
+                    if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout2d)):
                         mod.eval()
                 crit = CrossEntropyLoss2d(ignore_index=255)
-                out, aux = m(x.to(cuda))
-                (crit(out, t.to(cuda)) + 0.4 * crit(aux, t.to(cuda))).backward()
-                runs[math] = (out.detach().cpu().double(), {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()})
+                out = m(x.to(cuda))
+                if arch == "PSPNet":
+                    out, aux = out
+                    loss = crit(out, t.to(cuda)) + 0.4 * crit(aux, t.to(cuda))
+                else:
+                    loss = crit(out, t.to(cuda))
+                loss.backward()
+                runs[math] = (out.detach().cpu().double(), {k: p.grad.detach().cpu().double() for k, p in m.named_parameters() if p.grad is not None})
             o64, g64 = runs["f64"]
             for name in rows:
                 o, g = runs[name]
                 dl = (o - o64).abs().max().item() / o64.abs().max().item()
-                dg = statistics.median((g[k] - g64[k]).norm().item() / (g64[k].norm().item() + 1e-30) for k in g64)
+                dg = statistics.median((g[k] - g64[k]).norm().item() / (g64[k].norm().item() + 1e-30) for k in g64 if k in g)
                 rows[name].append((dl, dg))
     finally:
         ops.set_conv_math(prev)
     mean = {n: (statistics.mean(r[0] for r in v), statistics.mean(r[1] for r in v)) for n, v in rows.items()}
-    print("distance from the fp64 oracle over 5 seeds, mean (max|dlogit|/max|logit|, median per-tensor gradient rel-L2): "
+    print("%s: distance from the fp64 oracle over %d seeds, mean (max|dlogit|/max|logit|, median per-tensor gradient rel-L2): " % (family, nseeds)
           + " | ".join("%s %.2e %.2e" % (n, mean[n][0], mean[n][1]) for n in ("cpu32", "f32", "bf16x3")))
     for n in ("cpu32", "f32", "bf16x3"):
         print("   %-7s per seed: " % n + "  ".join("(%.1e, %.1e)" % r for r in rows[n]))

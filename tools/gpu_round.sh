@@ -184,5 +184,16 @@ r3final)
   ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -20 ) > gpurun_out/r3f_stray_aten.txt
   for c in cfg1 cfg3 cfg4 cfg5; do ( timeout 400 python bench.py --config $c --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3f_bench_$c.log; python -c "import json; d=json.loads(open('gpurun_out/r3f_bench_$c.log').read()); print('$c', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done
   bash tools/gpu_round.sh pk2 ;;
+r3g)
+  # round 3, call 5: in-order rocprof stats (agreement with bench.py's instrumented step), packed-fp32 cross experiment, new tests,
+  # whole suite under bf16x3 at HEAD
+  rm -rf gpurun_out/prof
+  ( SEGMI_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r3g_kernel_stats_f32_inorder.csv; head -4 gpurun_out/r3g_kernel_stats_f32_inorder.csv | cut -c1-200
+  ( timeout 400 python tools/probes/pk_two_process.py --cross --seconds 8 2>&1 | grep -v amdgpu.ids ) > gpurun_out/pk_two_process_cross.txt; cat gpurun_out/pk_two_process_cross.txt
+  ( timeout 900 python -m pytest tests/test_determinism_gpu.py tests/test_conv_bf16x3_gpu.py tests/test_ops_gpu.py tests/test_pspnet_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|distance from the fp64|Error|assert" | tail -30 ) > gpurun_out/r3g_new_tests.log; cat gpurun_out/r3g_new_tests.log
+  ( SEGMI_CONV_MATH=bf16x3 timeout 1500 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r3g_pytest_gpu_bf16x3.log
+  tail -12 gpurun_out/r3g_pytest_gpu_bf16x3.log | cut -c1-300 ;;
 esac
 done

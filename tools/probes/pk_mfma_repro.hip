@@ -2,7 +2,7 @@
 // (the HIGH half of v_pk_mul_f32 / v_pk_fma_f32 with op_sel) of one process's HBM-streaming kernel differed while ANOTHER process ran
 // v_mfma_f32_32x32x16_bf16 kernels on the same GPU.  This program isolates the two ingredients:
 //
-//   pk_mfma_repro victim  <seconds> [pk|asm|scalar]   streams y = a * s + b over 64 MB with (pk) compiler-formed packed math, (asm) a
+//   pk_mfma_repro victim  <seconds> [pk|asm|asm2|scalar]   streams y = a * s + b over 64 MB with (pk) compiler-formed packed math, (asm) a
 //                                                     hand-written v_pk_fma_f32 ... op_sel_hi:[1,0,1], or (scalar) plain v_fma_f32, and
 //                                                     checks every launch's output against a scalar recomputation on the device
 //   pk_mfma_repro aggressor <seconds> [bf16|f32]      keeps every CU busy with bf16 (or fp32) MFMA loops
@@ -41,6 +41,44 @@ __global__ __launch_bounds__(256) void victim_asm(const float4* __restrict__ a, 
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(dlo) : "v"(lo), "v"(ss), "v"(blo));
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(dhi) : "v"(hi), "v"(ss), "v"(bhi));
         y[i] = make_float4(dlo.x, dlo.y, dhi.x, dhi.y);
+    }
+}
+// the exact instruction forms of the SLP-built bilinear_fwd_kernel (profiles/r03_pk_two_process.txt): half-swapping v_pk_mov_b32,
+// v_pk_mul_f32 with op_sel:[1,0] op_sel_hi:[0,1] (src0 halves crossed), plain v_pk_fma_f32.  y.xy = (a.x, a.y) * (s, t) crossed:
+//   m = { a.y' ... } — the arithmetic below is checked against its own scalar restatement in check_asm2
+__global__ __launch_bounds__(256) void victim_asm2(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ y, float s, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float4 u = a[i], v = b[i];
+        f32x2 w = {s, 1.0f - s}, p0 = {u.x, u.y}, p1 = {u.z, u.w}, q0 = {v.x, v.y}, q1 = {v.z, v.w}, t0, t1, m0, m1, d0, d1;
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(t0) : "v"(p0), "v"(q0));      // t0 = {p0.y, q0.x}
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(t1) : "v"(p1), "v"(q1));      // t1 = {p1.y, q1.x}
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(m0) : "v"(w), "v"(t0));   // m0 = {w.y*t0.x, w.x*t0.y}
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(m1) : "v"(w), "v"(t1));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d0) : "v"(w), "v"(p0), "v"(m0));       // d0 = w * p0 + m0
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d1) : "v"(w), "v"(p1), "v"(m1));
+        y[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
+    }
+}
+__device__ __forceinline__ float mul_scalar(float a, float b) {
+    float d;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float fma_scalar(float a, float s, float b);
+__global__ __launch_bounds__(256) void check_asm2(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ y, float s, long n,
+                                                  unsigned long long* __restrict__ bad) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float4 u = a[i], v = b[i], g = y[i];
+        const float wx = s, wy = 1.0f - s;
+        const float e[4] = {fma_scalar(wx, u.x, mul_scalar(wy, u.y)), fma_scalar(wy, u.y, mul_scalar(wx, v.x)),
+                            fma_scalar(wx, u.z, mul_scalar(wy, u.w)), fma_scalar(wy, u.w, mul_scalar(wx, v.z))};
+        const float q[4] = {g.x, g.y, g.z, g.w};
+        for (int c = 0; c < 4; ++c)
+            if (__float_as_uint(e[c]) != __float_as_uint(q[c])) {
+                atomicAdd(&bad[0], 1ull);
+                atomicAdd(&bad[1 + c], 1ull);
+                atomicCAS(&bad[5], 0ull, (unsigned long long)i + 1ull);
+            }
     }
 }
 __device__ __forceinline__ float fma_scalar(float a, float s, float b) {
@@ -125,7 +163,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMalloc(&y, n * 16)); CK(hipMalloc(&bad, 48));
     CK(hipMemcpy(a, ha.data(), n * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb.data(), n * 16, hipMemcpyHostToDevice));
     CK(hipMemset(bad, 0, 48));
-    const int mode = !strcmp(var, "asm") ? 1 : (!strcmp(var, "scalar") ? 2 : 0);
+    const int mode = !strcmp(var, "asm") ? 1 : (!strcmp(var, "scalar") ? 2 : (!strcmp(var, "asm2") ? 3 : 0));
     long launches = 0, bad_launches = 0;
     unsigned long long prev = 0, h[6];
     const double t0 = now();
@@ -133,8 +171,10 @@ int main(int argc, char** argv) {
         const float s = 1.0f + 1e-3f * (float)(launches % 977);
         if (mode == 0) hipLaunchKernelGGL(victim_pk, dim3(4096), dim3(256), 0, 0, a, b, y, s, n);
         else if (mode == 1) hipLaunchKernelGGL(victim_asm, dim3(4096), dim3(256), 0, 0, a, b, y, s, n);
+        else if (mode == 3) hipLaunchKernelGGL(victim_asm2, dim3(4096), dim3(256), 0, 0, a, b, y, s, n);
         else hipLaunchKernelGGL(victim_scalar, dim3(4096), dim3(256), 0, 0, a, b, y, s, n);
-        hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, a, b, y, s, n, bad);
+        if (mode == 3) hipLaunchKernelGGL(check_asm2, dim3(4096), dim3(256), 0, 0, a, b, y, s, n, bad);
+        else hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, a, b, y, s, n, bad);
         ++launches;
         if (launches % 16 == 0) {
             CK(hipMemcpy(h, bad, 48, hipMemcpyDeviceToHost));
@@ -143,7 +183,7 @@ int main(int argc, char** argv) {
     }
     CK(hipMemcpy(h, bad, 48, hipMemcpyDeviceToHost));
     printf("victim %-6s: %ld launches of 16 Mi results in %.1f s; wrong components %llu (x %llu, y %llu, z %llu, w %llu), first wrong float4 index %lld, "
-           "16-launch windows with new errors %ld\n", mode == 0 ? "pk" : (mode == 1 ? "asm" : "scalar"), launches, now() - t0, h[0], h[1], h[2], h[3], h[4],
+           "16-launch windows with new errors %ld\n", mode == 0 ? "pk" : (mode == 1 ? "asm" : (mode == 3 ? "asm2" : "scalar")), launches, now() - t0, h[0], h[1], h[2], h[3], h[4],
            (long long)h[5] - 1, bad_launches);
     return h[0] ? 3 : 0;
 }

@@ -91,6 +91,7 @@ def aggressor(math, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--cross", action="store_true", help="synthetic victims x real aggressor, real victim x synthetic aggressor")
     ap.add_argument("--role", default=None)
     ap.add_argument("--variant", default=None)
     args = ap.parse_args()
@@ -100,6 +101,24 @@ def main():
         return aggressor(args.variant, args.seconds)
     build_slp_copy()
     me = [sys.executable, os.path.abspath(__file__)]
+    if args.cross:
+        # which side carries the ingredient?  synthetic victims (tools/probes/pk_mfma_repro.hip: compiler-packed, two hand-written
+        # packed forms, scalar) next to the REAL bf16x3 convolution; the REAL SLP-built bilinear kernel next to the synthetic
+        # register-only bf16 MFMA loop
+        synth = "/tmp/pk_mfma_repro"
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", synth, os.path.join(ROOT, "tools", "probes", "pk_mfma_repro.hip")],
+                       check=True, stderr=subprocess.DEVNULL)
+        for v in ("pk", "asm", "asm2", "scalar"):
+            print("== synthetic victim %s, REAL aggressor bf16x3" % v, flush=True)
+            a = subprocess.Popen(me + ["--role", "aggressor", "--variant", "bf16x3", "--seconds", str(args.seconds + 8)])
+            time.sleep(6)
+            subprocess.run([synth, "victim", str(args.seconds), v])
+            a.wait()
+        print("== REAL victim slp, synthetic aggressor bf16 (register-only MFMA loop)", flush=True)
+        a = subprocess.Popen([synth, "aggressor", str(args.seconds + 14), "bf16"])
+        subprocess.run(me + ["--role", "victim", "--variant", "slp", "--seconds", str(args.seconds)])
+        a.wait()
+        return
     for v in ("slp", "noslp"):
         for agg in (None, "f32", "bf16x3"):
             print("== victim %s, aggressor %s" % (v, agg or "none"), flush=True)

@@ -20,7 +20,7 @@ CONV = ("conv_dma_kernel", "conv_wgrad_dma_kernel", "splitk_reduce_kernel", "con
 
 
 def short(n):
-    return n.replace("void (anonymous namespace)::", "").split("(")[0]
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
 launches = collections.Counter()
