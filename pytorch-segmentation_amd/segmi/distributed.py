@@ -92,6 +92,7 @@ class GradAllReducer:
             _ops.register_grad_slots({p: self._where[id(p)][1] for p in self._slot_params})
             for p in self._slot_params:
                 p.grad = None
+        self.counters = {"adopted": 0, "copied": 0}      # gradients found in place in their slot / copied into it (diagnostics, tests)
         self._fired = set()        # id(param) of the parameters whose gradient arrived in the current iteration
         self.check_unused = os.environ.get("SEGMI_DDP_CHECK_UNUSED", "0") == "1"
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -128,9 +129,13 @@ class GradAllReducer:
         idx, view = self._where[id(p)]
         g = p.grad
         if g is not view:
-            # optimizer.zero_grad(set_to_none=True) dropped the view: autograd handed us a fresh tensor
+            # .grad was None: autograd handed us the tensor the backward function returned — an alias of the bucket slot the wgrad
+            # kernel wrote (nothing to do), or a fresh tensor (small parameters, optimizer.zero_grad(set_to_none=True)): one copy
             if g.data_ptr() != view.data_ptr():
                 view.copy_(g)
+                self.counters["copied"] += 1
+            else:
+                self.counters["adopted"] += 1
             p.grad = view
         b = self.buckets[idx]
         b["pending"] -= 1

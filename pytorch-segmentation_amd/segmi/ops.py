@@ -414,7 +414,10 @@ def _on_wgrad_stream(weight, tensors, fn):
     dev = weight.device
     side = _WGRAD_SIDE["streams"].get(dev.index)
     if side is None:
-        side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev)
+        # SEGMI_WGRAD_STREAM_PRIORITY: HIP stream priority of the side stream (lower number = higher priority; out-of-range values
+        # map to the nearest valid one).  Positive = BELOW the compute stream: the data-gradient chain (the critical path of the
+        # backward pass) gets the CUs first and the filter gradients fill what it leaves.
+        side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SEGMI_WGRAD_STREAM_PRIORITY", "0")))
     main = torch.cuda.current_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):

@@ -313,6 +313,11 @@ def test_filter_gradients_are_written_straight_into_the_bucket(cuda):
             assert len(taken) >= 15, len(taken)                       # the 3x3 / 1x1 filters of the U-Net (C % 4 == 0, KRSC in memory)
             for p in taken:
                 assert p.grad is red._where[id(p)][1]
+            # autograd ADOPTED every slot alias (AccumulateGrad neither cloned it nor added it into an existing gradient)
+            # (4-D parameters whose gradient does not come from a slot — the channel-padded RGB stem, the ConvTranspose2d filters —
+            # arrive as fresh tensors and are copied into the bucket once)
+            assert red.counters["adopted"] == len(taken) * (it + 1), (red.counters, len(taken))
+            assert red.counters["copied"] == (len(red._slot_params) - len(taken)) * (it + 1), (red.counters, len(red._slot_params), len(taken))
             red.finish()
             ops.set_wgrad_stream(False)
             for p in ref.parameters():

@@ -195,5 +195,12 @@ r3g)
   ( timeout 900 python -m pytest tests/test_determinism_gpu.py tests/test_conv_bf16x3_gpu.py tests/test_ops_gpu.py tests/test_pspnet_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|distance from the fp64|Error|assert" | tail -30 ) > gpurun_out/r3g_new_tests.log; cat gpurun_out/r3g_new_tests.log
   ( SEGMI_CONV_MATH=bf16x3 timeout 1500 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r3g_pytest_gpu_bf16x3.log
   tail -12 gpurun_out/r3g_pytest_gpu_bf16x3.log | cut -c1-300 ;;
+r3h)
+  # round 3, last call: side-stream priority A/B, then the whole suite + smoke on the final tree
+  python -c "import torch; print('stream priority range', torch.cuda.Stream.priority_range())" 2>&1 | tail -1
+  for pr in 0 1 -1; do ( SEGMI_WGRAD_STREAM_PRIORITY=$pr timeout 400 python bench.py --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r3h_bench_prio$pr.log; python -c "import json; d=json.loads(open('gpurun_out/r3h_bench_prio$pr.log').read()); print('priority $pr', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done
+  ( timeout 1500 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r3h_pytest_gpu.log
+  tail -4 gpurun_out/r3h_pytest_gpu.log | cut -c1-300
+  ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3h_smoke.log; tail -1 gpurun_out/r3h_smoke.log | cut -c1-200 ;;
 esac
 done
