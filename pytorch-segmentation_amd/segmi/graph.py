@@ -8,8 +8,10 @@ sharing the host's cores launch jitter becomes step-time jitter.  `GraphedStep` 
 capturing stream, so it is recorded like any other) and replays it with ONE host call per iteration.
 
 What makes a step capturable here
-  * no host synchronisation inside the step: losses / metrics stay on the device (`segmi.ops`), SyncBN's element count is
-    cached after the first step (`SyncBNContext.global_count`);
+  * no host synchronisation inside the step: losses / metrics stay on the device (`segmi.ops`), SyncBN's global element count
+    is summed on the device from the gathered partials (`segmi_bn_finalize(count_out)`);
+  * side-stream filter gradients (`ops.set_wgrad_stream`) fork from and re-join the capturing stream inside the step (the join is
+    an autograd-engine callback at the end of backward), which stream capture records as ordinary cross-stream dependencies;
   * dropout: the by-value seed would be frozen at capture, so the kernels fold a DEVICE-side epoch counter into the seed
     (`segmi_dropout(..., seed_epoch_dev)`), advanced by one captured `add_` at the end of the step;
   * stable gradient addresses: the fused SGD walks a device table of (param, grad, momentum) pointers that is built on

@@ -42,7 +42,7 @@ x3)
     ( SEGMI_CONV_MATH=$m timeout 300 python tools/conv_bench.py psp_bottleneck l4_3x3_d4 l4_1x1_up l3_1x1_down l1_1x1 stem3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/x3_convbench_$m.txt
     ( timeout 600 python bench.py --no-cpu --conv-math $m 2>&1 | tail -1 ) > gpurun_out/x3_bench_$m.log
   done
-  paste gpurun_out/x3_convbench_f32.txt gpurun_out/x3_convbench_bf16x3.txt; paste gpurun_out/x3_convbench_bf16x3_simple.txt gpurun_out/x3_convbench_bf16x3_pk.txt
+  paste gpurun_out/x3_convbench_f32.txt gpurun_out/x3_convbench_bf16x3.txt
   cat gpurun_out/x3_bench_*.log ;;
 x3prof)
   rm -rf gpurun_out/x3prof
