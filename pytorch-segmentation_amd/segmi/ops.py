@@ -414,10 +414,11 @@ def _on_wgrad_stream(weight, tensors, fn):
     dev = weight.device
     side = _WGRAD_SIDE["streams"].get(dev.index)
     if side is None:
-        # SEGMI_WGRAD_STREAM_PRIORITY: HIP stream priority of the side stream (lower number = higher priority; out-of-range values
-        # map to the nearest valid one).  Positive = BELOW the compute stream: the data-gradient chain (the critical path of the
-        # backward pass) gets the CUs first and the filter gradients fill what it leaves.
-        side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SEGMI_WGRAD_STREAM_PRIORITY", "0")))
+        # SEGMI_WGRAD_STREAM_PRIORITY: HIP stream priority of the side stream (lower number = higher priority; the MI355X range is
+        # {0, -1}).  Default -1: measured in one call at cfg2 (profiles/r03_wgrad_stream_priority.txt) 140.1 img/s against 138.4 /
+        # 138.9 at the compute stream's priority — a filter-gradient launch that is dispatched as soon as it is issued overlaps the
+        # HBM-bound BN-backward kernels that follow on the compute stream instead of queueing behind them.
+        side = _WGRAD_SIDE["streams"][dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SEGMI_WGRAD_STREAM_PRIORITY", "-1")))
     main = torch.cuda.current_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):

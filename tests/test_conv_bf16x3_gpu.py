@@ -153,6 +153,8 @@ def test_network_level_accuracy_over_seeds(cuda, family):
         return ro, losses_ref.cross_entropy(ro, t)
 
     prev = ops.get_conv_math()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))       # the oracle steps are small (<= 97x97): a 128-thread pool only adds fork/join time
     rows = {"f32": [], "bf16x3": [], "cpu32": []}
     try:
         for seed in range(nseeds):
@@ -189,6 +191,7 @@ def test_network_level_accuracy_over_seeds(cuda, family):
                 rows[name].append((dl, dg))
     finally:
         ops.set_conv_math(prev)
+        torch.set_num_threads(threads)
     mean = {n: (statistics.mean(r[0] for r in v), statistics.mean(r[1] for r in v)) for n, v in rows.items()}
     print("%s: distance from the fp64 oracle over %d seeds, mean (max|dlogit|/max|logit|, median per-tensor gradient rel-L2): " % (family, nseeds)
           + " | ".join("%s %.2e %.2e" % (n, mean[n][0], mean[n][1]) for n in ("cpu32", "f32", "bf16x3")))

@@ -202,5 +202,18 @@ r3h)
   ( timeout 1500 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r3h_pytest_gpu.log
   tail -4 gpurun_out/r3h_pytest_gpu.log | cut -c1-300
   ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3h_smoke.log; tail -1 gpurun_out/r3h_smoke.log | cut -c1-200 ;;
+r3pmc)
+  # matrix-pipe counters of the Winograd contraction (batched implicit-GEMM / filter-gradient launches) and of a direct 1x1 layer, one
+  # layer each in isolation (--pmc with --kernel-trace only; same counter set as profiles/r01_conv_dma_pmc.txt)
+  rm -rf gpurun_out/r3pmc
+  ( timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+      --output-format csv -d gpurun_out/r3pmc/sq -o r -- python tools/conv_bench.py aux_3x3 l4_1x1_up --iters 5 2>&1 | tail -8 ) > gpurun_out/r3pmc_sq.log
+  for d in gpurun_out/r3pmc/*/; do f=$(find $d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $d/r_counter_collection.csv 2>/dev/null; f=$(find $d -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp "$f" $d/r_kernel_trace.csv 2>/dev/null; done
+  ( cat gpurun_out/r3pmc_sq.log; python tools/pmc_summary.py gpurun_out/r3pmc/sq r conv_ wino_ 2>&1 | head -80 ) > gpurun_out/r3pmc_summary.txt; cat gpurun_out/r3pmc_summary.txt
+  find gpurun_out/r3pmc -name "*.csv" -size +4M -delete ;;
+r3i)
+  bash tools/gpu_round.sh r3pmc
+  ( timeout 700 python -m pytest tests/test_conv_bf16x3_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf --durations=12 -p no:cacheprovider 2>&1 | tail -30 ) > gpurun_out/r3i_tests.log; cat gpurun_out/r3i_tests.log
+  ( timeout 300 python bench.py --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r3i_bench.log; python -c "import json; d=json.loads(open('gpurun_out/r3i_bench.log').read()); print('bench', d['value'], d['ms_per_step'])" ;;
 esac
 done
