@@ -20,7 +20,7 @@ for r in rows:
 for n, c in acc.items():
     if not any(k in n for k in sys.argv[3:] or ["conv_"]):
         continue
-    short = n.replace("void (anonymous namespace)::", "").split("(")[0]
+    short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     us = sum(dur[n]) / len(dur[n]) if dur[n] else float("nan")
     print("%s   launches=%d   avg duration %.1f us" % (short, len(next(iter(c.values()))), us))
     avg = {k: sum(v) / len(v) for k, v in c.items()}
