@@ -389,6 +389,10 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
  * (un-normalised) and is consumed by the backward; loss_out[2] = {loss, n_present}.  At most 1820 classes.
  * rows < 2^24 (the reference's fp32 cumsums are exact only below that) and log2(C) + log2(rows) <= 32.  workspace must be
  * 256-byte aligned. */
+/* Sort used by segmi_lovasz_fwd (process-wide; the workspace size depends on it, query it after the call): 0 = the hand-written
+ * segmented radix sort (default), 1 = rocprim::radix_sort_keys over (class, error) — kept for A/B; both are stable, so the
+ * results are bit-identical.  Also selectable with SEGMI_LOVASZ_SORT=rocprim at first use. */
+int segmi_lovasz_set_sort(int algorithm);
 size_t segmi_lovasz_workspace(long rows, int C);
 int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
                      float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);

@@ -8,9 +8,12 @@
 //   2. lovasz_emit      one 64-bit word per (class, pixel):  [class | invalid | ~bits30(|fg - p_c|) | fg | pixel index]
 //                       (errors lie in [0, 2): their float bits fit 30 bits).  Ascending order of the upper field == classes
 //                       ascending, errors DESCENDING, ignored pixels last inside their class; the low PB + 1 bits are payload.
-//   3. ONE device-wide radix sort of C*P keys over the upper 31 + log2(C) bits only (rocPRIM radix_sort_keys, double buffered,
-//      begin_bit = PB + 1): the per-class sorts of the reference become a single bandwidth-bound pass set of 8 B per element
-//      per pass with the payload riding inside the key (key + value pairs over 41 bits cost 1.8x the traffic).
+//   3. a SEGMENTED least-significant-digit radix sort, hand-written (segsort_* below): the class is implicit in the segment
+//      (keys are emitted class-major), so only the 31-bit field [invalid | ~error] is sorted — four stable 8-bit passes
+//      (histogram per 4096-key tile -> per-class scan -> scatter through an LDS-sorted tile so that every digit's run leaves as
+//      one contiguous write), payload (fg bit, pixel index) riding inside the 64-bit key; absent classes are skipped on the
+//      device.  The per-class torch.sort calls of the reference become 12 bandwidth-bound launches.
+//      (SEGMI_LOVASZ_SORT=rocprim selects the former rocprim::radix_sort_keys over the 31 + log2(C) upper bits for A/B.)
 //   4. lovasz_chunk_count / lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index
 //      at every rank in the same float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels),
 //      first difference, dot with the sorted errors, and scatter of d loss / d p into the class-major G[class][pixel].
@@ -20,6 +23,7 @@
 // Ties: elements of one class with bit-equal errors may be ranked in any order (torch.sort is unstable too); the loss value
 // does not depend on that order, the per-pixel gradients inside a tie group do.
 #include "segmi_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -109,6 +113,150 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restric
                                            (unsigned long long)r;
             }
         __syncthreads();
+    }
+}
+
+// ---- segmented LSD radix sort of the class-major key array: keys[c * rows + i], i < rows, sorted per class by the digit field
+constexpr int ST = 4096;      // keys per sort tile: 256 threads x 16 rounds
+
+__device__ __forceinline__ unsigned seg_digit(unsigned long long k, int shift, unsigned mask) { return (unsigned)(k >> shift) & mask; }
+
+// lanes of this wave holding the same digit: rank of this lane among them (in lane order = key order) and their number
+__device__ __forceinline__ void wave_peers(unsigned d, bool valid, int lane, unsigned& rank, unsigned& count) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+    count = (unsigned)__popcll(peers);
+}
+
+// hist[(c * ntiles + tile) * 256 + d] = number of keys of tile `tile` of class c whose digit is d
+__global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long long* __restrict__ keys, long rows, int ntiles, int shift,
+                                                           unsigned mask, const unsigned* __restrict__ counts, unsigned* __restrict__ hist) {
+    const int c = blockIdx.y, tile = blockIdx.x;
+    if (counts[c] == 0) return;                          // absent class: never read downstream (classes='present')
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long* k = keys + (long)c * rows;
+    const long i0 = (long)tile * ST;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 2
+    for (int r = 0; r < ST / 256; ++r) {
+        const long i = i0 + r * 256 + threadIdx.x;
+        const bool valid = i < rows;
+        const unsigned d = valid ? seg_digit(k[i], shift, mask) : 0u;
+        unsigned rank, cnt;
+        wave_peers(d, valid, lane, rank, cnt);           // one LDS atomic per distinct digit and wave (the top digit is shared by most keys)
+        if (valid && rank == 0) atomicAdd(&h[d], cnt);
+    }
+    __syncthreads();
+    hist[((long)c * ntiles + tile) * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// in place: hist[c][tile][d] -> first output rank (inside the class segment) of that tile's keys with digit d:
+// exclusive scan in (digit, tile) order.  One block per class, thread d walks its digit's column (coalesced across threads).
+__global__ __launch_bounds__(256) void segsort_scan_kernel(unsigned* __restrict__ hist, int ntiles, const unsigned* __restrict__ counts) {
+    const int c = blockIdx.x, d = threadIdx.x;
+    if (counts[c] == 0) return;
+    unsigned* col = hist + (long)c * ntiles * 256 + d;
+    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int t = 0;
+    for (; t + 3 < ntiles; t += 4) {
+        t0 += col[(long)t * 256]; t1 += col[(long)(t + 1) * 256]; t2 += col[(long)(t + 2) * 256]; t3 += col[(long)(t + 3) * 256];
+    }
+    for (; t < ntiles; ++t) t0 += col[(long)t * 256];
+    const unsigned tot = (t0 + t1) + (t2 + t3);
+    __shared__ unsigned sm[256];
+    sm[d] = tot;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned y = d >= o ? sm[d - o] : 0u;
+        __syncthreads();
+        sm[d] += y;
+        __syncthreads();
+    }
+    unsigned run = sm[d] - tot;                          // keys of this class with a smaller digit
+    for (t = 0; t < ntiles; ++t) {
+        const unsigned v = col[(long)t * 256];
+        col[(long)t * 256] = run;
+        run += v;
+    }
+}
+
+// stable scatter of one tile: local ranks by rounds of 256 keys (wave peers + cross-wave prefix), the tile is assembled digit by
+// digit in LDS, then every digit's run is written to its global position as consecutive elements
+__global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
+                                                              long rows, int ntiles, int shift, unsigned mask,
+                                                              const unsigned* __restrict__ counts, const unsigned* __restrict__ hist) {
+    const int c = blockIdx.y, tile = blockIdx.x;
+    if (counts[c] == 0) return;
+    __shared__ unsigned long long sorted[ST];
+    __shared__ unsigned cnt[256], dstart[256], gbase[256], wcnt[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long* k = in + (long)c * rows;
+    const long i0 = (long)tile * ST;
+    const int nk = (int)(rows - i0 < (long)ST ? rows - i0 : (long)ST);
+    cnt[tid] = 0;
+    gbase[tid] = hist[((long)c * ntiles + tile) * 256 + tid];
+    __syncthreads();
+    // (the tile is read twice — histogram, then placement — instead of being held in 32 registers per lane: the second read hits L2,
+    // and a rolled loop keeps the 64-bit ballot masks of one round in SGPRs; the unrolled form spilled them through 512 VGPRs)
+#pragma unroll 1
+    for (int r = 0; r < ST / 256; ++r) {
+        const int i = r * 256 + tid;
+        const bool valid = i < nk;
+        const unsigned d = valid ? seg_digit(k[i0 + i], shift, mask) : 0u;
+        unsigned rank, n;
+        wave_peers(d, valid, lane, rank, n);
+        if (valid && rank == 0) atomicAdd(&cnt[d], n);
+    }
+    __syncthreads();
+    {   // dstart = exclusive scan of the tile histogram; cnt becomes the running count of keys already placed per digit
+        __shared__ unsigned sc[256];
+        const unsigned v = cnt[tid];
+        sc[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned y = tid >= o ? sc[tid - o] : 0u;
+            __syncthreads();
+            sc[tid] += y;
+            __syncthreads();
+        }
+        dstart[tid] = sc[tid] - v;
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < ST / 256; ++r) {
+        const int i = r * 256 + tid;
+        const bool valid = i < nk;
+        const unsigned long long key = valid ? k[i0 + i] : 0ull;
+        const unsigned d = seg_digit(key, shift, mask);
+        unsigned rank, n;
+        wave_peers(d, valid, lane, rank, n);
+        wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+        __syncthreads();
+        if (valid && rank == 0) wcnt[w][d] = n;
+        __syncthreads();
+        if (valid) {
+            unsigned pre = 0;
+            for (int ww = 0; ww < w; ++ww) pre += wcnt[ww][d];
+            sorted[dstart[d] + cnt[d] + pre + rank] = key;
+        }
+        __syncthreads();
+        cnt[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+        __syncthreads();
+    }
+    unsigned long long* o = out + (long)c * rows;
+    for (int j = tid; j < nk; j += 256) {
+        const unsigned long long kk = sorted[j];
+        const unsigned d = seg_digit(kk, shift, mask);
+        o[(long)gbase[d] + (unsigned)(j - (int)dstart[d])] = kk;
     }
 }
 
@@ -317,9 +465,18 @@ int lovasz_bwd_tp(int C) {
 
 struct LovaszLayout {
     size_t keys_a, keys_b, chunk_fg, counts, part, temp, total;
-    int nchunks, begin_bit, end_bit, PB;
+    int nchunks, begin_bit, end_bit, PB, ntiles;
     size_t temp_bytes;
 };
+// SEGMI_LOVASZ_SORT=rocprim: the device-wide rocPRIM sort over (class, error) instead of the hand-written segmented sort (A/B)
+int g_lovasz_sort = -1;       // 0 segmented (hand-written, default), 1 rocPRIM; segmi_lovasz_set_sort / SEGMI_LOVASZ_SORT
+bool lovasz_use_rocprim() {
+    if (g_lovasz_sort < 0) {
+        const char* e = getenv("SEGMI_LOVASZ_SORT");
+        g_lovasz_sort = (e && !strcmp(e, "rocprim")) ? 1 : 0;
+    }
+    return g_lovasz_sort == 1;
+}
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 bool lovasz_layout(long rows, int C, LovaszLayout* L) {
@@ -340,10 +497,14 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
     L->chunk_fg = off; off += align256((size_t)C * L->nchunks * 4);
     L->counts = off; off += align256((size_t)(C + 1) * 4);
     L->part = off; off += align256((size_t)C * L->nchunks * 8);
-    // rocPRIM temporary storage (histograms / lookback state): a host-side size query, nothing is launched
-    size_t tb = 0;
-    rocprim::double_buffer<unsigned long long> dk(nullptr, nullptr);
-    if (rocprim::radix_sort_keys(nullptr, tb, dk, n, (unsigned)L->begin_bit, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
+    // scratch of the sort: per-tile digit histograms [C][ntiles][256] of the segmented sort, or rocPRIM's temporary storage
+    // (histograms / lookback state: a host-side size query, nothing is launched)
+    L->ntiles = (int)((rows + ST - 1) / ST);
+    size_t tb = (size_t)C * L->ntiles * 256 * sizeof(unsigned);
+    if (lovasz_use_rocprim()) {
+        rocprim::double_buffer<unsigned long long> dk(nullptr, nullptr);
+        if (rocprim::radix_sort_keys(nullptr, tb, dk, n, (unsigned)L->begin_bit, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
+    }
     L->temp_bytes = tb;
     L->temp = off; off += align256(tb);
     L->total = off;
@@ -353,6 +514,12 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
 }  // namespace
 
 extern "C" {
+
+int segmi_lovasz_set_sort(int algorithm) {
+    if (algorithm != 0 && algorithm != 1) return SEGMI_ERR_BADARG;
+    g_lovasz_sort = algorithm;
+    return SEGMI_OK;
+}
 
 size_t segmi_lovasz_workspace(long rows, int C) {
     LovaszLayout L;
@@ -382,10 +549,28 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
                        ignore_index, lse, counts);
     hipLaunchKernelGGL(lovasz_emit_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ld, target, (const float*)lse,
                        rows, C, ignore_index, L.PB, ka);
-    rocprim::double_buffer<unsigned long long> dk(ka, kb);
-    size_t tb = L.temp_bytes;
-    if (rocprim::radix_sort_keys(ws + L.temp, tb, dk, (size_t)rows * C, (unsigned)L.begin_bit, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
-    const unsigned long long* ks = dk.current();
+    const unsigned long long* ks = ka;
+    if (lovasz_use_rocprim()) {
+        rocprim::double_buffer<unsigned long long> dk(ka, kb);
+        size_t tb = L.temp_bytes;
+        if (rocprim::radix_sort_keys(ws + L.temp, tb, dk, (size_t)rows * C, (unsigned)L.begin_bit, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
+        ks = dk.current();
+    } else {
+        // four stable 8-bit passes over the 31-bit field [invalid | ~error] above the fg bit: ka -> kb -> ka -> kb -> ka
+        unsigned* hist = (unsigned*)(ws + L.temp);
+        unsigned long long *src = ka, *dst = kb;
+        const dim3 tgrid((unsigned)L.ntiles, (unsigned)C);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = L.PB + 1 + 8 * pass;
+            const unsigned mask = pass < 3 ? 0xFFu : 0x7Fu;
+            hipLaunchKernelGGL(segsort_hist_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, rows, L.ntiles, shift, mask, (const unsigned*)counts, hist);
+            hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, hist, L.ntiles, (const unsigned*)counts);
+            hipLaunchKernelGGL(segsort_scatter_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, dst, rows, L.ntiles, shift, mask,
+                               (const unsigned*)counts, (const unsigned*)hist);
+            unsigned long long* t = src; src = dst; dst = t;
+        }
+        ks = src;                                          // == ka after an even number of passes
+    }
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
     hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);

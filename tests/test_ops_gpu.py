@@ -496,6 +496,35 @@ def test_lovasz_softmax_vs_oracle(cuda, case):
     assert float(xd.grad.cpu()[:, :, :2, :].abs().max()) == 0.0     # ignored pixels get no gradient
 
 
+@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255), (2, 19, 200, 210, 255), (1, 7, 5, 3, 255),
+                                  (2, 21, 256, 256, 255)])
+def test_lovasz_segmented_sort_equals_library_sort(cuda, case):
+    """The hand-written segmented radix sort of csrc/lovasz.hip (the default) and rocprim::radix_sort_keys (kept for A/B,
+    segmi_lovasz_set_sort) are both STABLE sorts of the same keys over the same bits, so loss and gradient must agree BIT FOR BIT —
+    on single-tile, multi-tile and ragged-last-tile segments (84 000 = 20.5 tiles of 4096 keys), with ignored pixels, absent
+    classes, and random (not block-constant) targets that put ties next to each other."""
+    import utils.losses as L
+    from segmi import lib
+    N, C, H, W, ign = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, C, H, W, generator=g) * 3
+    t = torch.randint(0, max(2, C - 2), (N, H, W), generator=g)
+    t[:, :1, :] = ign
+    res = []
+    try:
+        for algo in (0, 1):
+            assert lib.segmi_lovasz_set_sort(algo) == 0
+            xd = x.to(cuda).requires_grad_(True)
+            ld = L.LovaszSoftmax(ignore_index=ign)(xd, t.to(cuda))
+            ld.backward()
+            res.append((ld.detach().clone(), xd.grad.clone()))
+    finally:
+        lib.segmi_lovasz_set_sort(0)
+    assert torch.equal(res[0][0], res[1][0]), (res[0][0].item(), res[1][0].item())
+    assert torch.equal(res[0][1], res[1][1]), (res[0][1] - res[1][1]).abs().max().item()
+    assert torch.isfinite(res[0][0]) and float(res[0][1].abs().max()) > 0
+
+
 def test_fused_sgd_matches_torch_sgd(cuda):
     """segmi.optim.SGD (one launch over all tensors) vs torch.optim.SGD over 3 steps: two parameter groups with different lr
     (the reference's differential learning rates), momentum 0.9, weight decay 1e-4, lr changed between steps (schedulers do),

@@ -215,5 +215,11 @@ r3i)
   bash tools/gpu_round.sh r3pmc
   ( timeout 700 python -m pytest tests/test_conv_bf16x3_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf --durations=12 -p no:cacheprovider 2>&1 | tail -30 ) > gpurun_out/r3i_tests.log; cat gpurun_out/r3i_tests.log
   ( timeout 300 python bench.py --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r3i_bench.log; python -c "import json; d=json.loads(open('gpurun_out/r3i_bench.log').read()); print('bench', d['value'], d['ms_per_step'])" ;;
+r3j)
+  # hand-written segmented Lovasz sort: bit-identity vs the library sort, goldens, cfg5 audit, cfg5 A/B
+  ( timeout 400 python -m pytest tests/test_ops_gpu.py tests/test_fullsize_golden_gpu.py tests/test_fullsize_properties_gpu.py -k "lovasz or losses_match or cfg5" -m gpu -q -rf -p no:cacheprovider 2>&1 | tail -15 ) > gpurun_out/r3j_tests.log; cat gpurun_out/r3j_tests.log
+  ( timeout 200 python bench.py --config cfg5 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3j_cfg5_seg.log
+  ( SEGMI_LOVASZ_SORT=rocprim timeout 200 python bench.py --config cfg5 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3j_cfg5_rocprim.log
+  for f in seg rocprim; do python -c "import json; d=json.loads(open('gpurun_out/r3j_cfg5_$f.log').read()); print('cfg5 $f', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done ;;
 esac
 done
