@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restric
 }
 
 // ---- segmented LSD radix sort of the class-major key array: keys[c * rows + i], i < rows, sorted per class by the digit field
-constexpr int ST = 4096;      // keys per sort tile: 256 threads x 16 rounds
+constexpr int ST = 4096;      // keys per sort tile: 256 threads x 16 rounds (8192-key tiles, 73 KB of LDS, two blocks per CU: 3 % slower)
+constexpr int SEG_MLP = 8;    // key loads a wave keeps in flight (16 rounds in groups of SEG_MLP; the ballots of a group stay in SGPRs)
 
 __device__ __forceinline__ unsigned seg_digit(unsigned long long k, int shift, unsigned mask) { return (unsigned)(k >> shift) & mask; }
 
@@ -145,14 +146,23 @@ __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long l
     const unsigned long long* k = keys + (long)c * rows;
     const long i0 = (long)tile * ST;
     const int lane = threadIdx.x & 63;
-#pragma unroll 2
-    for (int r = 0; r < ST / 256; ++r) {
-        const long i = i0 + r * 256 + threadIdx.x;
-        const bool valid = i < rows;
-        const unsigned d = valid ? seg_digit(k[i], shift, mask) : 0u;
-        unsigned rank, cnt;
-        wave_peers(d, valid, lane, rank, cnt);           // one LDS atomic per distinct digit and wave (the top digit is shared by most keys)
-        if (valid && rank == 0) atomicAdd(&h[d], cnt);
+#pragma unroll 1
+    for (int r0 = 0; r0 < ST / 256; r0 += SEG_MLP) {     // SEG_MLP 512-byte loads per wave in flight (one at a time is latency-bound: 1 TB/s)
+        unsigned long long kq[SEG_MLP];
+        bool vq[SEG_MLP];
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const long i = i0 + (r0 + u) * 256 + threadIdx.x;
+            vq[u] = i < rows;
+            kq[u] = vq[u] ? k[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const unsigned d = seg_digit(kq[u], shift, mask);
+            unsigned rank, cnt;
+            wave_peers(d, vq[u], lane, rank, cnt);       // one LDS atomic per distinct digit and wave (the top digit is shared by most keys)
+            if (vq[u] && rank == 0) atomicAdd(&h[d], cnt);
+        }
     }
     __syncthreads();
     hist[((long)c * ntiles + tile) * 256 + threadIdx.x] = h[threadIdx.x];
@@ -188,37 +198,53 @@ __global__ __launch_bounds__(256) void segsort_scan_kernel(unsigned* __restrict_
     }
 }
 
-// stable scatter of one tile: local ranks by rounds of 256 keys (wave peers + cross-wave prefix), the tile is assembled digit by
-// digit in LDS, then every digit's run is written to its global position as consecutive elements
+// stable scatter of one tile.  Each WAVE owns a contiguous quarter of the tile (1024 keys = 16 rounds of 64), so after one
+// block-level histogram phase the placement needs no block barrier at all: position = first slot of the digit in the tile
+// + keys of that digit in earlier waves' quarters + keys of that digit this wave has already placed + rank among the wave's
+// lanes holding the digit in this round (ballots).  The tile is assembled digit by digit in LDS, then every digit's run is
+// written to its global position as consecutive elements.
 __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                               long rows, int ntiles, int shift, unsigned mask,
                                                               const unsigned* __restrict__ counts, const unsigned* __restrict__ hist) {
     const int c = blockIdx.y, tile = blockIdx.x;
     if (counts[c] == 0) return;
+    constexpr int WQ = ST / 4;                         // keys per wave
     __shared__ unsigned long long sorted[ST];
-    __shared__ unsigned cnt[256], dstart[256], gbase[256], wcnt[4][256];
+    __shared__ unsigned wbase[4][256], wrun[4][256], gbase[256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long* k = in + (long)c * rows;
     const long i0 = (long)tile * ST;
     const int nk = (int)(rows - i0 < (long)ST ? rows - i0 : (long)ST);
-    cnt[tid] = 0;
+    wbase[0][tid] = 0; wbase[1][tid] = 0; wbase[2][tid] = 0; wbase[3][tid] = 0;
+    wrun[0][tid] = 0; wrun[1][tid] = 0; wrun[2][tid] = 0; wrun[3][tid] = 0;
     gbase[tid] = hist[((long)c * ntiles + tile) * 256 + tid];
     __syncthreads();
-    // (the tile is read twice — histogram, then placement — instead of being held in 32 registers per lane: the second read hits L2,
-    // and a rolled loop keeps the 64-bit ballot masks of one round in SGPRs; the unrolled form spilled them through 512 VGPRs)
+    // phase 1: per-wave digit histograms of the wave's quarter (one lane per distinct digit adds: no atomics, a wave's LDS
+    // operations execute in order).  The tile is read twice (here and in phase 2, from L2) instead of being held in registers:
+    // a rolled loop keeps one round's 64-bit ballot masks in SGPRs (the unrolled form spilled them through 512 VGPRs).
 #pragma unroll 1
-    for (int r = 0; r < ST / 256; ++r) {
-        const int i = r * 256 + tid;
-        const bool valid = i < nk;
-        const unsigned d = valid ? seg_digit(k[i0 + i], shift, mask) : 0u;
-        unsigned rank, n;
-        wave_peers(d, valid, lane, rank, n);
-        if (valid && rank == 0) atomicAdd(&cnt[d], n);
+    for (int r0 = 0; r0 < WQ / 64; r0 += SEG_MLP) {      // SEG_MLP loads per wave in flight
+        unsigned long long kq[SEG_MLP];
+        bool vq[SEG_MLP];
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const int i = w * WQ + (r0 + u) * 64 + lane;
+            vq[u] = i < nk;
+            kq[u] = vq[u] ? k[i0 + i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const unsigned d = seg_digit(kq[u], shift, mask);
+            unsigned rank, n;
+            wave_peers(d, vq[u], lane, rank, n);
+            if (vq[u] && rank == 0) wbase[w][d] += n;
+        }
     }
     __syncthreads();
-    {   // dstart = exclusive scan of the tile histogram; cnt becomes the running count of keys already placed per digit
-        __shared__ unsigned sc[256];
-        const unsigned v = cnt[tid];
+    {   // wbase[w][d] <- first slot of (wave w, digit d) in the tile: exclusive scan of the tile histogram over digits, then over waves
+        const unsigned h0 = wbase[0][tid], h1 = wbase[1][tid], h2 = wbase[2][tid], h3 = wbase[3][tid];
+        const unsigned v = h0 + h1 + h2 + h3;
+        unsigned* sc = &wrun[3][0];                    // scan scratch (wrun[3] is re-zeroed below)
         sc[tid] = v;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -227,36 +253,39 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
             sc[tid] += y;
             __syncthreads();
         }
-        dstart[tid] = sc[tid] - v;
-        cnt[tid] = 0;
+        const unsigned start = sc[tid] - v;
+        __syncthreads();
+        wbase[0][tid] = start; wbase[1][tid] = start + h0; wbase[2][tid] = start + h0 + h1; wbase[3][tid] = start + h0 + h1 + h2;
+        wrun[3][tid] = 0;
     }
     __syncthreads();
+    // phase 2: placement, wave by wave, no block barrier
 #pragma unroll 1
-    for (int r = 0; r < ST / 256; ++r) {
-        const int i = r * 256 + tid;
-        const bool valid = i < nk;
-        const unsigned long long key = valid ? k[i0 + i] : 0ull;
-        const unsigned d = seg_digit(key, shift, mask);
-        unsigned rank, n;
-        wave_peers(d, valid, lane, rank, n);
-        wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
-        __syncthreads();
-        if (valid && rank == 0) wcnt[w][d] = n;
-        __syncthreads();
-        if (valid) {
-            unsigned pre = 0;
-            for (int ww = 0; ww < w; ++ww) pre += wcnt[ww][d];
-            sorted[dstart[d] + cnt[d] + pre + rank] = key;
+    for (int r0 = 0; r0 < WQ / 64; r0 += SEG_MLP) {
+        unsigned long long kq[SEG_MLP];
+        bool vq[SEG_MLP];
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const int i = w * WQ + (r0 + u) * 64 + lane;
+            vq[u] = i < nk;
+            kq[u] = vq[u] ? k[i0 + i] : 0ull;
         }
-        __syncthreads();
-        cnt[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SEG_MLP; ++u) {
+            const unsigned d = seg_digit(kq[u], shift, mask);
+            unsigned rank, n;
+            wave_peers(d, vq[u], lane, rank, n);
+            const unsigned before = wrun[w][d];        // every lane reads before the digit's first lane adds this round's count
+            if (vq[u]) sorted[wbase[w][d] + before + rank] = kq[u];
+            if (vq[u] && rank == 0) wrun[w][d] = before + n;
+        }
     }
+    __syncthreads();
     unsigned long long* o = out + (long)c * rows;
     for (int j = tid; j < nk; j += 256) {
         const unsigned long long kk = sorted[j];
         const unsigned d = seg_digit(kk, shift, mask);
-        o[(long)gbase[d] + (unsigned)(j - (int)dstart[d])] = kk;
+        o[(long)gbase[d] + (unsigned)(j - (int)wbase[0][d])] = kk;
     }
 }
 

@@ -221,5 +221,8 @@ r3j)
   ( timeout 200 python bench.py --config cfg5 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3j_cfg5_seg.log
   ( SEGMI_LOVASZ_SORT=rocprim timeout 200 python bench.py --config cfg5 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3j_cfg5_rocprim.log
   for f in seg rocprim; do python -c "import json; d=json.loads(open('gpurun_out/r3j_cfg5_$f.log').read()); print('cfg5 $f', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done ;;
+r3k)
+  ( timeout 200 python -m pytest tests/test_ops_gpu.py -k "lovasz" -m gpu -q -p no:cacheprovider 2>&1 | tail -3 ) > gpurun_out/r3k_tests.log; cat gpurun_out/r3k_tests.log
+  ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3k_smoke.log; cut -c1-220 gpurun_out/r3k_smoke.log ;;
 esac
 done
