@@ -23,7 +23,8 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 # per-file additions: no compiler-formed packed-fp32 arithmetic (v_pk_mul/fma/add_f32) in the HBM-bound kernels.  The SLP-packed
 # form of bilinear_fwd_kernel returns wrong high halves while a bf16x3 convolution kernel of ANOTHER process shares the GPU
-# (tools/probes/pk_two_process.py reproduces it with exactly these two kernels; profiles/r03_pk_two_process.txt);
+# (tools/probes/pk_two_process.py reproduces it with exactly these two kernels: 32 % of the launches wrong against an fp64 reference,
+# profiles/r03_pk_two_process_ref.txt);
 # the scalar form never does.  These kernels are HBM-bound: no cost.
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize", "-fno-vectorize"] for f in ("pool_resize.hip", "conv_winograd.hip", "bn.hip", "loss.hip", "misc.hip", "optim.hip",
                                                     "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip")}
