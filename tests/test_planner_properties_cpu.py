@@ -71,3 +71,61 @@ def test_baseline_shapes_take_the_lds_dma_kernels(shape):
     assert conv_variant(d, 0).startswith("conv_dma_kernel<")
     assert conv_variant(d, 1).startswith("conv_dma_kernel<")
     assert conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<")
+
+
+wino_descs = st.builds(lambda N, H, W, C, K, dil: _desc(N, H, W, C, K, 3, 1, dil), st.integers(1, 16), st.integers(1, 130), st.integers(1, 130),
+                       st.sampled_from([4, 64, 256, 304, 512, 2048]), st.sampled_from([19, 21, 64, 256, 512]),
+                       st.sampled_from([1, 2, 4, 6, 12])).filter(lambda d: d is not None)
+
+
+@settings(max_examples=200, deadline=None)
+@given(wino_descs)
+def test_winograd_plans_are_consistent(d):
+    """Winograd F(2x2,3x3) planners (csrc/conv_winograd.hip): tile count, workspace decomposition of the three passes, the kept
+    transformed input, and the batched filter-gradient split, for random 3x3 stride-1 "same" problems incl. dilation > map."""
+    import ctypes
+    from segmi import lib
+
+    def al(b):
+        return (b + 255) & ~255
+
+    assert lib.segmi_conv2d_winograd_ok(d, 0) == 1
+    th, tw = (-(-d.H // d.dil) + 1) // 2, (-(-d.W // d.dil) + 1) // 2
+    T = d.N * d.dil * d.dil * th * tw
+    assert lib.segmi_conv2d_winograd_tiles(d) == T and 4 * T >= d.N * d.H * d.W          # the tiles cover every output pixel
+    Tp, Kp = (T + 31) & ~31, (d.K + 3) & ~3
+    assert lib.segmi_conv2d_winograd_v_bytes(d) == 16 * Tp * d.C * 4
+    assert lib.segmi_conv2d_winograd_workspace(d, 0) == al(16 * d.K * d.C * 4) + al(16 * Tp * d.C * 4) + al(16 * T * Kp * 4)
+    if lib.segmi_conv2d_winograd_ok(d, 1) == 1:
+        TpK = Tp                                       # dgrad: the transformed input is dy (Kp channels), the product has C columns
+        assert lib.segmi_conv2d_winograd_workspace(d, 1) == al(16 * d.C * Kp * 4) + al(16 * TpK * Kp * 4) + al(16 * T * d.C * 4)
+    assert lib.segmi_conv2d_winograd_wgrad_ok(d) == 1
+    buf = ctypes.create_string_buffer(128)
+    assert lib.segmi_conv2d_winograd_wgrad_variant(d, buf, 128) == 0
+    m = re.match(r"^winograd_f2x2_3x3 wgrad: 16 x conv_wgrad_dma_kernel<(64|128), (64|128), true, [01]> splitk=(\d+)$", buf.value.decode())
+    assert m, buf.value
+    ns = int(m.group(3))
+    assert 1 <= ns <= 512 and ns <= Tp // 32                                   # every split owns at least one 32-row chunk of tiles
+    assert lib.segmi_conv2d_winograd_wgrad_workspace(d) == al(16 * Tp * d.C * 4) + al(16 * Tp * Kp * 4) + al(ns * 16 * d.K * d.C * 4)
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.integers(1, 1 << 22), st.sampled_from([2, 3, 19, 21, 150, 255]))
+def test_lovasz_workspace_layout(rows, C):
+    """segmi_lovasz_workspace under both sorts: two 64-bit key buffers + scan scratch + the sort's own scratch (per-tile digit
+    histograms [C][ceil(rows/4096)][256] for the hand-written segmented sort), 256-byte aligned pieces; set_sort is validated."""
+    from segmi import lib
+    assert lib.segmi_lovasz_set_sort(7) != 0
+    try:
+        assert lib.segmi_lovasz_set_sort(0) == 0
+        seg = lib.segmi_lovasz_workspace(rows, C)
+        assert lib.segmi_lovasz_set_sort(1) == 0
+        roc = lib.segmi_lovasz_workspace(rows, C)
+    finally:
+        lib.segmi_lovasz_set_sort(0)
+    keys = 2 * ((rows * C * 8 + 255) & ~255)
+    hist = C * ((rows + 4095) // 4096) * 256 * 4
+    assert seg % 256 == 0 and roc % 256 == 0
+    assert seg >= keys + hist and seg - keys - ((hist + 255) & ~255) < (1 << 20) + C * ((rows + 2047) // 2048) * 12 + 2048
+    assert roc >= keys
+    assert lib.segmi_lovasz_workspace(1 << 24, C) == 0          # fp32-exact rank arithmetic ends at 2^24 pixels, like the reference's cumsums
