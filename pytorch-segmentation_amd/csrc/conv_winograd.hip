@@ -1,5 +1,6 @@
-// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (padding == dilation, "same" size): forward and data gradient.
-// Replaces, for those layers, the same call sites as conv_igemm.hip (aten::conv2d / convolution_backward input gradient of
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (padding == dilation, "same" size): forward, data gradient and filter
+// gradient — the default algorithm of the eligible layers (segmi/ops.py: min(C, K) >= 256, sub-grids of >= 8 pixels).
+// Replaces, for those layers, the same call sites as conv_igemm.hip (aten::conv2d / convolution_backward of
 // models/resnet.py:84-86 conv2 of every Bottleneck, models/pspnet.py:27-30 bottleneck, models/deeplabv3_plus.py:264-284 ASPP,
 // :307-318 decoder, models/unet.py:15-18) with 2.25x fewer multiplications in the SAME arithmetic:
 //
@@ -12,10 +13,13 @@
 //
 // Dataflow (HBM layouts, fp32):
 //   wino_filter_kernel   g [O,3,3,I]            -> U [16][O][I]          (per step: the filters change)
-//   wino_input_kernel    x [N,H,W,ldx]          -> V [16][T][Cin]        T = N * dil^2 * th * tw tiles
+//   wino_input_kernel    x [N,H,W,ldx]          -> V [16][Tpad][Cin]     T = N * dil^2 * th * tw tiles, Tpad = round_up(T, 32) (zero rows);
+//                                                  the forward pass may write V into a caller buffer kept for the filter gradient
 //   segmi_internal_gemm_batched                   M_xi [T, Cout] = V_xi [T, Cin] x U_xi [Cout, Cin]^T, xi < 16, ONE launch of the
 //                                                  LDS-DMA implicit-GEMM kernel (blockIdx.y = xi), under the process-wide conv arithmetic
 //   wino_output_kernel   M [16][T][ldm]         -> y [N,H,W,ldy]  (+ bias) (+ y)
+//   filter gradient:     wino_dy_kernel dy -> W [16][Tpad][Kp];  ONE batched launch of the filter-gradient kernel (blockIdx.z = xi)
+//                        dU_xi = W_xi^T V_xi into split partials;  wino_filter_grad_kernel sums the splits and applies G^T . G
 // A dilation d decomposes into d*d dense problems on the sub-grids (h % d, w % d): tile (n, i, j, ty, tx) covers the output
 // pixels h = (2 ty + a) d + i, w = (2 tx + b) d + j, a, b < 2, and reads rows (2 ty - 1 + u) d + i, u < 4.
 // The transforms are HBM streams (V is 4x the input, M 4x the output); the contraction is MFMA-bound and 2.25x shorter.
