@@ -67,6 +67,16 @@ typedef struct segmi_conv_desc {
 size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d);
 int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
                      int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+/* Forward convolution that feeds a BatchNorm (the conv -> bn pairs of models/resnet.py:105-121, models/unet.py:12-21,
+ * models/deeplabv3_plus.py:80-86): y = conv(x, w) (+ bias) AND, from the output tile while it is still in registers, the
+ * per-channel Welford partials {count, mean, M2} of every row tile: stats_partials [parts][3][K] floats, parts =
+ * segmi_conv2d_fwd_stats_parts(d) (0 = this problem has no such epilogue: K % 4 != 0, split-reduction launches of tiny outputs,
+ * operands beyond 4 GiB; call segmi_conv2d_fwd then).  The partials are what segmi_bn_stats would compute from y — the BN layer
+ * merges them (segmi_bn_finalize_from_parts / segmi_bn_stats_from_parts) and never reads y for its statistics:
+ * one HBM pass of nn.BatchNorm2d's aten::native_batch_norm less (14.2 -> 9.5 GB per cfg2 step). */
+int segmi_conv2d_fwd_stats_parts(const segmi_conv_desc* d);
+int segmi_conv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
+                           float* stats_partials, segmi_stream_t stream);
 /* dx = conv_transpose(dy, w) (+ dx if accumulate).  w_crsk is the filter re-laid as [C,R,S,K]
  * (segmi_filter_krsc_to_crsk); requires K % 4 == 0 padding handled by the caller via ldy. */
 int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
@@ -205,6 +215,17 @@ int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const floa
                             float momentum, int clamp_mode, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                             void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+/* The same two results from Welford partials a PRODUCER already wrote (segmi_conv2d_fwd_stats: [nparts][3][C] floats):
+ * _stats_from_parts = segmi_bn_stats without reading x (one packed partial for the SyncBN all-gather), _finalize_from_parts =
+ * segmi_bn_stats_finalize without reading x.  More than 512 partials are merged in two levels through `workspace`
+ * (segmi_bn_parts_workspace bytes). */
+size_t segmi_bn_parts_workspace(int nparts, int C);
+int segmi_bn_stats_from_parts(const float* partials, int nparts, int C, float* partial, void* workspace, size_t workspace_bytes,
+                              segmi_stream_t stream);
+int segmi_bn_finalize_from_parts(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, int clamp_mode, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                                 void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* eval / frozen BN: scale/shift from running statistics */
 int segmi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                          float eps, int C, float* mean, float* invstd, float* scale, float* shift,

@@ -1,6 +1,8 @@
 """Generate tests/golden/full_*.pt: the REAL reference (/root/reference) run on torch CPU at the BASELINE.json shapes.
 
     python oracle/gen_golden_fullsize.py [cfg2 cfg3 cfg4 cfg5]      (build container only; ~5 min, peak RSS ~13 GB)
+    python oracle/gen_golden_fullsize.py f64 [cfg...]               fp64 oracle logits + the reference's distance from them
+    python oracle/gen_golden_fullsize.py f64grads cfgN              fp64 oracle BACKWARD: gradient digests + the reference's distance
 
 One training step per config (dropout neutralised, BN batch statistics, weights from oracle.weights.synth_state_dict,
 inputs from oracle.weights.synth_batch) with exactly the loss expression of the reference's hot loop
@@ -120,6 +122,84 @@ def add_f64(name):
           % (name, rec["ref_err_f64"], rec["ref_err_f64"] / rec["logit_absmax"], os.path.getsize(path) / 1e6), flush=True)
 
 
+def _lovasz_softmax_any_dtype(logits, target, ignore_index):
+    """oracle.losses_ref.lovasz_softmax with every intermediate in the logits' dtype (the reference hard-codes .float() in
+    utils/lovasz_losses.py:185,194-198 and therefore raises for fp64 input): the same piecewise-linear function, evaluated in fp64."""
+    import torch.nn.functional as F
+    C = logits.shape[1]
+    p = F.softmax(logits, dim=1).permute(0, 2, 3, 1).reshape(-1, C)
+    t = target.reshape(-1)
+    keep = t != ignore_index
+    p, t = p[keep], t[keep]
+    losses = []
+    for c in range(C):
+        fg = (t == c).to(p.dtype)
+        total = fg.sum()
+        if total == 0:
+            continue
+        err = (fg - p[:, c]).abs()
+        err_sorted, perm = torch.sort(err, 0, descending=True)
+        g = fg[perm]
+        jac = 1.0 - (total - g.cumsum(0)) / (total + (1 - g).cumsum(0))
+        if g.numel() > 1:
+            jac[1:] = jac[1:] - jac[:-1].clone()
+        losses.append(torch.dot(err_sorted, jac.detach()))
+    return sum(losses) / len(losses)
+
+
+def add_f64_grads(name):
+    """Append the fp64 oracle BACKWARD to an existing fixture: per-tensor digests of d loss / d parameter
+    evaluated in fp64 at the same sample positions as `grads` ("grads_f64": norm, 64 strided samples, first 8 values), and
+    `ref_grad_err_f64` = the REAL reference's own fp32 digests' relative L2 distance from them, per tensor, with its median and
+    maximum — the measured rounding-noise floor of this config's gradients that tests/test_fullsize_golden_gpu.py holds the HIP
+    path to.  One process per config (cfg2: ~25 GB, cfg3 at batch 16 and cfg5: more; run them one at a time)."""
+    import statistics
+    from oracle import deeplab_ref, losses_ref, pspnet_ref
+    path = os.path.join(GOLD, "full_%s.pt" % name)
+    rec = torch.load(path, weights_only=False)
+    sd = synth_state_dict(rec["manifest"], seed=rec["weight_seed"])
+    N, _, H, W = rec["input_shape"]
+    C, ign = rec["num_classes"], rec["ignore_index"]
+    x, t = synth_batch(N, 3, H, W, C, ignore_index=ign, seed=rec["batch_seed"])
+    dt = torch.float64
+    st = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}, requires_grad=True)
+    t0 = time.time()
+    if rec["arch"] == "PSPNet":
+        out, aux = pspnet_ref.pspnet_forward(st, x.to(dt), training=True, backbone=rec["kwargs"]["backbone"])
+        loss = losses_ref.cross_entropy(out, t, ign) + 0.4 * losses_ref.cross_entropy(aux, t, ign)
+        del aux
+    else:
+        out = deeplab_ref.deeplab_forward(st, x.to(dt), rec["kwargs"]["backbone"], rec["kwargs"]["output_stride"], training=True)
+        if rec["loss_name"] == "LovaszSoftmax":
+            loss = _lovasz_softmax_any_dtype(out, t, ign)
+        else:
+            loss = losses_ref.cross_entropy(out, t, ign)
+    s = rec["stride"]
+    assert (out.detach()[:, :, ::s, ::s].float() - rec["logits_f64"]).abs().max().item() <= 1e-5 * rec["logit_absmax"], "fp64 forward drifted"
+    del out
+    loss.backward()
+    g64, errs = {}, {}
+    for k, dg in rec["grads"].items():
+        g = st[k].grad.detach().reshape(-1)
+        step = max(1, g.numel() // 64)
+        g64[k] = {"norm": g.norm().item(), "head": g[:8].clone(), "sample": g[::step][:64].clone()}
+        a = torch.cat([dg["sample"], dg["head"]]).double()
+        b = torch.cat([g64[k]["sample"], g64[k]["head"]])
+        errs[k] = ((a - b).norm() / (b.norm() + 1e-300)).item()
+    top = max(v["norm"] for v in g64.values())
+    live = [e for k, e in errs.items() if g64[k]["norm"] > 1e-5 * top]     # analytically-zero gradients are pure rounding noise
+    rec["grads_f64"] = g64
+    rec["ref_grad_err_f64"] = {"per_tensor": errs, "median": statistics.median(live), "max": max(live),
+                               "worst": max((e, k) for k, e in errs.items() if g64[k]["norm"] > 1e-5 * top)[1]}
+    rec["loss_f64"] = loss.item()
+    torch.save(rec, path)
+    import resource
+    print("%s: fp64 backward in %.0f s (peak RSS %.1f GB); reference fp32 gradient digests vs fp64: rel-L2 median %.3e max %.3e (%s); "
+          "loss fp64 %.8f vs reference %.8f" % (name, time.time() - t0, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6,
+                                                rec["ref_grad_err_f64"]["median"], rec["ref_grad_err_f64"]["max"], rec["ref_grad_err_f64"]["worst"],
+                                                rec["loss_f64"], rec["loss"].item()), flush=True)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -127,6 +207,10 @@ if __name__ == "__main__":
     if args and args[0] == "f64":           # second pass, separate process (the oracle and the reference share module names)
         for name in (args[1:] or list(FULL)):
             add_f64(name)
+        sys.exit(0)
+    if args and args[0] == "f64grads":      # third pass, ONE config per process (memory)
+        for name in (args[1:] or list(FULL)):
+            add_f64_grads(name)
         sys.exit(0)
     models, losses = reference_harness.load()
     for name in (args or list(FULL)):

@@ -106,11 +106,18 @@ __device__ __forceinline__ void finalize_channel(const FinalizeArgs& f, int c, f
 // each lane folds parts y, y+16, ... serially (<= 32 steps at the 512-part cap), then a Chan tree over
 // the 16 lanes in LDS — the serial one-thread-per-channel form cost 160 us per BN layer.
 // FINAL: single-device BN — the merged statistics go straight to mean/invstd/scale/shift (no packed partial, no second launch)
+// blockIdx.y = slice of `slice` consecutive partials (first level of a two-level merge: gridDim.y partials come out, FINAL false);
+// gridDim.y == 1 merges everything
 template <bool FINAL>
 __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int nparts, int Cp,
-                                                             float* __restrict__ out, FinalizeArgs fin) {
+                                                             float* __restrict__ out, FinalizeArgs fin, int slice) {
     const int c = blockIdx.x * 16 + threadIdx.x;
     const bool cok = c < Cp;
+    if (gridDim.y > 1) {
+        part += (long)blockIdx.y * slice * 3 * Cp;
+        nparts = min(slice, nparts - (int)blockIdx.y * slice);
+        out += (long)blockIdx.y * 3 * Cp;
+    }
     float n = 0.f, m = 0.f, q = 0.f;
     if (cok) {
         // four partials per step are loaded unconditionally BEFORE the (serial) Chan merges, so 12 loads are in flight at once
@@ -412,7 +419,7 @@ int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, voi
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
-    hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial, FinalizeArgs{});
+    hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial, FinalizeArgs{}, 0);
     return segmi_launch_status();
 }
 
@@ -430,8 +437,49 @@ int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const floa
     g.grid.y = parts;
     hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
     const FinalizeArgs f = {gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
-    hipLaunchKernelGGL((bn_stats_merge_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, (float*)nullptr, f);
+    hipLaunchKernelGGL((bn_stats_merge_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, (float*)nullptr, f, 0);
     return segmi_launch_status();
+}
+
+// ---- statistics from partials a PRODUCER already wrote (the convolution's BN-statistics epilogue, segmi_conv2d_fwd_stats):
+// up to 512 partials merge in one launch; more (row tiles of the 128x128 / 256x256 maps) go through a first level of 64-partial
+// slices into the workspace.
+static int merge_level1_parts(int nparts) { return nparts > STATS_MAX_PARTS ? segmi_cdiv(nparts, 64) : 0; }
+size_t segmi_bn_parts_workspace(int nparts, int C) { return (size_t)merge_level1_parts(nparts) * 3 * C * sizeof(float) + 16; }
+
+static int merge_parts(const float* partials, int nparts, int C, float* out, const FinalizeArgs* fin, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
+    const float* src = partials;
+    int n = nparts;
+    const int l1 = merge_level1_parts(nparts);
+    if (l1) {
+        if (!workspace || workspace_bytes < segmi_bn_parts_workspace(nparts, C)) return SEGMI_ERR_WORKSPACE;
+        hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16), l1), dim3(16, 16), 0, st, partials, nparts, C,
+                           (float*)workspace, FinalizeArgs{}, 64);
+        src = (const float*)workspace;
+        n = l1;
+    }
+    if (fin) hipLaunchKernelGGL((bn_stats_merge_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, src, n, C, (float*)nullptr, *fin, 0);
+    else     hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, src, n, C, out, FinalizeArgs{}, 0);
+    return segmi_launch_status();
+}
+
+int segmi_bn_stats_from_parts(const float* partials, int nparts, int C, float* partial, void* workspace, size_t workspace_bytes,
+                              segmi_stream_t stream) {
+    if (!partials || !partial || nparts <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+    if (C & 3) return SEGMI_ERR_ALIGN;
+    return merge_parts(partials, nparts, C, partial, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int segmi_bn_finalize_from_parts(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, int clamp_mode, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                                 void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!partials || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return SEGMI_ERR_BADARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SEGMI_ERR_BADARG;
+    if (C & 3) return SEGMI_ERR_ALIGN;
+    const FinalizeArgs f = {gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
+    return merge_parts(partials, nparts, C, nullptr, &f, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int segmi_bn_finalize(const float* partials, int nparts, int C, const float* gamma, const float* beta, float eps,

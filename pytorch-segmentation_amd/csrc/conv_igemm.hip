@@ -59,6 +59,11 @@ struct GatherParams {
     // operands lie bs_src / bs_wgt / bs_dst floats apart (the 16 transform-domain GEMMs of a Winograd convolution)
     int batch;
     long bs_src, bs_wgt, bs_dst;
+    // fprop feeding a BatchNorm (LDS-DMA kernel, ksplit == 1, batch == 1, no accumulate): every workgroup also writes the Welford
+    // partial {count, mean, M2} of ITS output tile, per channel, to stats[tile_m][3][stats_cp] — the layout bn_stats_merge_kernel
+    // folds (csrc/bn.hip) — so the statistics pass of the BN layer never reads the tensor again
+    float* stats;
+    int stats_cp;
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -753,6 +758,65 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (kok && roff[q] >= 0) st4(dst_base + roff[q] + k, v[q]);
+        if (MODE == MODE_FPROP && p.stats) {
+            // BN statistics of the tile while its values are in registers: a lane holds NQ rows x 4 channels — exact two-pass
+            // {count, mean, M2} per lane, Chan merge across the 8 lanes that share the channel group (lane bits 3..5), then the
+            // wave's 32-channel partial goes to LDS for the cross-wave merge below
+            float cnt = 0.f;
+            float4 sum = zero4();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (roff[q] >= 0) { cnt += 1.f; sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
+            const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+            float4 mean = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv), m2 = zero4();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (roff[q] >= 0) {
+                    const float dx = v[q].x - mean.x, dy = v[q].y - mean.y, dz = v[q].z - mean.z, dw = v[q].w - mean.w;
+                    m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+                }
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                const float nb = __shfl_xor(cnt, off);
+                const float4 mb = make_float4(__shfl_xor(mean.x, off), __shfl_xor(mean.y, off), __shfl_xor(mean.z, off), __shfl_xor(mean.w, off));
+                const float4 qb = make_float4(__shfl_xor(m2.x, off), __shfl_xor(m2.y, off), __shfl_xor(m2.z, off), __shfl_xor(m2.w, off));
+                const float nn = cnt + nb;
+                const float f = nn > 0.f ? nb / nn : 0.f, g2 = cnt * f;
+                float d;
+                d = mb.x - mean.x; mean.x += d * f; m2.x += qb.x + d * d * g2;
+                d = mb.y - mean.y; mean.y += d * f; m2.y += qb.y + d * d * g2;
+                d = mb.z - mean.z; mean.z += d * f; m2.z += qb.z + d * d * g2;
+                d = mb.w - mean.w; mean.w += d * f; m2.w += qb.w + d * d * g2;
+                cnt = nn;
+            }
+            if (er == 0) {
+                float* sst = smem + 4 * (TM * 32 * EP) + (wave / WN) * (3 * BN) + wn0 + j * 32 + ec;
+                st4(sst, make_float4(cnt, cnt, cnt, cnt));
+                st4(sst + BN, mean);
+                st4(sst + 2 * BN, m2);
+            }
+        }
+    }
+    if (MODE == MODE_FPROP && p.stats) {             // (workgroup-uniform)
+        static_assert(4 * (BM / WM) * EP + WM * 3 * BN <= 2 * (BM + BN) * BK, "statistics slice fits behind the staging slices");
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cd) {
+            const float* sst = smem + 4 * (TM * 32 * EP) + tid;
+            float n = sst[0], m = sst[BN], q2 = sst[2 * BN];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) {            // fixed order: deterministic
+                const float nb = sst[w * 3 * BN], mb = sst[w * 3 * BN + BN], qb = sst[w * 3 * BN + 2 * BN];
+                const float nn = n + nb;
+                if (nb > 0.f) {
+                    const float d = mb - m, f = nb / nn;
+                    m += d * f;
+                    q2 += qb + d * d * n * f;
+                    n = nn;
+                }
+            }
+            float* o = p.stats + (long)tm * 3 * p.stats_cp + n0 + tid;
+            o[0] = n; o[p.stats_cp] = m; o[2 * p.stats_cp] = q2;
+        }
     }
 }
 
@@ -773,6 +837,7 @@ struct WgradParams {
     // results lie bs_x / bs_dy / bs_out floats apart (the 16 transform-domain contractions of a Winograd filter gradient)
     int batch;
     long bs_x, bs_dy, bs_out;
+    int flat;  // 1: (tile, split) from the linear workgroup id through xcd_swizzle, split-major (see conv_wgrad_dma_kernel); 0: blockIdx.y = split
 };
 
 template <int BM, int BN, int BKP, int WM, int WN>
@@ -931,13 +996,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 
     // tile = (c-tile, k-tile, tap) with the tap fastest, and each XCD owning a contiguous range of tile ids:
     // an XCD's L2 then holds only ITS channel slices of x (read once per tap from L2, not from HBM) plus dy.
+    // Workgroups are dispatched x-fastest and dealt round-robin to the 8 XCDs.  The (tile, split) pair is taken from the LINEAR
+    // workgroup id through xcd_swizzle, split-major: an XCD then owns a contiguous range of pixel splits with ALL their tiles, so
+    // the 64 workgroups resident on it walk the same pixel rows of x and dy together and every operand byte enters exactly one
+    // L2 (with blockIdx.y = split and only the tiles swizzled, the 16 x 4 tiles of one split of a 512 -> 2048 1x1 layer sat on all
+    // 8 XCDs: dy was fetched by 4 of them, x by 2 — 726 MB per launch for 335 MB of operands, profiles/r03_cfg2_conv_traffic_f32.json)
     const int RSn = p.pack4 ? 1 : p.R * p.S;
-    int tidx = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned lin = p.flat ? xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y)
+                                : xcd_swizzle(blockIdx.x, gridDim.x) + gridDim.x * blockIdx.y;
+    int tidx = (int)(lin % gridDim.x);
     const int tap = tidx % RSn; tidx /= RSn;
     const int tk = tidx % p.tiles_k; tidx /= p.tiles_k;
     const int tc = tidx;
     const int k0 = tk * BM, c0 = tc * BN;
-    const int split = blockIdx.y;
+    const int split = (int)(lin / gridDim.x);
     const int mbeg = split * p.chunks_per_split * BKP;
     const int mend = min(p.M, mbeg + p.chunks_per_split * BKP);
     const int PQ = p.P * p.Q;
@@ -1257,12 +1329,30 @@ __global__ void colsum_partial_kernel(const float* x, int ld, long rows, int C, 
     __syncthreads();
     if (rl == 0 && c < C) part[(long)blockIdx.y * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
-__global__ void colsum_final_kernel(const float* part, int nparts, int C, float* out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int i = 0; i < nparts; ++i) acc += part[(long)i * C + c];
-    out[c] = acc;
+// block = (32 channels, 8 partial lanes): four independent loads per lane and step, LDS tree over the lanes (one thread per
+// channel walking up to 512 partials serially cost 40 us per bias gradient: every load waited for the previous add)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    float a = 0.f;
+    if (c < C) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = threadIdx.y;
+        for (; i + 24 < nparts; i += 32) {
+            a0 += part[(long)i * C + c]; a1 += part[(long)(i + 8) * C + c];
+            a2 += part[(long)(i + 16) * C + c]; a3 += part[(long)(i + 24) * C + c];
+        }
+        for (; i < nparts; i += 8) a0 += part[(long)i * C + c];
+        a = (a0 + a1) + (a2 + a3);
+    }
+    __shared__ float sm[8][33];
+    sm[threadIdx.y][threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 // planes[p][i] (bf16, p = 0 h, 1 m, 2 l; plane stride n elements) of the fp32 array w[n]: the same split as split_pair, done once
@@ -1507,8 +1597,18 @@ bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
     return conv_dma() && *xb && *dyb;
 }
 
+int g_wgrad_flat = -1;  // SEGMI_WGRAD_FLAT=0: the round-3 workgroup order (A/B hook)
+int wgrad_flat() {
+    if (g_wgrad_flat < 0) {
+        const char* e = getenv("SEGMI_WGRAD_FLAT");
+        g_wgrad_flat = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_wgrad_flat;
+}
+
 template <int BM, int BN>
 int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    p.flat = wgrad_flat();
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
     dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : p.R * p.S)), (unsigned)pl.nsplit, (unsigned)(p.batch > 1 ? p.batch : 1));
     unsigned xb, dyb;
@@ -1539,8 +1639,18 @@ size_t segmi_conv2d_fwd_workspace(const segmi_conv_desc* d) {
     return fs.ksplit > 1 ? (size_t)fs.ksplit * d->N * d->P * d->Q * d->ldy * sizeof(float) : 0;
 }
 
+// Number of {count, mean, M2} partials the forward kernel's BN-statistics epilogue emits for this problem (one per row tile), or 0
+// when the launch that would serve it has no such epilogue (register-staged fallback, split reduction of tiny outputs, K % 4)
+static int fwd_stats_parts(const segmi_conv_desc* d) {
+    if (!desc_ok(d) || !dma_eligible_fwd(d) || (d->K & 3)) return 0;
+    if (plan_fwd_split(d).ksplit > 1) return 0;
+    const int M = d->N * d->P * d->Q;
+    const int bm = (d->K > 32 && dma_half_m(M, d->K)) ? 64 : 128;
+    return segmi_cdiv(M, bm);
+}
+
 static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w, const void* planes, const float* bias, float* y,
-                         int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+                         int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream, float* stats = nullptr) {
     if (!desc_ok(d) || !x || (!w && !planes) || !y) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < ((d->K + 3) & ~3) || !aligned16(x) ||
         !aligned16(planes ? planes : (const void*)w) || !aligned16(y))
@@ -1554,8 +1664,13 @@ static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* 
     p.M = d->N * d->P * d->Q; p.accumulate = accumulate;
     p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
     p.batch = 1; p.bs_src = p.bs_wgt = p.bs_dst = 0;
+    p.stats = nullptr; p.stats_cp = 0;
+    if (stats) {
+        if (accumulate || fwd_stats_parts(d) == 0) return SEGMI_ERR_BADARG;
+        p.stats = stats; p.stats_cp = d->K;
+    }
     const FwdSplit fs = plan_fwd_split(d);
-    if (fs.ksplit > 1 && !accumulate && !bias && dma_eligible_fwd(d) && workspace) {      // workspace == NULL: caller opts out of the split
+    if (!stats && fs.ksplit > 1 && !accumulate && !bias && dma_eligible_fwd(d) && workspace) {      // workspace == NULL: caller opts out of the split
         if (workspace_bytes < segmi_conv2d_fwd_workspace(d) || !aligned16(workspace)) return SEGMI_ERR_WORKSPACE;
         p.ksplit = fs.ksplit; p.its_per_split = fs.its_per_split; p.ws = (float*)workspace;
     }
@@ -1566,6 +1681,14 @@ int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, c
                      int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     if (!w) return SEGMI_ERR_BADARG;
     return conv_fwd_impl(d, x, w, nullptr, bias, y, accumulate, workspace, workspace_bytes, stream);
+}
+
+int segmi_conv2d_fwd_stats_parts(const segmi_conv_desc* d) { return fwd_stats_parts(d); }
+
+int segmi_conv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* stats_partials,
+                           segmi_stream_t stream) {
+    if (!w || !stats_partials) return SEGMI_ERR_BADARG;
+    return conv_fwd_impl(d, x, w, nullptr, bias, y, 0, nullptr, 0, stream, stats_partials);
 }
 
 static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const float* w_crsk, const void* planes, float* dx, int accumulate,
@@ -1586,6 +1709,7 @@ static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const floa
     p.M = d->N * d->H * d->W; p.accumulate = accumulate;
     p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
     p.batch = 1; p.bs_src = p.bs_wgt = p.bs_dst = 0;
+    p.stats = nullptr; p.stats_cp = 0;
     const int st = d->stride;
     const bool dma_ok = conv_dma() && span32((long)d->N * d->P * d->Q * d->ldy) && span32((long)d->C * d->R * d->S * Kpad);
     if (st == 1 || !dma_ok || d->R * d->S > 16) return dispatch_gather<MODE_DGRAD>(p, (hipStream_t)stream);
@@ -1768,7 +1892,7 @@ int segmi_colsum(const float* x, int ld, long rows, int C, float* out, void* wor
     const int parts = colsum_parts(rows);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(segmi_cdiv(C, 64), parts), dim3(256), 0, st, x, ld, rows, C, (float*)workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(segmi_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, parts, C, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(segmi_cdiv(C, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, C, out);
     return segmi_launch_status();
 }
 
@@ -1791,6 +1915,7 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
     p.M = M; p.accumulate = 0;
     p.ksplit = 1; p.its_per_split = 0; p.ws = nullptr; p.sub = 0;
     p.batch = batch; p.bs_src = bs_a; p.bs_wgt = bs_w; p.bs_dst = bs_d;
+    p.stats = nullptr; p.stats_cp = 0;
     return dispatch_gather<MODE_FPROP>(p, st);
 }
 

@@ -38,6 +38,8 @@ SIGNATURES = {
     "segmi_copy_rows": (i32, [vp, i32, vp, i32, i64, i32, i32, vp]),
     "segmi_conv2d_fwd_workspace": (sz, [PD]),
     "segmi_conv2d_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "segmi_conv2d_fwd_stats_parts": (i32, [PD]),
+    "segmi_conv2d_fwd_stats": (i32, [PD, vp, vp, vp, vp, vp, vp]),
     "segmi_conv2d_dgrad": (i32, [PD, vp, vp, vp, i32, vp]),
     "segmi_conv2d_wgrad_workspace": (sz, [PD]),
     "segmi_conv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
@@ -77,6 +79,9 @@ SIGNATURES = {
     "segmi_bn_stats": (i32, [vp, i32, i64, i32, vp, vp, sz, vp]),
     "segmi_bn_finalize": (i32, [vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "segmi_bn_stats_finalize": (i32, [vp, i32, i64, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "segmi_bn_parts_workspace": (sz, [i32, i32]),
+    "segmi_bn_stats_from_parts": (i32, [vp, i32, i32, vp, vp, sz, vp]),
+    "segmi_bn_finalize_from_parts": (i32, [vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),

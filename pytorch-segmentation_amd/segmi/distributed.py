@@ -90,6 +90,7 @@ class GradAllReducer:
             from . import ops as _ops
             self._ops = _ops
             _ops.register_grad_slots({p: self._where[id(p)][1] for p in self._slot_params})
+            _ops.mark_reducer_hooks(self._slot_params)
             for p in self._slot_params:
                 p.grad = None
         self.counters = {"adopted": 0, "copied": 0}      # gradients found in place in their slot / copied into it (diagnostics, tests)
@@ -132,6 +133,10 @@ class GradAllReducer:
             # .grad was None: autograd handed us the tensor the backward function returned — an alias of the bucket slot the wgrad
             # kernel wrote (nothing to do), or a fresh tensor (small parameters, optimizer.zero_grad(set_to_none=True)): one copy
             if g.data_ptr() != view.data_ptr():
+                if self._ops is not None and g.is_cuda and g.dim() == 4:
+                    # a filter gradient that is not the slot alias may still be in flight on the filter-gradient side stream
+                    # (optimizer.zero_grad(set_to_none=True), a slot already handed out): the copy below runs on the compute stream
+                    self._ops.wgrad_stream_join()
                 view.copy_(g)
                 self.counters["copied"] += 1
             else:
@@ -176,6 +181,8 @@ class GradAllReducer:
                     view = self._where[id(p)][1]
                     if p.grad is not view:
                         if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                            if self._ops is not None:
+                                self._ops.wgrad_stream_join()
                             view.copy_(p.grad)
                         p.grad = view
                 self._launch(b)
@@ -226,6 +233,14 @@ class GradAllReducer:
         self._hooks = []
         if self._ops is not None:
             self._ops.register_grad_slots({p: None for p in self._slot_params})
+            self._ops.mark_reducer_hooks(self._slot_params, on=False)
+            self._slot_params = []
+
+    def __del__(self):
+        try:
+            self.remove()
+        except Exception:
+            pass
 
 
 class SyncBNContext:

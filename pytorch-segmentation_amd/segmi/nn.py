@@ -31,15 +31,19 @@ class Conv2d(nn.Conv2d):
                 raise ValueError("segmi.nn.Conv2d needs symmetric %s, got %s" % (name, (v,)))
         if not self.depthwise and (self.kernel_size[0] > 1 or self.kernel_size[1] > 1):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        # set by the BatchNorm2d that receives this module's output (ops._note_bn_consumer): True while a batch-statistics BN
+        # consumes it — the convolution then emits the BN statistics partials from its epilogue (ops._BN_FUSE)
+        self._bn_consumer = False
 
     def forward(self, x, with_skip=False):
         if self.depthwise:
             return ops.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
+        fuse = self._bn_consumer and torch.is_grad_enabled()
         if with_skip:   # (conv(x), x): residual fork whose backward accumulates dgrad onto the skip gradient (ops.conv2d_skip)
             if self.bias is not None:
                 raise ValueError("with_skip is for the bias-free first convolution of a residual block")
-            return ops.conv2d_skip(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+            return ops.conv2d_skip(x, self.weight, self.stride[0], self.padding[0], self.dilation[0], bn_stats=fuse, producer=self)
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0], bn_stats=fuse, producer=self)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

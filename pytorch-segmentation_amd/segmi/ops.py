@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -159,16 +159,31 @@ def _filter_krsc(w, Ce):
 # tensor handed to autograd is a fresh alias of the slot (its own TensorImpl, so AccumulateGrad adopts it without a clone or an
 # in-place add) and the reducer's hook finds the gradient already in place — no per-parameter copy in the N > 1 path.
 # A slot is handed out once per iteration (a filter used twice in one graph accumulates through the ordinary path).
-_GRAD_SLOTS = {}          # id(parameter) -> [view into the bucket, taken this iteration]
+_GRAD_SLOTS = {}          # id(parameter) -> [view into the bucket, taken this iteration, weakref to the parameter]
+_HOOK_SAFE = weakref.WeakSet()   # parameters whose post-accumulate hook is a GradAllReducer's (it joins the side stream itself)
 
 
 def register_grad_slots(views):
-    """views: {parameter: gradient view with the parameter's shape and strides, or None to unregister that parameter}."""
+    """views: {parameter: gradient view with the parameter's shape and strides, or None to unregister that parameter}.
+    Entries hold only a weak reference to their parameter and are verified by identity when handed out: a slot whose parameter
+    died (its id may be reused by a new tensor) is dropped instead of being written."""
     for p, v in views.items():
         if v is None:
-            _GRAD_SLOTS.pop(id(p), None)
+            e = _GRAD_SLOTS.get(id(p))
+            if e is not None and e[2]() is p:
+                del _GRAD_SLOTS[id(p)]
+            _HOOK_SAFE.discard(p)
         else:
-            _GRAD_SLOTS[id(p)] = [v, False]
+            _GRAD_SLOTS[id(p)] = [v, False, weakref.ref(p)]
+    for k in [k for k, e in _GRAD_SLOTS.items() if e[2]() is None]:
+        del _GRAD_SLOTS[k]
+
+
+def mark_reducer_hooks(params, on=True):
+    """A GradAllReducer declares that the post-accumulate hook on these parameters is its own (it waits for the filter-gradient
+    side stream before it reads a gradient): such a hook does not force the filter gradient in order (see _on_wgrad_stream)."""
+    for p in params:
+        (_HOOK_SAFE.add if on else _HOOK_SAFE.discard)(p)
 
 
 def reset_grad_slots(params=None):
@@ -179,6 +194,9 @@ def reset_grad_slots(params=None):
 
 def _take_grad_slot(w):
     e = _GRAD_SLOTS.get(id(w))
+    if e is not None and e[2]() is not w:          # stale entry under a reused id
+        del _GRAD_SLOTS[id(w)]
+        return None
     if e is None or e[1] or w.grad is not None or e[0].shape != w.shape or e[0].stride() != w.stride() or (e[0].data_ptr() & 15):
         return None
     e[1] = True
@@ -324,8 +342,26 @@ def _winograd_wgrad_variant(d):
     return buf.value.decode()
 
 
-def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False):
+# BatchNorm statistics from the producing convolution's epilogue (segmi_conv2d_fwd_stats, default on; SEGMI_CONV_BN_STATS=0 keeps the
+# separate statistics pass): a convolution whose output goes to a training-mode BatchNorm writes the per-row-tile Welford partials
+# of its output while the tile is in registers, and the BN layer merges those instead of reading the tensor again.  The pairing
+# is discovered at run time: the convolution tags its output with its module, the BN layer that receives a tagged tensor marks
+# that module (`_bn_consumer`), and from the next step on the convolution emits the partials (`bn_stats=True`), attached to
+# its output as `_segmi_bn_stats` = (partials, nparts, tensor version).
+_BN_FUSE = {"on": os.environ.get("SEGMI_CONV_BN_STATS", "1") == "1", "emitted": 0, "consumed": 0, "last": None}
+
+
+def set_conv_bn_stats(on):
+    _BN_FUSE["on"] = bool(on)
+
+
+def get_conv_bn_stats():
+    return {k: _BN_FUSE[k] for k in ("on", "emitted", "consumed")}
+
+
+def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
     """segmi_conv2d_fwd (or its pre-split-filter / Winograd form when that applies) with its workspace and roofline span.
+    bn_stats: also emit the BN-statistics partials of y when the launch has that epilogue (left in _BN_FUSE["last"]).
     w: flat KRSC filter tensor of d.K * d.R * d.S * d.C floats.  keep_v: the caller will need this layer's filter gradient —
     returns the Winograd-transformed input V (a tensor to keep for `_conv_wgrad(v=...)`) when the layer runs on the Winograd
     kernels with a Winograd filter gradient, else None."""
@@ -342,11 +378,20 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False):
                                                 y.data_ptr(), accumulate, v.data_ptr() if v is not None else None, ws.data_ptr(), nws, st),
                   "conv2d_winograd_fwd")
         return v
+    bp = bias.data_ptr() if bias is not None else None
+    pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
+    if bn_stats and not accumulate and pre is None:
+        parts = lib.segmi_conv2d_fwd_stats_parts(d)
+        if parts > 0:
+            part = torch.empty(parts * 3 * d.K, device=dev, dtype=torch.float32)
+            with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+                check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
+            _BN_FUSE["last"] = (part, parts)
+            _BN_FUSE["emitted"] += 1
+            return None
     nws = lib.segmi_conv2d_fwd_workspace(d) if (bias is None and not accumulate) else 0
     ws = workspace(nws, dev) if nws else None
     wsp = ws.data_ptr() if ws is not None else None
-    bp = bias.data_ptr() if bias is not None else None
-    pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
     with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
         if pre is not None:
             check(lib.segmi_conv2d_fwd_presplit(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
@@ -380,8 +425,13 @@ def _conv_wgrad(d, C, x, dy, dwb, v=None):
 # Rules that keep it exact: the side stream first waits for the main stream (dy is complete), x / dy / dW are record_stream()ed so the
 # caching allocator does not recycle them early, the main stream re-joins at the END of the backward pass (autograd engine
 # callback), and the path is only taken when the parameter has no gradient yet (AccumulateGrad then adopts the tensor without
-# launching anything; an accumulating or bucket-view gradient keeps the in-order path).
-_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": None, "launches": 0}
+# launching anything; an accumulating or bucket-view gradient keeps the in-order path).  Two more cases stay in order because
+# something on the compute stream reads dW before the end-of-backward join: a filter used MORE THAN ONCE in one graph (the engine
+# sums the two gradients in its input buffer — the second use first joins the side stream, then runs in order), and a parameter
+# carrying tensor hooks or post-accumulate hooks other than a GradAllReducer's (torch DDP, a clipping hook: they see dW during
+# backward; the reducer's own hook joins the side stream before it touches a gradient).
+_WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": None, "launches": 0,
+               "task": None, "inflight": set(), "in_order_reuse": 0, "in_order_hooks": 0}
 
 
 def set_wgrad_stream(on):
@@ -389,11 +439,14 @@ def set_wgrad_stream(on):
 
 
 def get_wgrad_stream():
-    return {"on": _WGRAD_SIDE["on"], "launches": _WGRAD_SIDE["launches"]}
+    return {"on": _WGRAD_SIDE["on"], "launches": _WGRAD_SIDE["launches"], "in_order_reuse": _WGRAD_SIDE["in_order_reuse"],
+            "in_order_hooks": _WGRAD_SIDE["in_order_hooks"]}
 
 
 def _join_wgrad_stream():
     _WGRAD_SIDE["armed"] = None
+    _WGRAD_SIDE["task"] = None
+    _WGRAD_SIDE["inflight"].clear()
     for side in _WGRAD_SIDE["streams"].values():
         torch.cuda.current_stream(side.device).wait_stream(side)
 
@@ -411,6 +464,20 @@ def _on_wgrad_stream(weight, tensors, fn):
     when that is enabled and safe (see _WGRAD_SIDE), in order on the current stream otherwise."""
     if not (_WGRAD_SIDE["on"] and weight.grad is None and weight.is_leaf and torch.is_grad_enabled() is False):
         return fn()
+    task = torch._C._current_graph_task_id()
+    if _WGRAD_SIDE["task"] != task:
+        _WGRAD_SIDE["task"] = task
+        _WGRAD_SIDE["inflight"].clear()
+    if id(weight) in _WGRAD_SIDE["inflight"]:
+        # second use of this filter in the same graph: the engine will add the two gradients on the compute stream
+        wgrad_stream_join()
+        _WGRAD_SIDE["in_order_reuse"] += 1
+        return fn()
+    if weight._backward_hooks or (getattr(weight, "_post_accumulate_grad_hooks", None) and weight not in _HOOK_SAFE):
+        _WGRAD_SIDE["in_order_hooks"] += 1
+        return fn()
+    if task >= 0:
+        _WGRAD_SIDE["inflight"].add(id(weight))
     dev = weight.device
     side = _WGRAD_SIDE["streams"].get(dev.index)
     if side is None:
@@ -429,7 +496,6 @@ def _on_wgrad_stream(weight, tensors, fn):
     _WGRAD_SIDE["launches"] += 1
     # one join per backward pass, keyed by the engine's graph-task id (a pass that died with an exception never ran its
     # callback: the next pass has a new id and arms again)
-    task = torch._C._current_graph_task_id()
     if task < 0:                           # not inside an engine-driven backward pass: join right away
         _join_wgrad_stream()
     elif _WGRAD_SIDE["armed"] != task:
@@ -537,9 +603,15 @@ def _filter_crsk(weight, w, K, R, S, Ce, Kp):
     return wt
 
 
+# Grad mode at the time a convolution wrapper was called (inside Function.forward it is always off, and needs_input_grad reflects
+# requires_grad only): under torch.no_grad() validation nothing will ever ask for the filter gradient, so the Winograd layers must
+# not allocate the 4x-size V buffer they keep for it.
+_FWD = {"grad": True}
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, stride, pad, dil, bn_stats=False):
         x = to_nhwc(x, "conv2d")
         _need_cuda(weight, "conv2d")
         N, C, H, W = x.shape
@@ -551,7 +623,7 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, K, P, Q, x.device)
         d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
-        v = _conv_fwd(d, C, x, w, bias, y, keep_v=ctx.needs_input_grad[1])
+        v = _conv_fwd(d, C, x, w, bias, y, keep_v=ctx.needs_input_grad[1] and _FWD["grad"], bn_stats=bn_stats)
         if ctx.needs_input_grad[0]:
             _filter_transposes.note(weight, w, K, R, S, Ce, pad4(K))
         ctx.save_for_backward(x, weight, v)
@@ -588,12 +660,27 @@ class _Conv2dFn(torch.autograd.Function):
             ws = workspace(nws, x.device)
             db = torch.empty(K, device=x.device, dtype=torch.float32)
             check(lib.segmi_colsum(dy.data_ptr(), ld_of(dy), rows, K, db.data_ptr(), ws.data_ptr(), nws, st), "colsum")
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
-    """aten::conv2d replacement (groups == 1, symmetric stride/padding/dilation)."""
-    return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+def _tag_bn_stats(y, producer):
+    """Attach what a following BatchNorm can use: the producing module (pairing discovery) and, when the convolution emitted
+    them, the statistics partials of exactly this tensor version."""
+    last, _BN_FUSE["last"] = _BN_FUSE["last"], None
+    if producer is not None:
+        y._segmi_producer = weakref.ref(producer)
+    if last is not None:
+        y._segmi_bn_stats = (last[0], last[1], y._version)
+    return y
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, bn_stats=False, producer=None):
+    """aten::conv2d replacement (groups == 1, symmetric stride/padding/dilation).  bn_stats: the output feeds a training-mode
+    BatchNorm — emit its statistics partials from the convolution's epilogue when the launch supports it."""
+    _FWD["grad"] = torch.is_grad_enabled()
+    _BN_FUSE["last"] = None
+    y = _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(bn_stats) and _BN_FUSE["on"])
+    return _tag_bn_stats(y, producer)
 
 
 class _Conv2dSkipFn(torch.autograd.Function):
@@ -604,18 +691,18 @@ class _Conv2dSkipFn(torch.autograd.Function):
     for batch_norm_act(residual=skip, relu=True), whose backward allocates the residual gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dil):
+    def forward(ctx, x, weight, stride, pad, dil, bn_stats=False):
         x = to_nhwc(x, "conv2d")
-        y = _Conv2dFn.forward(ctx, x, weight, None, stride, pad, dil)
+        y = _Conv2dFn.forward(ctx, x, weight, None, stride, pad, dil, bn_stats)
         return y, x[:]
 
     @staticmethod
     def backward(ctx, dy, dskip):
         if dskip is None or not ctx.needs_input_grad[0]:
-            dx, dw, _, _, _, _ = _Conv2dFn.backward(ctx, dy)
+            dx, dw = _Conv2dFn.backward(ctx, dy)[:2]
             if dskip is not None and dx is not None:
                 dx = add(dx, dskip)
-            return (dx if dx is not None else dskip), dw, None, None, None
+            return (dx if dx is not None else dskip), dw, None, None, None, None
         x, weight, v = ctx.saved_tensors
         N, C, H, W, K, R, S, P, Q, stride, pad, dil = ctx.geom
         dy = to_nhwc(dy, "conv2d.backward")
@@ -634,12 +721,15 @@ class _Conv2dSkipFn(torch.autograd.Function):
             else:
                 _conv_wgrad(d, C, x, dy, dwb, v)
             dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
-        return dskip, dw, None, None, None
+        return dskip, dw, None, None, None, None
 
 
-def conv2d_skip(x, weight, stride=1, padding=0, dilation=1):
+def conv2d_skip(x, weight, stride=1, padding=0, dilation=1, bn_stats=False, producer=None):
     """(conv2d(x, weight), x) with a fused backward: see _Conv2dSkipFn for the ownership contract of the skip gradient."""
-    return _Conv2dSkipFn.apply(x, weight, int(stride), int(padding), int(dilation))
+    _FWD["grad"] = torch.is_grad_enabled()
+    _BN_FUSE["last"] = None
+    y, skip = _Conv2dSkipFn.apply(x, weight, int(stride), int(padding), int(dilation), bool(bn_stats) and _BN_FUSE["on"])
+    return _tag_bn_stats(y, producer), skip
 
 
 # --------------------------------------------------------------------------- depthwise convolution
@@ -769,10 +859,26 @@ def conv_transpose2x2(x, weight, bias=None):
 
 
 # --------------------------------------------------------------------------- batch norm (+ReLU +residual)
+def _producer_stats(x, C):
+    """(partials, nparts) the producing convolution wrote for exactly this tensor (same version, matching width), else None."""
+    st = getattr(x, "_segmi_bn_stats", None)
+    if st is None or not _BN_FUSE["on"] or st[2] != x._version or st[0].numel() != st[1] * 3 * C:
+        return None
+    return st[0], st[1]
+
+
+def _note_bn_consumer(x, batch_stats):
+    """Pairing discovery: tell the module that produced `x` whether a batch-statistics BatchNorm consumes its output."""
+    ref = getattr(x, "_segmi_producer", None)
+    mod = ref() if ref is not None else None
+    if mod is not None:
+        mod._bn_consumer = bool(batch_stats)
+
+
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, num_batches_tracked, training, momentum,
-                eps, relu, sync):
+                eps, relu, sync, pstats=None):
         x = to_nhwc(x, "batch_norm")
         N, C, H, W = x.shape
         if C & 3:
@@ -789,7 +895,24 @@ class _BatchNormActFn(torch.autograd.Function):
         rm = running_mean.data_ptr() if running_mean is not None else None
         rv = running_var.data_ptr() if running_var is not None else None
         nbt = num_batches_tracked.data_ptr() if num_batches_tracked is not None else None
-        if training and sync is None:
+        if training and pstats is not None and (sync is not None or rows > 1):
+            part, nparts = pstats
+            nws = lib.segmi_bn_parts_workspace(nparts, C)
+            ws = workspace(nws, dev)
+            _BN_FUSE["consumed"] += 1
+            if sync is None:
+                check(lib.segmi_bn_finalize_from_parts(part.data_ptr(), nparts, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
+                                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                       ws.data_ptr(), nws, st), "bn_finalize_from_parts")
+            else:
+                one = torch.empty(3 * C, device=dev, dtype=torch.float32)
+                check(lib.segmi_bn_stats_from_parts(part.data_ptr(), nparts, C, one.data_ptr(), ws.data_ptr(), nws, st), "bn_stats_from_parts")
+                allp, nall = sync.gather_stats(one)
+                count = None
+                check(lib.segmi_bn_finalize(allp.data_ptr(), nall, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
+                                            mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            coef.data_ptr() + 16 * C, st), "bn_finalize")
+        elif training and sync is None:
             if rows <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
             nws = lib.segmi_bn_stats_workspace(rows, C)
@@ -858,14 +981,17 @@ class _BatchNormActFn(torch.autograd.Function):
                                          ld_of(dres) if dres is not None else 0, st), "bn_bwd_apply")
         if want_res and not relu:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, residual=None, training=True,
                    momentum=0.1, eps=1e-5, relu=False, sync=None):
-    """BN (batch or running statistics) -> (+ residual) -> (ReLU), one fused apply pass."""
+    """BN (batch or running statistics) -> (+ residual) -> (ReLU), one fused apply pass.  Batch statistics come from the
+    producing convolution's epilogue when it emitted them for this tensor (see _BN_FUSE), else from a pass over x."""
+    _note_bn_consumer(x, training)
+    pstats = _producer_stats(x, x.shape[1]) if (training and x.dim() == 4) else None
     return _BatchNormActFn.apply(x, gamma, beta, residual, running_mean, running_var, num_batches_tracked,
-                                 bool(training), float(momentum), float(eps), bool(relu), sync)
+                                 bool(training), float(momentum), float(eps), bool(relu), sync, pstats)
 
 
 # --------------------------------------------------------------------------- SyncBN layers that share their collectives
@@ -877,9 +1003,16 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracke
 # before the ONE all-reduce.  Same kernels, same operands, same summation order as the one-layer path: results are bit-identical
 # to it (tests/test_distributed_gpu.py); 122 -> 108 collectives per PSPNet-R50 step (reference: one master/slave exchange per
 # layer and direction, utils/sync_batchnorm/batchnorm.py:105-126).
-def _bn_member_stats(x):
+def _bn_member_stats(x, pstats=None):
     N, C, H, W = x.shape
     rows, dev = N * H * W, x.device
+    if pstats is not None:
+        nws = lib.segmi_bn_parts_workspace(pstats[1], C)
+        ws = workspace(nws, dev)
+        part = torch.empty(3 * C, device=dev, dtype=torch.float32)
+        check(lib.segmi_bn_stats_from_parts(pstats[0].data_ptr(), pstats[1], C, part.data_ptr(), ws.data_ptr(), nws, _stream()), "bn_stats_from_parts")
+        _BN_FUSE["consumed"] += 1
+        return part
     nws = lib.segmi_bn_stats_workspace(rows, C)
     ws = workspace(nws, dev)
     part = torch.empty(3 * C, device=dev, dtype=torch.float32)
@@ -945,15 +1078,15 @@ class _SyncBNGroupFn(torch.autograd.Function):
         for x in xs:
             if x.shape[1] & 3:
                 raise SegmiError("batch_norm: channel count must be a multiple of 4 (got %d)" % x.shape[1])
-        parts = [_bn_member_stats(x) for x in xs]
+        parts = [_bn_member_stats(x, h[4] if len(h) > 4 else None) for x, h in zip(xs, hyper)]
         gathered = hyper[0][3].gather_stats_many(parts)
         coefs, ys = [], []
-        for x, (_, g, b, rm, rv, nbt), (eps, mom, relu, sync), (pall, npart) in zip(xs, mem, hyper, gathered):
+        for x, (_, g, b, rm, rv, nbt), (eps, mom, relu, sync, *_), (pall, npart) in zip(xs, mem, hyper, gathered):
             coef = _bn_member_finalize(pall, npart, x.shape[1], g, b, rm, rv, nbt, eps, mom, sync.clamp_mode, x.device)
             coefs.append(coef)
             ys.append(_bn_member_apply(x, None, coef, relu))
         ctx.save_for_backward(*xs, *coefs)
-        ctx.hyper = hyper
+        ctx.hyper = [h[:4] for h in hyper]
         return tuple(ys)
 
     @staticmethod
@@ -984,15 +1117,15 @@ class _SyncBNResidualTailFn(torch.autograd.Function):
         xm, xp = to_nhwc(mem[0][0], "sync_bn_tail"), to_nhwc(mem[1][0], "sync_bn_tail")
         if xm.shape != xp.shape or (xm.shape[1] & 3):
             raise SegmiError("sync_bn_tail: main and projection branch must have the same shape, channels a multiple of 4")
-        parts = [_bn_member_stats(xm), _bn_member_stats(xp)]
+        parts = [_bn_member_stats(xm, hyper[0][3] if len(hyper[0]) > 3 else None), _bn_member_stats(xp, hyper[1][3] if len(hyper[1]) > 3 else None)]
         gathered = hyper[0][2].gather_stats_many(parts)
         coefs = []
-        for x, (_, g, b, rm, rv, nbt), (eps, mom, sync), (pall, npart) in zip((xm, xp), mem, hyper, gathered):
+        for x, (_, g, b, rm, rv, nbt), (eps, mom, sync, *_), (pall, npart) in zip((xm, xp), mem, hyper, gathered):
             coefs.append(_bn_member_finalize(pall, npart, x.shape[1], g, b, rm, rv, nbt, eps, mom, sync.clamp_mode, x.device))
         ident = _bn_member_apply(xp, None, coefs[1], False)
         y = _bn_member_apply(xm, ident, coefs[0], True)
         ctx.save_for_backward(xm, xp, y, coefs[0], coefs[1])
-        ctx.hyper = hyper
+        ctx.hyper = [h[:3] for h in hyper]
         return y
 
     @staticmethod
@@ -1027,7 +1160,9 @@ def sync_batch_norm_group(xs, bns, relu=True):
     and one all-reduce (backward); falls back to layer-by-layer calls when the layers are not synchronized."""
     if not sync_groupable(bns):
         return [bn(x, relu=relu) for x, bn in zip(xs, bns)]
-    hyper = [(float(b.eps), float(b.momentum), bool(relu), b.sync) for b in bns]
+    for x in xs:
+        _note_bn_consumer(x, True)
+    hyper = [(float(b.eps), float(b.momentum), bool(relu), b.sync, _producer_stats(x, x.shape[1])) for x, b in zip(xs, bns)]
     args = []
     for x, b in zip(xs, bns):
         args += [x, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked]
@@ -1039,7 +1174,9 @@ def sync_batch_norm_residual_tail(x_main, bn_main, x_proj, bn_proj):
     are not synchronized (the caller then takes the one-layer path)."""
     if not sync_groupable([bn_main, bn_proj]):
         return None
-    hyper = [(float(b.eps), float(b.momentum), b.sync) for b in (bn_main, bn_proj)]
+    for x in (x_main, x_proj):
+        _note_bn_consumer(x, True)
+    hyper = [(float(b.eps), float(b.momentum), b.sync, _producer_stats(x, x.shape[1])) for x, b in ((x_main, bn_main), (x_proj, bn_proj))]
     args = []
     for x, b in ((x_main, bn_main), (x_proj, bn_proj)):
         args += [x, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked]
@@ -1250,7 +1387,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         tp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in Ts])
         check(lib.segmi_pyramid_up_fwd(tp, N, H, W, K, nl, bh, bw, y.data_ptr(), ld_of(y), (ws.data_ptr() + 15) & ~15, nws, st), "pyramid_up_fwd")
         d = ConvDesc(N, H, W, Cx, K, 3, 3, H, W, 1, 1, 1, ld_of(x), ld_of(y))
-        v = _conv_fwd(d, Cx, x, fx, None, y, accumulate=1, keep_v=ctx.needs_input_grad[1])             # accumulate onto the pyramid part
+        v = _conv_fwd(d, Cx, x, fx, None, y, accumulate=1, keep_v=ctx.needs_input_grad[1] and _FWD["grad"])             # accumulate onto the pyramid part
         ctx.has_v = v is not None
         ctx.save_for_backward(x, weight, *ps, *([v] if v is not None else []))
         ctx.geom = (N, Cx, H, W, K, Ct, tuple(cs), tuple(bins))
@@ -1265,7 +1402,10 @@ class _PyramidBottleneckFn(torch.autograd.Function):
         dev, st = x.device, _stream()
         nl = len(ps)
         bh, bw = (ctypes.c_int * nl)(*[b[0] for b in bins]), (ctypes.c_int * nl)(*[b[1] for b in bins])
-        dwb = torch.empty((K, Ct, 3, 3), device=dev, dtype=torch.float32, memory_format=torch.channels_last)   # KRSC memory, filled slice by slice
+        # KRSC memory, filled slice by slice; under a data-parallel reducer this is the parameter's slot in the all-reduce bucket
+        dwb = _take_grad_slot(weight) if (_GRAD_SLOTS and ctx.needs_input_grad[1]) else None
+        if dwb is None:
+            dwb = torch.empty((K, Ct, 3, 3), device=dev, dtype=torch.float32, memory_format=torch.channels_last)
         fx = torch.empty(K * 9 * Cx, device=dev, dtype=torch.float32)
         check(lib.segmi_filter_slice(weight.data_ptr(), K, 9, Ct, 0, Cx, 0, fx.data_ptr(), st), "filter_slice")
         # ---- feature channels: plain dgrad / wgrad of the 3x3 convolution over Cx channels
@@ -1317,6 +1457,7 @@ class _PyramidBottleneckFn(torch.autograd.Function):
 def pyramid_bottleneck_conv(x, pyramid, weight):
     """F.conv2d(torch.cat([x] + [F.interpolate(p, x.shape[2:], mode='bilinear', align_corners=True) for p in pyramid], 1), weight,
     padding=1) without building the upsampled maps or the concatenation (see _PyramidBottleneckFn)."""
+    _FWD["grad"] = torch.is_grad_enabled()
     return _PyramidBottleneckFn.apply(x, weight, *pyramid)
 
 

@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 6
+    assert lib.segmi_abi_version() == 7
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
@@ -359,3 +359,21 @@ def test_synth_loader_shards_batches_by_rank():
         assert not torch.equal(r0[i][0], r1[i][0])
         assert torch.equal(r0[i][0], single[2 * i][0]) and torch.equal(r1[i][1], single[2 * i + 1][1])
     assert Synth(**kw).world == 1 and Synth(**kw).rank == 0          # no process group: the whole sequence
+
+
+def test_bn_stats_epilogue_planning():
+    """segmi_conv2d_fwd_stats_parts (no launch): one Welford partial per row tile of the forward kernel — 128-row tiles, 64-row
+    tiles for problems that would not fill the chip — and 0 where the launch has no statistics epilogue (K % 4, split reduction of
+    tiny outputs); more than 512 partials need the two-level merge workspace."""
+    from segmi import lib
+    from segmi._lib import ConvDesc
+    d = ConvDesc(8, 64, 64, 512, 2048, 1, 1, 64, 64, 1, 0, 1, 512, 2048)
+    assert lib.segmi_conv2d_fwd_stats_parts(d) == 8 * 64 * 64 // 128
+    d = ConvDesc(8, 32, 32, 728, 728, 1, 1, 32, 32, 1, 0, 1, 728, 728)          # Xception middle flow: 64-row tiles
+    assert lib.segmi_conv2d_fwd_stats_parts(d) == 8 * 32 * 32 // 64
+    d = ConvDesc(8, 6, 6, 2048, 512, 1, 1, 6, 6, 1, 0, 1, 2048, 512)            # pyramid stage: split reduction
+    assert lib.segmi_conv2d_fwd_stats_parts(d) == 0
+    d = ConvDesc(8, 64, 64, 512, 21, 1, 1, 64, 64, 1, 0, 1, 512, 24)            # classifier: K % 4
+    assert lib.segmi_conv2d_fwd_stats_parts(d) == 0
+    assert lib.segmi_bn_parts_workspace(256, 2048) == 16
+    assert lib.segmi_bn_parts_workspace(1024, 256) == 16 * 3 * 256 * 4 + 16

@@ -392,3 +392,108 @@ def test_syncbn_batched_collectives_equal_the_layerwise_path(cuda):
             assert torch.equal(a["grads"][k], gb), k
         for k, vb in b["running"].items():
             assert torch.equal(a["running"][k], vb), k
+
+
+def test_reducer_waits_for_side_stream_filter_gradients(cuda):
+    """a filter gradient launched on the wgrad side stream that is NOT the reducer's slot alias (slot already
+    handed out, optimizer.zero_grad(set_to_none=True)) is copied into the bucket by the post-accumulate hook — only after the
+    compute stream has joined the side stream.  PSPNet-R50 at a feature-map size where the bottleneck's filter gradient (2048 ->
+    512, 3x3) outlasts the small pyramid kernels that follow it on the compute stream; both the slot path (the factored
+    bottleneck now writes straight into its slot) and the forced copy path must equal the in-order, reducer-free run bit for bit."""
+    import copy
+    from segmi import ops
+    from segmi.distributed import GradAllReducer
+    from utils.losses import CrossEntropyLoss2d
+    net = _build(5, 3, cuda)
+    ref = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 256, 256, generator=g).to(cuda)
+    t = torch.randint(0, 5, (4, 256, 256), generator=g).to(cuda)
+    crit = CrossEntropyLoss2d()
+
+    def run(m):
+        out, aux = m(x)
+        (crit(out, t) + 0.4 * crit(aux, t)).backward()
+
+    prev = ops.get_wgrad_stream()["on"]
+    ops.set_wgrad_stream(False)
+    run(ref)
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    red = GradAllReducer(net.parameters(), bucket_bytes=64 << 20)
+    bott = net.master_branch[0].bottleneck[0].weight
+    try:
+        ops.set_wgrad_stream(True)
+        for mode in ("slots", "copies", "slots"):
+            red.zero_grad()
+            if mode == "copies":
+                for p in red._slot_params:              # every slot "already handed out": wgrad kernels fill fresh tensors
+                    ops._GRAD_SLOTS[id(p)][1] = True
+            before = dict(red.counters)
+            run(net)
+            red.finish()
+            torch.cuda.synchronize()
+            if mode == "slots":
+                assert bott.grad is red._where[id(bott)][1]
+                assert red.counters["adopted"] - before["adopted"] >= 50          # incl. the factored bottleneck's filter
+            else:
+                assert red.counters["copied"] - before["copied"] >= 50
+            for k, p in net.named_parameters():
+                assert torch.equal(p.grad, want[k]), (mode, k)
+    finally:
+        ops.set_wgrad_stream(prev)
+        red.remove()
+
+
+def test_side_stream_stays_in_order_for_reused_filters_and_foreign_hooks(cuda):
+    """a filter used twice in one graph (the engine sums both gradients on the compute stream) and a
+    parameter with a tensor hook (it reads dW during backward) keep their filter gradient off the side stream."""
+    from segmi import nn as snn, ops
+    torch.manual_seed(0)
+    conv = snn.Conv2d(64, 64, 3, padding=1, bias=False).to(cuda)
+    other = snn.Conv2d(64, 64, 1, bias=False).to(cuda)
+    x1, x2 = torch.randn(2, 64, 48, 48, device=cuda), torch.randn(2, 64, 48, 48, device=cuda)
+
+    def run():
+        for p in (conv.weight, other.weight):
+            p.grad = None
+        (conv(x1).square().mean() + conv(other(x2)).square().mean()).backward()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone(), other.weight.grad.clone()
+
+    prev = ops.get_wgrad_stream()["on"]
+    try:
+        ops.set_wgrad_stream(False)
+        want = run()
+        ops.set_wgrad_stream(True)
+        c0 = ops.get_wgrad_stream()
+        got = run()
+        c1 = ops.get_wgrad_stream()
+        assert c1["in_order_reuse"] == c0["in_order_reuse"] + 1 and c1["launches"] >= c0["launches"] + 2
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        seen = []
+        h = other.weight.register_hook(lambda g: seen.append(float(g.abs().sum())))
+        got = run()
+        h.remove()
+        c2 = ops.get_wgrad_stream()
+        assert c2["in_order_hooks"] == c1["in_order_hooks"] + 1
+        assert seen == [float(want[1].abs().sum())] and torch.equal(got[1], want[1])
+    finally:
+        ops.set_wgrad_stream(prev)
+
+
+def test_grad_slots_do_not_outlive_their_parameters(cuda):
+    """slots are verified by identity — an entry whose parameter died is never handed to a new tensor that
+    happens to reuse its id, and a second reducer over the same parameters replaces the first one's slots explicitly."""
+    from segmi import nn as snn, ops
+    from segmi.distributed import GradAllReducer
+    conv = snn.Conv2d(16, 16, 3, padding=1, bias=False).to(cuda)
+    red = GradAllReducer(conv.parameters())
+    key = id(conv.weight)
+    assert key in ops._GRAD_SLOTS and ops._GRAD_SLOTS[key][2]() is conv.weight
+    stale = ops._GRAD_SLOTS[key]
+    red.remove()
+    assert key not in ops._GRAD_SLOTS
+    # a stale entry (as a dropped reducer would have left it) under the id of a DIFFERENT live tensor is rejected and removed
+    w2 = torch.nn.Parameter(torch.randn(16, 16, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last))
+    ops._GRAD_SLOTS[id(w2)] = stale
+    assert ops._take_grad_slot(w2) is None and id(w2) not in ops._GRAD_SLOTS

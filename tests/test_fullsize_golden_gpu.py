@@ -9,23 +9,24 @@ numbers of SURVEY.md §7 (pytest -s, or the captured stdout of a failure):
     mismatch count of the full-resolution masks, the largest oracle margin among mismatching pixels, max|dlogit|
 
 and asserts
-  * logits:  max|dlogit| <= 1e-3 * max|logit|          (strided sample of the main head; aux head for PSPNet)
-             — or, where the fp32 reference ITSELF is further than 5e-4 * max|logit| from the fp64 oracle (cfg3: DeepLab-R101 with
-             batch statistics at batch 2 amplifies fp32 rounding to 8.4e-4; two independent fp32 evaluations then differ by
-             ~sqrt(2) of that and no second fp32 implementation can meet 1e-3), the noise-floor criterion of
-             tests/test_pspnet_gpu.py: the HIP logits are at most 2x as far from the fp64 oracle as the reference's own are.
-             Both distances are printed for every config.
+  * logits:  max|dlogit| <= 1e-3 * max|logit| for EVERY config (strided sample of the main head; aux head for PSPNet); where the
+             fp32 reference itself is further than 5e-4 * max|logit| from the fp64 oracle (cfg3), additionally the noise-floor
+             criterion of tests/test_pspnet_gpu.py: the HIP logits are at most 2x as far from the fp64 oracle as the reference's
+             own are.  Both distances are printed for every config.
   * masks :  0 mismatches among pixels whose oracle top-2 margin exceeds 2*max|dlogit| — bit-identity on EVERY pixel is not
              attainable between two fp32 summation orders (torch-CPU NCHW vs channels_last already differ on 341 of 1 M
              pixels); every remaining mismatch is a numerical tie, and the count is printed
   * loss  :  |d| < 1e-4
-  * gradients (BN batch statistics => ill conditioned): per-tensor norm within 10 %, median within 1 %; AND the
-             stored per-tensor digests (64 strided samples + the first 8 values of every parameter gradient, oracle/gen_golden.py
-             `_grad_digest`): relative L2 distance of the sampled values per tensor, median <= 10 %, max <= 50 % — a permuted,
-             sign-flipped or zeroed slice with the right norm scores 141 % / 200 % / 100 % and fails; the rounding noise of two
-             fp32 evaluations of a batch-statistics network does not (first hardware run, both conv algorithms alike: median
-             2.1-2.5 % / max 3.7-4.2 % for cfg2, cfg4, cfg5; median 6.2 % / max 14.3 % for the 101-layer cfg3).  The measured
-             values are printed and recorded in gpurun_out/audit.json.
+  * gradients (BN batch statistics => ill conditioned), pinned to the MEASURED rounding-noise floor of each config:
+             the fixtures carry the fp64 oracle's gradient digests (`grads_f64`: 64 strided samples + the first 8 values of every
+             parameter gradient, oracle/gen_golden_fullsize.py `add_f64_grads`) and `ref_grad_err_f64` = the REAL reference's own
+             fp32 digests' relative L2 distance from them (median / max over tensors: cfg2 1.85e-2 / 2.9e-2, cfg3 4.4e-2 / 7.0e-2,
+             cfg4 1.9e-2 / 2.7e-2, cfg5 1.6e-2 / 2.9e-2).  The HIP path's distance from the SAME fp64 digests must be
+             median <= 1.5 x and max <= 2 x the reference's own: a second fp32 evaluation cannot be expected closer to fp64 than
+             the first, and anything systematically wrong (a dropped Winograd sub-grid, a lost split-K partial, 5 % of a tensor's
+             energy corrupted) lands far above it.  Per-tensor norms: median within 1 %, max within 3 % of the reference's.
+             The distance from the reference's fp32 digests (~ sqrt(2) x the floor) is printed as well; everything is recorded in
+             gpurun_out/audit.json.
 Batches: cfg2 8 (= BASELINE), cfg3 the batch stored in the fixture (16 = BASELINE when the build container could hold it), cfg4 one
 shard of 4 (= BASELINE per GPU), cfg5 8 (= BASELINE per GPU); the test id carries the batch.
 The same file is the acceptance test of any alternative conv arithmetic (SEGMI_CONV_MATH): identical tolerances.
@@ -86,7 +87,7 @@ def run_fullsize_audit(name, device):
         res["max_abs_daux"] = (aux.detach()[:, :, ::2 * s, ::2 * s].cpu() - rec["aux"]).abs().max().item()
         res["aux_absmax"] = rec["aux"].abs().max().item()
     named = dict(m.named_parameters())
-    rel, srel = [], []
+    rel, srel, frel = [], [], []
     for k, dg in rec["grads"].items():
         g = named[k].grad.detach().reshape(-1)
         rel.append((abs(g.norm().item() - dg["norm"]) / (dg["norm"] + 1e-30), k, dg["norm"]))
@@ -94,23 +95,30 @@ def run_fullsize_audit(name, device):
         got = torch.cat([g[::step][:64], g[:8]]).cpu().double()
         ref = torch.cat([dg["sample"], dg["head"]]).double()
         srel.append(((got - ref).norm().item() / (ref.norm().item() + 1e-30), k, dg["norm"]))
+        d64 = rec["grads_f64"][k]
+        r64 = torch.cat([d64["sample"], d64["head"]]).double()
+        frel.append(((got - r64).norm().item() / (r64.norm().item() + 1e-300), k, d64["norm"]))
     res["grad_norm_rel_err_median"] = statistics.median(r[0] for r in rel)
     floor = 1e-5 * max(r[2] for r in rel)        # analytically-zero gradients (BN bias in front of a batch-stat BN) are rounding noise
     res["grad_norm_rel_err_max"], res["grad_norm_worst"] = max(((r[0], r[1]) for r in rel if r[2] > floor), default=(0.0, ""))
     res["grad_sample_rel_err_median"] = statistics.median(r[0] for r in srel)
     res["grad_sample_rel_err_max"], res["grad_sample_worst"] = max(((r[0], r[1]) for r in srel if r[2] > floor), default=(0.0, ""))
+    # distance from the fp64 oracle's digests, over the same "live" tensors as the fixture's own floor (gen_golden_fullsize.add_f64_grads)
+    top = max(r[2] for r in frel)
+    live = [r for r in frel if r[2] > 1e-5 * top]
+    res["grad_f64_rel_err_median"] = statistics.median(r[0] for r in live)
+    res["grad_f64_rel_err_max"], res["grad_f64_worst"] = max((r[0], r[1]) for r in live)
+    res["ref_grad_f64_rel_err_median"] = rec["ref_grad_err_f64"]["median"]
+    res["ref_grad_f64_rel_err_max"] = rec["ref_grad_err_f64"]["max"]
     res["batch"] = N
     sd_after = m.state_dict()
     res["running_ok"] = all(torch.allclose(sd_after[k].cpu().float(), v.float(), rtol=1e-4, atol=1e-5) for k, v in rec["running"].items())
     return res
 
 
-def _fixture_batch(name):
-    # (the id is computed at collection time from the fixture header: the batch is part of the numerics under batch-statistics BN)
-    try:
-        return torch.load(os.path.join(GOLD, "full_%s.pt" % name), weights_only=False)["input_shape"][0]
-    except Exception:
-        return 0
+# batch of every fixture (part of the numerics under batch-statistics BN, so it is in the test id); kept here so that collecting
+# this module does not load 60 MB of fixtures — the test asserts it against the fixture header
+FIXTURE_BATCH = {"cfg2": 8, "cfg3": 16, "cfg4": 4, "cfg5": 8}
 
 
 def audit_line(r, algo):
@@ -118,11 +126,14 @@ def audit_line(r, algo):
     return ("[fullsize %s batch %d, conv math %s, %s] pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
             "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
             "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s) | "
-            "grad-sample rel-L2 median %.2e max %.2e (%s)"
+            "grad-sample rel-L2 from the reference fp32 median %.2e max %.2e (%s) | from the fp64 oracle: HIP median %.2e max %.2e (%s), "
+            "reference fp32 median %.2e max %.2e"
             % (r["config"], r["batch"], ops.get_conv_math(), algo, r["pixels"], r["mismatches"], r["max_margin_among_mismatches"],
                r["max_abs_dlogit"], r["logit_absmax"], r["hip_err_f64"], r["ref_err_f64"], r["mismatches_outside_margin"],
                r["near_ties_in_oracle(margin<2d)"], r["loss"], r["loss_ref"], r["grad_norm_rel_err_median"], r["grad_norm_rel_err_max"],
-               r["grad_norm_worst"], r["grad_sample_rel_err_median"], r["grad_sample_rel_err_max"], r["grad_sample_worst"]))
+               r["grad_norm_worst"], r["grad_sample_rel_err_median"], r["grad_sample_rel_err_max"], r["grad_sample_worst"],
+               r["grad_f64_rel_err_median"], r["grad_f64_rel_err_max"], r["grad_f64_worst"], r["ref_grad_f64_rel_err_median"],
+               r["ref_grad_f64_rel_err_max"]))
 
 
 def record_audit(r, algo):
@@ -141,18 +152,21 @@ def record_audit(r, algo):
     return audit_line(r, algo)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"], ids=lambda n: "%s-batch%d" % (n, _fixture_batch(n)))
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"], ids=lambda n: "%s-batch%d" % (n, FIXTURE_BATCH[n]))
 def test_fullsize_step_matches_reference_golden(cuda, name, conv_algorithm):
     r = run_fullsize_audit(name, cuda)
     print("\n" + record_audit(r, conv_algorithm or "default"))
-    if r["ref_err_f64"] <= 5e-4 * r["logit_absmax"]:
-        assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
-    else:                                     # the reference's own fp32 rounding noise is already ~1e-3 of the logit scale here
+    assert r["batch"] == FIXTURE_BATCH[name]
+    assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
+    if r["ref_err_f64"] > 5e-4 * r["logit_absmax"]:
+        # additionally, where the reference's own fp32 rounding noise is a sizeable part of that bar (cfg3, parity unpinned for the
+        # restated torchvision ResNet-v1.5 backbone): the HIP logits are no further from the fp64 oracle than twice the reference's
         assert r["hip_err_f64"] <= 2.0 * r["ref_err_f64"] and r["max_abs_dlogit"] <= 3.0 * r["ref_err_f64"], r
     assert r["mismatches_outside_margin"] == 0, r
     if "max_abs_daux" in r:
         assert r["max_abs_daux"] <= 1e-3 * r["aux_absmax"], r
     assert abs(r["loss"] - r["loss_ref"]) < 1e-4, r
-    assert r["grad_norm_rel_err_median"] <= 1e-2 and r["grad_norm_rel_err_max"] <= 0.1, r
-    assert r["grad_sample_rel_err_median"] <= 0.1 and r["grad_sample_rel_err_max"] <= 0.5, r
+    assert r["grad_norm_rel_err_median"] <= 1e-2 and r["grad_norm_rel_err_max"] <= 3e-2, r
+    assert r["grad_f64_rel_err_median"] <= 1.5 * r["ref_grad_f64_rel_err_median"], r
+    assert r["grad_f64_rel_err_max"] <= 2.0 * r["ref_grad_f64_rel_err_max"], r
     assert r["running_ok"], r

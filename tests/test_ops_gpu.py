@@ -848,3 +848,149 @@ def test_cross_entropy_fused_with_final_upsample(cuda, case):
     assert abs(val2.item() - val.item()) <= 1e-6 * abs(val.item()) + 1e-7
     assert (ld2.grad - ld.grad).abs().max().item() <= 2e-5 * scale + 1e-9
     assert ops.upsample_source(up2.detach() + 0) is None and ops.upsample_source(up2.detach()) is None     # new tensors carry no tag
+
+
+def test_winograd_keeps_no_transformed_input_under_no_grad(cuda):
+    """validation under torch.no_grad() with trainable weights must not allocate the 4x-size Winograd V buffer
+    that only a filter gradient would use."""
+    prev = ops.get_conv_winograd()
+    ops.set_conv_winograd(True, wgrad=True, keep_v=True)
+    try:
+        w = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last) * 0.02)
+        x = ops.to_nhwc(torch.randn(4, 256, 64, 64, device=cuda))
+        xbytes = x.numel() * 4
+        ops.conv2d(x, w, padding=1)                     # warm the workspace
+        torch.cuda.synchronize()
+
+        def peak(fn):
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            y = fn()
+            torch.cuda.synchronize()
+            return torch.cuda.max_memory_allocated() - base, y
+
+        with torch.no_grad():
+            p_eval, _ = peak(lambda: ops.conv2d(x, w, padding=1))
+        p_train, y = peak(lambda: ops.conv2d(x, w, padding=1))
+        assert p_eval < 2 * xbytes, (p_eval, xbytes)                 # the output only
+        assert p_train >= 4 * xbytes, (p_train, xbytes)              # output + kept V (4x the input)
+        del y
+    finally:
+        ops.set_conv_winograd(prev["on"], prev["min_channels"], prev["min_subgrid"], prev["wgrad"], prev["keep_v"])
+
+
+STATS_CASES = [
+    # N, C, H, W, K, R, stride, pad, dil, bias      (row tiles: full, ragged last tile, 64-row tiles, 128x32 tiles, > 512 partials)
+    (8, 64, 32, 32, 256, 1, 1, 0, 1, False),
+    (2, 32, 17, 19, 48, 3, 1, 1, 1, False),
+    (2, 128, 24, 24, 728, 1, 1, 0, 1, False),
+    (3, 64, 15, 15, 32, 1, 1, 0, 1, True),
+    (2, 16, 200, 200, 64, 3, 1, 1, 1, False),
+    (2, 64, 33, 33, 128, 3, 2, 1, 1, False),
+    (1, 256, 40, 40, 136, 3, 1, 2, 2, False),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_bn_stats_epilogue_matches_the_statistics_pass(cuda, case):
+    """segmi_conv2d_fwd_stats: y is bit-identical to segmi_conv2d_fwd, and the Welford partials its epilogue writes per row tile
+    merge (segmi_bn_stats_from_parts, one or two levels) to the packed {count, mean, M2} that segmi_bn_stats computes from y:
+    counts exactly, mean / M2 to fp32 rounding of a different merge tree; segmi_bn_finalize_from_parts == segmi_bn_stats_finalize
+    to the same accuracy (reference: nn.BatchNorm2d batch statistics, models/resnet.py:105-121)."""
+    from segmi import ops
+    from segmi._lib import ConvDesc, lib
+    N, C, H, W, K, R, stride, pad, dil, bias = case
+    g = torch.Generator().manual_seed(5)
+    x = ops.to_nhwc((torch.randn(N, C, H, W, generator=g) + 0.3).to(cuda))
+    w = (torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(cuda).contiguous(memory_format=torch.channels_last)
+    b = (torch.randn(K, generator=g) * 2).to(cuda) if bias else None
+    P, Q = ops.conv_out_size(H, R, stride, pad, dil), ops.conv_out_size(W, R, stride, pad, dil)
+    st = torch.cuda.current_stream().cuda_stream
+    y0, y1 = ops.empty_nhwc(N, K, P, Q, cuda), ops.empty_nhwc(N, K, P, Q, cuda)
+    d = ConvDesc(N, H, W, C, K, R, R, P, Q, stride, pad, dil, ops.ld_of(x), ops.ld_of(y0))
+    parts = lib.segmi_conv2d_fwd_stats_parts(d)
+    assert parts > 0
+    wf = w.permute(0, 2, 3, 1).contiguous() if R > 1 else w.reshape(K, C).contiguous()
+    assert lib.segmi_conv2d_fwd(d, x.data_ptr(), wf.data_ptr(), b.data_ptr() if bias else None, y0.data_ptr(), 0, None, 0, st) == 0
+    part = torch.full((parts * 3 * K,), float("nan"), device=cuda)
+    assert lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), wf.data_ptr(), b.data_ptr() if bias else None, y1.data_ptr(), part.data_ptr(), st) == 0
+    assert torch.equal(y0, y1)
+    assert not torch.isnan(part).any()
+    rows = N * P * Q
+    assert float(part.view(parts, 3, K)[:, 0].sum(0).min()) == rows == float(part.view(parts, 3, K)[:, 0].sum(0).max())
+    nws = max(lib.segmi_bn_stats_workspace(rows, K), lib.segmi_bn_parts_workspace(parts, K))
+    ws = torch.empty(nws + 16, dtype=torch.uint8, device=cuda)
+    ref, got = torch.empty(3 * K, device=cuda), torch.empty(3 * K, device=cuda)
+    assert lib.segmi_bn_stats(y0.data_ptr(), ops.ld_of(y0), rows, K, ref.data_ptr(), ws.data_ptr(), nws, st) == 0
+    assert lib.segmi_bn_stats_from_parts(part.data_ptr(), parts, K, got.data_ptr(), ws.data_ptr(), nws, st) == 0
+    ref, got = ref.view(3, K).cpu().double(), got.view(3, K).cpu().double()
+    assert torch.equal(ref[0], got[0]) and float(ref[0][0]) == rows
+    y64 = y0.detach().cpu().double().permute(0, 2, 3, 1).reshape(rows, K)
+    mean64, m264 = y64.mean(0), ((y64 - y64.mean(0)) ** 2).sum(0)
+    scale = y64.abs().max().item()
+    # both paths against the fp64 statistics: the fused partials must be as good as the streaming pass
+    for name, t in (("statistics pass", ref), ("conv epilogue", got)):
+        assert (t[1] - mean64).abs().max().item() <= 2e-6 * scale, name
+        assert ((t[2] - m264).abs() / m264).max().item() <= 2e-5, name
+    gamma, beta = (torch.rand(K, generator=g) + 0.5).to(cuda), torch.randn(K, generator=g).to(cuda)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.full((K,), 0.25, device=cuda), torch.full((K,), 2.0, device=cuda)
+        nbt = torch.zeros((), dtype=torch.int64, device=cuda)
+        coef = torch.empty(4, K, device=cuda)
+        ptrs = [coef[i].data_ptr() for i in range(4)]
+        if fused:
+            assert lib.segmi_bn_finalize_from_parts(part.data_ptr(), parts, K, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 0, rm.data_ptr(),
+                                                    rv.data_ptr(), nbt.data_ptr(), *ptrs, ws.data_ptr(), nws, st) == 0
+        else:
+            assert lib.segmi_bn_stats_finalize(y0.data_ptr(), ops.ld_of(y0), rows, K, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 0,
+                                               rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), *ptrs, ws.data_ptr(), nws, st) == 0
+        outs.append((coef.cpu(), rm.cpu(), rv.cpu(), int(nbt.item())))
+    assert outs[0][3] == outs[1][3] == 1
+    for a, c in zip(outs[0][:3], outs[1][:3]):
+        torch.testing.assert_close(a, c, rtol=2e-5, atol=2e-6 * scale)
+
+
+def test_conv_to_batchnorm_pairing_is_discovered_and_used(cuda):
+    """The conv -> BN pairing is found at run time (the BN layer marks the module that produced its input) and from the second
+    step on the BN statistics come from the convolution's epilogue: same outputs and gradients as the separate statistics pass to
+    fp32 rounding, `consumed` counts the layers, eval mode and torch.no_grad() switch it off again."""
+    import copy
+    import models
+    from segmi import ops
+    torch.manual_seed(3)
+    net = models.UNet(3).to(cuda).train()
+    ref = copy.deepcopy(net)
+    x = torch.randn(2, 3, 64, 64, device=cuda)
+    t = torch.randint(0, 3, (2, 64, 64), device=cuda)
+    from utils.losses import CrossEntropyLoss2d
+    crit = CrossEntropyLoss2d()
+    prev = ops.get_conv_bn_stats()["on"]
+    try:
+        ops.set_conv_bn_stats(False)
+        crit(ref(x), t).backward()
+        ops.set_conv_bn_stats(True)
+        crit(net(x), t).backward()                              # step 1: discovery only (no statistics emitted yet)
+        c1 = ops.get_conv_bn_stats()
+        marked = [m for m in net.modules() if getattr(m, "_bn_consumer", False)]
+        assert len(marked) >= 18, len(marked)
+        for p in net.parameters():
+            p.grad = None
+        out = net(x)
+        crit(out, t).backward()                                 # step 2: statistics from the conv epilogues
+        c2 = ops.get_conv_bn_stats()
+        assert c2["consumed"] - c1["consumed"] >= 10 and c2["emitted"] - c1["emitted"] >= c2["consumed"] - c1["consumed"]
+        with torch.no_grad():
+            oref = ref(x)
+        assert (out.detach() - oref).abs().max().item() <= 2e-5 * oref.abs().max().item()
+        errs = []
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            errs.append(((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)).item())
+        assert max(errs) <= 1e-3 and sorted(errs)[len(errs) // 2] <= 1e-4, (max(errs), sorted(errs)[len(errs) // 2])
+        net.eval()
+        with torch.no_grad():
+            net(x)
+        c3 = ops.get_conv_bn_stats()
+        assert c3["emitted"] == c2["emitted"] and not any(getattr(m, "_bn_consumer", False) for m in net.modules())
+    finally:
+        ops.set_conv_bn_stats(prev)

@@ -224,5 +224,33 @@ r3j)
 r3k)
   ( timeout 200 python -m pytest tests/test_ops_gpu.py -k "lovasz" -m gpu -q -p no:cacheprovider 2>&1 | tail -3 ) > gpurun_out/r3k_tests.log; cat gpurun_out/r3k_tests.log
   ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r3k_smoke.log; cut -c1-220 gpurun_out/r3k_smoke.log ;;
+r4a)
+  # round 4, call 1: kernel-level evidence for the four other BASELINE configs (rocprofv3 kernel stats, filter gradients in order so
+  # durations are per-kernel), the HBM-bound call table of each, and the un-profiled bench line of each
+  for c in cfg1 cfg3 cfg4 cfg5; do
+    rm -rf gpurun_out/prof_$c
+    ( SEGMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$c -o r -- python bench.py --config $c --steps 7 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r4a_prof_$c.log
+    find gpurun_out/prof_$c -name "*kernel_trace*" -delete
+    f=$(find gpurun_out/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4a_${c}_kernel_stats.csv
+    rm -rf gpurun_out/prof_$c
+    ( timeout 300 python tools/membound_ops.py $c 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4a_${c}_membound_ops.txt
+    ( timeout 400 python bench.py --config $c --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4a_bench_$c.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4a_bench_$c.log').read()); r=d['roofline']; print('$c', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1
+    head -8 gpurun_out/r4a_${c}_kernel_stats.csv | cut -c1-160
+  done ;;
+r4b)
+  # round 4, call 2: ADVICE fixes, BN statistics from the conv epilogue, split-major wgrad order: tests, then A/B bench lines
+  ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_distributed_gpu.py tests/test_pspnet_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -x -p no:cacheprovider 2>&1 | tail -30 ) > gpurun_out/r4b_tests.log
+  tail -8 gpurun_out/r4b_tests.log
+  for v in default nostats noflat; do
+    case $v in default) e="";; nostats) e="SEGMI_CONV_BN_STATS=0";; noflat) e="SEGMI_WGRAD_FLAT=0";; esac
+    ( env $e timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4b_bench_$v.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4b_bench_$v.log').read()); r=d['roofline']; print('cfg2 $v', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1
+  done
+  for c in cfg1 cfg3 cfg5; do for v in default nostats; do
+    case $v in default) e="";; nostats) e="SEGMI_CONV_BN_STATS=0";; esac
+    ( env $e timeout 400 python bench.py --config $c --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4b_bench_${c}_$v.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4b_bench_${c}_$v.log').read()); print('$c $v', d['value'], d['ms_per_step'])" 2>&1 | tail -1
+  done; done ;;
 esac
 done
