@@ -321,23 +321,28 @@ int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, 
                          float* const* G, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 
 /* ------------------------------------------------------------------ training-time augmentation */
-/* The cv2 / PIL sequence of BaseDataSet._augmentation + __getitem__ (base/base_dataset.py:63-136) on the device, one call per
- * stage and sample; images are uint8 HWC (3 channels), labels int32 HW, all device memory; the random decisions are the
- * caller's (dataloaders/gpu_augment.py draws them in the reference's order).
- *   segmi_aug_resize : cv2.resize INTER_LINEAR (image) / INTER_NEAREST (label) to dst_h x dst_w                     (:71-72)
- *   segmi_aug_rotate : cv2.warpAffine, bilinear / nearest, constant border 0; inv_affine6 = the INVERSE of
- *                      getRotationMatrix2D((w/2, h/2), angle, 1.0) as 6 host floats {m00 m01 m02 m10 m11 m12}         (:76-81)
- *   segmi_aug_blur   : cv2.GaussianBlur(ksize x ksize, sigma), BORDER_REFLECT_101; kernel_half4 = host floats {centre, +-1,
- *                      +-2, +-3 taps} of getGaussianKernel (ksize odd <= 7); scratch = 3*h*w floats                    (:113-117)
+/* The cv2 / PIL sequence of BaseDataSet._augmentation, _val_augmentation and __getitem__ (base/base_dataset.py:40-136) on the
+ * device, one call per stage and sample; images are uint8 HWC (3 channels), labels int32 HW, all device memory; the random
+ * decisions are the caller's (dataloaders/gpu_augment.py draws them in the reference's order).  The pixel arithmetic is
+ * OpenCV's FIXED-POINT arithmetic for 8-bit images, in integers; what OpenCV derives in double / float per output row and
+ * column arrives as int32 device tables the caller computes the same way (layouts below):
+ *   segmi_aug_resize : cv2.resize INTER_LINEAR (image; 11-bit coefficients, or the 2x2 box average when area2x: both scales are
+ *                      exactly 2) / nearest label to dst_h x dst_w.  tables_dev = xs[dw] | xa[dw] | ys[dh] | yb[dh] | lx[dw] | ly[dh]:
+ *                      source column and packed coefficients (c0 | c1 << 16) per output column, the same per output row (rows are
+ *                      clipped by the kernel), source column / row of the label (cv2 INTER_NEAREST or PIL NEAREST)   (:48-50,71-72)
+ *   segmi_aug_rotate : cv2.warpAffine, bilinear (1/32-pixel grid, 15-bit weights) / nearest, constant border 0.
+ *                      tables_dev = adelta[w] | bdelta[w] | X0[h] | Y0[h]: the inverted getRotationMatrix2D((w/2, h/2), angle, 1.0)
+ *                      scaled by 2^10 as cv::warpAffine rounds it, without the interpolation's rounding offset         (:76-81)
+ *   segmi_aug_blur   : cv2.GaussianBlur(3x3, sigma) on CV_8U, BORDER_REFLECT_101: taps {m0, m1, m0} in 8.8 fixed point
+ *                      (2*m0 + m1 == 256); scratch = 3*h*w uint16                                                    (:113-117)
  *   segmi_aug_finish : zero padding at the bottom / right up to the crop, crop at (start_h, start_w), optional fliplr,
  *                      ToTensor + Normalize(mean, std) into the fp32 NHWC batch slot `out` (pixel stride ld >= 4, channels
  *                      3..ld-1 zeroed) and the int64 label slot                                                     (:84-110,129-136) */
 int segmi_aug_resize(const uint8_t* image, const int32_t* label, int src_h, int src_w, uint8_t* out_image, int32_t* out_label,
-                     int dst_h, int dst_w, segmi_stream_t stream);
-int segmi_aug_rotate(const uint8_t* image, const int32_t* label, int h, int w, const float* inv_affine6, uint8_t* out_image,
+                     int dst_h, int dst_w, const int32_t* tables_dev, int area2x, segmi_stream_t stream);
+int segmi_aug_rotate(const uint8_t* image, const int32_t* label, int h, int w, const int32_t* tables_dev, uint8_t* out_image,
                      int32_t* out_label, segmi_stream_t stream);
-int segmi_aug_blur(const uint8_t* image, int h, int w, int ksize, const float* kernel_half4, float* scratch, uint8_t* out_image,
-                   segmi_stream_t stream);
+int segmi_aug_blur(const uint8_t* image, int h, int w, int m0, int m1, uint16_t* scratch, uint8_t* out_image, segmi_stream_t stream);
 int segmi_aug_finish(const uint8_t* image, const int32_t* label, int h, int w, int crop_h, int crop_w, int start_h, int start_w,
                      int flip, const float* mean3, const float* std3, float* out, int ld, int64_t* out_label, segmi_stream_t stream);
 

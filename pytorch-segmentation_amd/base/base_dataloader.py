@@ -1,4 +1,13 @@
-"""DataPrefetcher — host->HBM input staging for the hot loop (reference: base/base_dataloader.py:49-85, used at trainer.py:31-33).
+"""BaseDataLoader + DataPrefetcher — the reference's loader surface (base/base_dataloader.py:7-85, used at trainer.py:31-33).
+
+`BaseDataLoader(dataset, batch_size, shuffle, num_workers, val_split)` has the reference's constructor and `get_val_loader()`;
+iterating it yields `(input fp32 [N,3,crop,crop] NHWC-backed, target int64 [N,crop,crop])` batches ALREADY ON THE DEVICE: the raw
+uint8 samples of a `base.BaseDataSet` are decoded by `num_workers` host threads one batch ahead, staged through one pinned buffer
+per batch, and augmented / normalised by the libsegmi kernels (dataloaders/gpu_augment.py) according to the dataset's
+`base_size / crop_size / augment / scale / flip / rotate / blur / val` attributes — the values `train_loader.args` of config.json
+carries (config.json:14-31 of the reference).  Under torch.distributed every rank draws its own shard of each global step.
+
+DataPrefetcher — host->HBM input staging for loaders that still produce host tensors.
 
 Same surface as the reference class: `DataPrefetcher(loader, device, stop_after=None)`, `len()`, iteration yields
 `(input, target)` already on the device, `.dataset` / `.loader` pass-through (plus `batch_size`, `MEAN`, `STD`, which the trainer
@@ -12,7 +21,101 @@ reads from its loader).  What is different underneath:
     are `record_stream`-ed on the compute stream, so the caching allocator cannot recycle them under a kernel still reading them;
   * batches that are already device tensors (e.g. `dataloaders.Synth(device=...)`) pass through untouched.
 """
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
 import torch
+import torch.distributed as dist
+
+
+class BaseDataLoader:
+    def __init__(self, dataset, batch_size, shuffle, num_workers, val_split=0.0, device=None, seed=None, drop_last=False,
+                 rank=None, world=None, _indices=None, _is_val_split=False):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = bool(shuffle)
+        self.num_workers = max(1, int(num_workers or 1))
+        self.drop_last = drop_last
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.seed = 0 if seed is None else int(seed)
+        self.epoch = 0
+        ddp = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank() if ddp else 0) if rank is None else int(rank)
+        self.world = (dist.get_world_size() if ddp else 1) if world is None else int(world)
+        self.nbr_examples = len(dataset)
+        self.val_indices = None
+        if _indices is not None:
+            self.indices = np.asarray(_indices)
+        elif val_split:
+            # the reference's split (base/base_dataloader.py:25-44): a fixed permutation under np.random.seed(0), the first
+            # `val_split` share validates
+            self.shuffle = False if _is_val_split else self.shuffle
+            split = int(self.nbr_examples * val_split)
+            order = np.random.RandomState(0).permutation(self.nbr_examples)
+            self.indices, self.val_indices = order[split:], order[:split]
+        else:
+            self.indices = np.arange(self.nbr_examples)
+        self.nbr_examples = len(self.indices)
+        self._init_kwargs = dict(batch_size=batch_size, shuffle=False, num_workers=num_workers, device=device, seed=seed, drop_last=drop_last)
+        self._augment = None
+
+    def get_val_loader(self):
+        if self.val_indices is None:
+            return None
+        return BaseDataLoader(self.dataset, _indices=self.val_indices, _is_val_split=True, **self._init_kwargs)
+
+    # ---- batching
+    def _batches(self):
+        idx = np.array(self.indices)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + 1000003 * self.epoch)
+            idx = idx[torch.randperm(len(idx), generator=g).numpy()]
+        nb = len(idx) // self.batch_size if self.drop_last else -(-len(idx) // self.batch_size)
+        all_b = [idx[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
+        per_rank = len(all_b) // self.world if self.world > 1 else len(all_b)
+        return [all_b[i * self.world + self.rank] for i in range(per_rank)]     # this rank's shard of global step i
+
+    def __len__(self):
+        n = len(self.indices) // self.batch_size if self.drop_last else -(-len(self.indices) // self.batch_size)
+        return n // self.world if self.world > 1 else n
+
+    def _augmenter(self):
+        if self._augment is None:
+            from dataloaders.gpu_augment import GPUAugment
+            ds = self.dataset
+            train = bool(ds.augment) and not ds.val
+            if train and not ds.crop_size:
+                raise ValueError("%s: crop_size is required to batch augmented samples on the device (the reference's configs set it)" % type(self).__name__)
+            self._augment = GPUAugment(ds.mean, ds.std, base_size=ds.base_size if train else None, crop_size=ds.crop_size,
+                                       scale=ds.scale if train else False, flip=ds.flip if train else False,
+                                       rotate=ds.rotate if train else False, blur=ds.blur if train else False, device=self.device,
+                                       seed=self.seed * 7919 + self.rank if self.seed else None)
+        return self._augment
+
+    def __iter__(self):
+        batches = self._batches()
+        self.epoch += 1
+        aug = self._augmenter()
+        ds = self.dataset
+        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
+            def submit(b):
+                return [pool.submit(ds.__getitem__, int(i)) for i in b]
+            pending = submit(batches[0]) if batches else None
+            for k in range(len(batches)):
+                raw = [f.result() for f in pending]
+                pending = submit(batches[k + 1]) if k + 1 < len(batches) else None      # decode the next batch while this one runs
+                pairs = [(r[0], r[1]) for r in raw]
+                if ds.val:
+                    x, t = aug.validation(pairs)
+                elif ds.augment:
+                    x, t = aug(pairs)
+                else:
+                    x, t = aug.plain(pairs)     # neither branch of the reference's __getitem__ (:127-130): ToTensor + Normalize only
+                if getattr(ds, "return_id", False):
+                    yield x, t, [r[2] for r in raw]
+                else:
+                    yield x, t
 
 
 class _PinnedSlot:

@@ -1,75 +1,79 @@
 // Training-time augmentation on the device: the cv2 / PIL sequence of the reference's
-// BaseDataSet._augmentation (base/base_dataset.py:63-120) and __getitem__ (:125-136) as four gather kernels per sample:
+// BaseDataSet._augmentation (base/base_dataset.py:63-120), _val_augmentation (:40-61) and __getitem__ (:125-136) as gather
+// kernels per sample:
 //
-//   aug_resize   cv2.resize(image, INTER_LINEAR) + cv2.resize(label, INTER_NEAREST)        (:71-72)   uint8 HWC3 / int32 HW
+//   aug_resize   cv2.resize(image, INTER_LINEAR) + cv2.resize(label, INTER_NEAREST) / PIL NEAREST    (:48-50,71-72)  uint8 HWC3 / int32 HW
 //   aug_rotate   cv2.warpAffine(getRotationMatrix2D(centre, angle, 1.0)), bilinear image / nearest label, constant border 0 (:76-81)
-//   aug_blur     cv2.GaussianBlur(ksize, sigma, BORDER_REFLECT_101), separable                (:113-117)
-//   aug_finish   copyMakeBorder(bottom/right, 0) + random crop + fliplr + ToTensor + Normalize(mean, std) + label -> int64
+//   aug_blur     cv2.GaussianBlur(3x3, sigma, BORDER_REFLECT_101)                                     (:113-117)
+//   aug_finish   copyMakeBorder(bottom/right, 0) + crop + fliplr + ToTensor + Normalize(mean, std) + label -> int64
 //                (:84-110,129-136), written straight into the NHWC-backed fp32 batch (pixel stride 4) the model consumes
 //
-// The random decisions (long side, angle, crop origin, flip, sigma) are drawn on the host in the reference's order
-// (dataloaders/gpu_augment.py), so a seeded run takes the same decisions; the resampling arithmetic is fp32 where cv2 uses
-// fixed point (11-bit resize coefficients, 1/32-pixel warp coordinates — the latter IS mirrored), so results can differ from
-// cv2 by one uint8 level at isolated pixels.  cv2 is not installed in the build image: parity against it is unpinned; the
-// kernels are held bit-exactly (labels) / within one level (images) to oracle/augment_ref.py, the numpy restatement of the
-// same formulas.  HBM-bound gathers, one thread per output pixel; off the timed hot path (the metric excludes data loading).
+// cv2's 8-bit paths are FIXED POINT (11-bit resize coefficients, 1/32-pixel warp grid with 15-bit weights, 8.8 Gaussian taps);
+// the kernels evaluate exactly that integer arithmetic.  Everything that OpenCV derives in double / float on the host — source
+// offsets and coefficients per output column / row, the inverted affine map scaled by 2^10 — arrives as small int32 TABLES
+// computed by the host code in the same way (dataloaders/gpu_augment.py), so there is no floating point in the pixel path at
+// all and the results are held BIT-EXACTLY to oracle/augment_ref.py, an independent numpy restatement of OpenCV's published
+// algorithms.  cv2 itself is not installed in the build image: parity against the library is unpinned (oracle header).
+// HBM-bound gathers, one thread per output pixel; off the timed hot path (the metric excludes data loading).
 #include "segmi_common.h"
 
 namespace {
 
-__device__ __forceinline__ unsigned char sat_u8(float v) {
-    v = rintf(v);
-    return (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
-}
+__device__ __forceinline__ unsigned char sat_u8i(int v) { return (unsigned char)min(max(v, 0), 255); }
 
-// cv2.resize INTER_LINEAR (half-pixel centres, edge clamp) / INTER_NEAREST (floor(dst * scale))
+// tab: xs[dw] | xa[dw] (a0 | a1 << 16) | ys[dh] | yb[dh] (b0 | b1 << 16) | lx[dw] | ly[dh]   (int32 each)
+// area2x: both scales are exactly 2 — cv::resize turns INTER_LINEAR into the 2x2 box average
 __global__ __launch_bounds__(256) void aug_resize_kernel(const unsigned char* __restrict__ img, const int* __restrict__ lab, int sh, int sw,
-                                                         unsigned char* __restrict__ oimg, int* __restrict__ olab, int dh, int dw) {
+                                                         unsigned char* __restrict__ oimg, int* __restrict__ olab, int dh, int dw,
+                                                         const int* __restrict__ tab, int area2x) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)dh * dw) return;
     const int y = (int)(p / dw), x = (int)(p % dw);
-    const float fy = (float)sh / (float)dh, fx = (float)sw / (float)dw;
-    float sy = ((float)y + 0.5f) * fy - 0.5f, sx = ((float)x + 0.5f) * fx - 0.5f;
-    int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
-    float wy = sy - (float)y0, wx = sx - (float)x0;
-    if (y0 < 0) { y0 = 0; wy = 0.f; }
-    if (x0 < 0) { x0 = 0; wx = 0.f; }
-    if (y0 >= sh - 1) { y0 = sh - 1; wy = 0.f; }
-    if (x0 >= sw - 1) { x0 = sw - 1; wx = 0.f; }
-    const int y1 = min(y0 + 1, sh - 1), x1 = min(x0 + 1, sw - 1);
+    const int* xs = tab;
+    const int* xa = tab + dw;
+    const int* ys = tab + 2 * dw;
+    const int* yb = ys + dh;
+    const int* lx = yb + dh;
+    const int* ly = lx + dw;
+    if (area2x) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float a = img[((long)y0 * sw + x0) * 3 + c], b = img[((long)y0 * sw + x1) * 3 + c];
-        const float d = img[((long)y1 * sw + x0) * 3 + c], e = img[((long)y1 * sw + x1) * 3 + c];
-        oimg[p * 3 + c] = sat_u8((1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * d + wx * e));
+        for (int c = 0; c < 3; ++c) {
+            const unsigned char* q = img + ((long)(2 * y) * sw + 2 * x) * 3 + c;
+            oimg[p * 3 + c] = (unsigned char)(((int)q[0] + q[3] + q[(long)sw * 3] + q[(long)sw * 3 + 3] + 2) >> 2);
+        }
+    } else {
+        const int x0 = xs[x], x1 = min(x0 + 1, sw - 1);
+        const int a0 = (short)(xa[x] & 0xFFFF), a1 = xa[x] >> 16;
+        const int sy = ys[y];
+        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);       // rows clipped, coefficients kept
+        const int b0 = (short)(yb[y] & 0xFFFF), b1 = yb[y] >> 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int d0 = (int)img[((long)y0 * sw + x0) * 3 + c] * a0 + (int)img[((long)y0 * sw + x1) * 3 + c] * a1;
+            const int d1 = (int)img[((long)y1 * sw + x0) * 3 + c] * a0 + (int)img[((long)y1 * sw + x1) * 3 + c] * a1;
+            oimg[p * 3 + c] = sat_u8i((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2);
+        }
     }
-    const int ny = min((int)floorf((float)y * fy), sh - 1), nx = min((int)floorf((float)x * fx), sw - 1);
-    olab[p] = lab[(long)ny * sw + nx];
+    olab[p] = lab[(long)ly[y] * sw + lx[x]];
 }
 
-// cv2.warpAffine with the INVERSE of M = getRotationMatrix2D((w/2, h/2), angle, 1): source coordinates quantised to 1/32 pixel
-// (INTER_BITS = 5) for the bilinear image, rounded to the nearest pixel for the label; outside pixels are the border value 0
+// tab: adelta[w] | bdelta[w] | X0[h] | Y0[h]: cv::warpAffine's fixed-point (2^10) inverse map without the rounding offset
 __global__ __launch_bounds__(256) void aug_rotate_kernel(const unsigned char* __restrict__ img, const int* __restrict__ lab, int h, int w,
-                                                         float m00, float m01, float m02, float m10, float m11, float m12,
-                                                         unsigned char* __restrict__ oimg, int* __restrict__ olab) {
+                                                         const int* __restrict__ tab, unsigned char* __restrict__ oimg, int* __restrict__ olab) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)h * w) return;
     const int y = (int)(p / w), x = (int)(p % w);
-    const float sxf = m00 * (float)x + m01 * (float)y + m02, syf = m10 * (float)x + m11 * (float)y + m12;
-    const float qx = rintf(sxf * 32.f), qy = rintf(syf * 32.f);          // 1/32-pixel grid
-    const int X = (int)qx, Y = (int)qy;
-    const int x0 = X >> 5, y0 = Y >> 5;                                   // floor (arithmetic shift)
-    const float wx = (float)(X & 31) * (1.f / 32.f), wy = (float)(Y & 31) * (1.f / 32.f);
-    auto px = [&](int yy, int xx, int c) -> float {
-        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (float)img[((long)yy * w + xx) * 3 + c] : 0.f;
+    const int ad = tab[x], bd = tab[w + x], X0 = tab[2 * w + y], Y0 = tab[2 * w + h + y];
+    const int X = (X0 + 16 + ad) >> 5, Y = (Y0 + 16 + bd) >> 5;           // 1/32-pixel grid (arithmetic shifts = floor)
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int w00 = 32 * (32 - fy) * (32 - fx), w01 = 32 * (32 - fy) * fx, w10 = 32 * fy * (32 - fx), w11 = 32 * fy * fx;
+    auto px = [&](int yy, int xx, int c) -> int {
+        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (int)img[((long)yy * w + xx) * 3 + c] : 0;
     };
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = (1.f - wy) * ((1.f - wx) * px(y0, x0, c) + wx * px(y0, x0 + 1, c)) +
-                        wy * ((1.f - wx) * px(y0 + 1, x0, c) + wx * px(y0 + 1, x0 + 1, c));
-        oimg[p * 3 + c] = sat_u8(v);
-    }
-    const int nx = (int)rintf(sxf), ny = (int)rintf(syf);
+    for (int c = 0; c < 3; ++c)
+        oimg[p * 3 + c] = sat_u8i((px(sy, sx, c) * w00 + px(sy, sx + 1, c) * w01 + px(sy + 1, sx, c) * w10 + px(sy + 1, sx + 1, c) * w11 + (1 << 14)) >> 15);
+    const int nx = (X0 + 512 + ad) >> 10, ny = (Y0 + 512 + bd) >> 10;
     olab[p] = (ny >= 0 && ny < h && nx >= 0 && nx < w) ? lab[(long)ny * w + nx] : 0;
 }
 
@@ -78,27 +82,23 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
     return i;
 }
-// one axis of cv2.GaussianBlur (kernel <= 7 taps: ksize = int(3.3 * sigma) made odd, sigma < 1) with BORDER_REFLECT_101;
-// AXIS 0 = along x into a float scratch image, AXIS 1 = along y, rounding to uint8
+// cv2.GaussianBlur(3x3) on CV_8U: taps {m0, m1, m0} in 8.8 fixed point; AXIS 0 = rows into a uint16 scratch image
+// (ufixedpoint16), AXIS 1 = columns with rounding (+2^15) >> 16; BORDER_REFLECT_101
 template <int AXIS>
-__global__ __launch_bounds__(256) void aug_blur_kernel(const unsigned char* __restrict__ img, const float* __restrict__ tmp_in, int h, int w,
-                                                       int ksize, float k0, float k1, float k2, float k3,
-                                                       float* __restrict__ tmp_out, unsigned char* __restrict__ oimg) {
+__global__ __launch_bounds__(256) void aug_blur_kernel(const unsigned char* __restrict__ img, const unsigned short* __restrict__ tmp_in, int h, int w,
+                                                       int m0, int m1, unsigned short* __restrict__ tmp_out, unsigned char* __restrict__ oimg) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)h * w) return;
     const int y = (int)(p / w), x = (int)(p % w);
-    const float kk[4] = {k0, k1, k2, k3};        // centre, +-1, +-2, +-3
-    const int r = ksize >> 1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float acc = 0.f;
-        for (int d = -r; d <= r; ++d) {
-            const float wgt = kk[d < 0 ? -d : d];
-            if (AXIS == 0) acc += wgt * (float)img[((long)y * w + reflect101(x + d, w)) * 3 + c];
-            else           acc += wgt * tmp_in[((long)reflect101(y + d, h) * w + x) * 3 + c];
+        if (AXIS == 0) {
+            const int l = img[((long)y * w + reflect101(x - 1, w)) * 3 + c], r = img[((long)y * w + reflect101(x + 1, w)) * 3 + c];
+            tmp_out[p * 3 + c] = (unsigned short)(m0 * (l + r) + m1 * (int)img[p * 3 + c]);
+        } else {
+            const int u = tmp_in[((long)reflect101(y - 1, h) * w + x) * 3 + c], d = tmp_in[((long)reflect101(y + 1, h) * w + x) * 3 + c];
+            oimg[p * 3 + c] = sat_u8i((m0 * (u + d) + m1 * (int)tmp_in[p * 3 + c] + (1 << 15)) >> 16);
         }
-        if (AXIS == 0) tmp_out[p * 3 + c] = acc;
-        else           oimg[p * 3 + c] = sat_u8(acc);
     }
 }
 
@@ -134,30 +134,29 @@ int blocks(long n) { return (int)((n + 255) / 256); }
 extern "C" {
 
 int segmi_aug_resize(const uint8_t* image, const int32_t* label, int src_h, int src_w, uint8_t* out_image, int32_t* out_label,
-                     int dst_h, int dst_w, segmi_stream_t stream) {
-    if (!image || !label || !out_image || !out_label || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return SEGMI_ERR_BADARG;
+                     int dst_h, int dst_w, const int32_t* tables_dev, int area2x, segmi_stream_t stream) {
+    if (!image || !label || !out_image || !out_label || !tables_dev || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return SEGMI_ERR_BADARG;
+    if (area2x && (src_h < 2 * dst_h || src_w < 2 * dst_w)) return SEGMI_ERR_BADARG;
     hipLaunchKernelGGL(aug_resize_kernel, dim3(blocks((long)dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, image, label, src_h, src_w,
-                       out_image, out_label, dst_h, dst_w);
+                       out_image, out_label, dst_h, dst_w, tables_dev, area2x ? 1 : 0);
     return segmi_launch_status();
 }
 
-int segmi_aug_rotate(const uint8_t* image, const int32_t* label, int h, int w, const float* inv_affine6, uint8_t* out_image,
+int segmi_aug_rotate(const uint8_t* image, const int32_t* label, int h, int w, const int32_t* tables_dev, uint8_t* out_image,
                      int32_t* out_label, segmi_stream_t stream) {
-    if (!image || !label || !out_image || !out_label || !inv_affine6 || h <= 0 || w <= 0) return SEGMI_ERR_BADARG;
-    hipLaunchKernelGGL(aug_rotate_kernel, dim3(blocks((long)h * w)), dim3(256), 0, (hipStream_t)stream, image, label, h, w, inv_affine6[0],
-                       inv_affine6[1], inv_affine6[2], inv_affine6[3], inv_affine6[4], inv_affine6[5], out_image, out_label);
+    if (!image || !label || !out_image || !out_label || !tables_dev || h <= 0 || w <= 0) return SEGMI_ERR_BADARG;
+    hipLaunchKernelGGL(aug_rotate_kernel, dim3(blocks((long)h * w)), dim3(256), 0, (hipStream_t)stream, image, label, h, w, tables_dev,
+                       out_image, out_label);
     return segmi_launch_status();
 }
 
-int segmi_aug_blur(const uint8_t* image, int h, int w, int ksize, const float* kernel_half4, float* scratch, uint8_t* out_image,
-                   segmi_stream_t stream) {
-    if (!image || !out_image || !scratch || !kernel_half4 || h <= 0 || w <= 0 || ksize < 1 || ksize > 7 || !(ksize & 1)) return SEGMI_ERR_BADARG;
+int segmi_aug_blur(const uint8_t* image, int h, int w, int m0, int m1, uint16_t* scratch, uint8_t* out_image, segmi_stream_t stream) {
+    if (!image || !out_image || !scratch || h <= 0 || w <= 0 || m0 < 0 || m1 < 0 || 2 * m0 + m1 != 256) return SEGMI_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int nb = blocks((long)h * w);
-    hipLaunchKernelGGL((aug_blur_kernel<0>), dim3(nb), dim3(256), 0, st, image, (const float*)nullptr, h, w, ksize, kernel_half4[0],
-                       kernel_half4[1], kernel_half4[2], kernel_half4[3], scratch, (unsigned char*)nullptr);
-    hipLaunchKernelGGL((aug_blur_kernel<1>), dim3(nb), dim3(256), 0, st, (const unsigned char*)nullptr, (const float*)scratch, h, w, ksize,
-                       kernel_half4[0], kernel_half4[1], kernel_half4[2], kernel_half4[3], (float*)nullptr, out_image);
+    hipLaunchKernelGGL((aug_blur_kernel<0>), dim3(nb), dim3(256), 0, st, image, (const unsigned short*)nullptr, h, w, m0, m1, scratch, (unsigned char*)nullptr);
+    hipLaunchKernelGGL((aug_blur_kernel<1>), dim3(nb), dim3(256), 0, st, (const unsigned char*)nullptr, (const unsigned short*)scratch, h, w, m0, m1,
+                       (unsigned short*)nullptr, out_image);
     return segmi_launch_status();
 }
 

@@ -10,6 +10,7 @@
 //
 // All kernels: NHWC fp32, a thread owns one float4 channel group and walks pixels (rowgeom.h).
 #include "rowgeom.h"
+#include <cstdlib>
 
 namespace {
 
@@ -135,12 +136,133 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     }
 }
 
+
+// ---- 3x3, stride 1, pad == dil == D ("same" depthwise convolutions: all of Xception's except the four strided ones): a thread
+// computes a strip of 4 consecutive outputs of one image row, so the 3 x (4 + 2D) input taps it loads serve 4 outputs —
+// 4.5 float4 loads per output for D = 1 instead of 9 (the one-output-per-thread kernels above are load-issue bound: 28 us per
+// 728-channel 32x32 layer whose tensors stream in 10 us).
+// FLIP: the filter is read rotated by 180 degrees — the data gradient of the same convolution (dx = dy (*) rot180(w)).
+template <int D, bool FLIP>
+__global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                          float* __restrict__ y, int ldy, int N, int H, int W, int C) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= C) return;
+    float4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = ld4(w + (long)(FLIP ? 8 - t : t) * C + c4 * 4);
+    const int QS = (W + 3) >> 2;
+    const long strips = (long)N * H * QS;
+    for (long sidx = (long)blockIdx.y * blockDim.y + threadIdx.y; sidx < strips; sidx += (long)gridDim.y * blockDim.y) {
+        const int qs = (int)(sidx % QS);
+        const long t1 = sidx / QS;
+        const int p = (int)(t1 % H), n = (int)(t1 / H);
+        const int q0 = qs * 4;
+        float4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = p + (r - 1) * D;
+            if ((unsigned)h >= (unsigned)H) continue;
+            const float* rowp = x + ((long)(n * H + h) * W) * ldx + c4 * 4;
+            float4 v[4 + 2 * D];
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * D; ++j) {
+                const int ww = q0 - D + j;
+                v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const float4 f = wt[r * 3 + s2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 u = v[j + s2 * D];
+                    acc[j].x = fmaf(u.x, f.x, acc[j].x); acc[j].y = fmaf(u.y, f.y, acc[j].y);
+                    acc[j].z = fmaf(u.z, f.z, acc[j].z); acc[j].w = fmaf(u.w, f.w, acc[j].w);
+                }
+            }
+        }
+        float* o = y + ((long)(n * H + p) * W + q0) * ldy + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q0 + j < W) st4(o + (long)j * ldy, acc[j]);
+    }
+}
+
+// filter gradient of the same convolutions, same strips: part[blockIdx.y][t][C] = sum over this block's strips of dy (x) x-taps
+template <int D>
+__global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                                float* __restrict__ part, int N, int H, int W, int C) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 * 4 < C;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = zero4();
+    const int QS = (W + 3) >> 2;
+    const long strips = (long)N * H * QS;
+    if (cok)
+        for (long sidx = (long)blockIdx.y * blockDim.y + threadIdx.y; sidx < strips; sidx += (long)gridDim.y * blockDim.y) {
+            const int qs = (int)(sidx % QS);
+            const long t1 = sidx / QS;
+            const int p = (int)(t1 % H), n = (int)(t1 / H);
+            const int q0 = qs * 4;
+            float4 gy[4];
+            const float* gp = dy + ((long)(n * H + p) * W + q0) * lddy + c4 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gy[j] = q0 + j < W ? ld4(gp + (long)j * lddy) : zero4();
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int h = p + (r - 1) * D;
+                if ((unsigned)h >= (unsigned)H) continue;
+                const float* rowp = x + ((long)(n * H + h) * W) * ldx + c4 * 4;
+                float4 v[4 + 2 * D];
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * D; ++j) {
+                    const int ww = q0 - D + j;
+                    v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 u = v[j + s2 * D];
+                        float4& a = acc[r * 3 + s2];
+                        a.x = fmaf(u.x, gy[j].x, a.x); a.y = fmaf(u.y, gy[j].y, a.y);
+                        a.z = fmaf(u.z, gy[j].z, a.z); a.w = fmaf(u.w, gy[j].w, a.w);
+                    }
+            }
+        }
+    __shared__ float4 sm[256];
+    const int tix = threadIdx.y * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        sm[tix] = acc[t];
+        __syncthreads();
+        for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+            if ((int)threadIdx.y < s) {
+                float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                sm[tix] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.y == 0 && cok) st4(part + ((long)blockIdx.y * 9 + t) * C + c4 * 4, sm[tix]);
+        __syncthreads();
+    }
+}
+
 // out[i] = sum_p part[p][i]; block = (32 elements, 8 part lanes)
 __global__ __launch_bounds__(256) void dw_sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
     const int i = blockIdx.x * 32 + threadIdx.x;
     float a = 0.f;
-    if (i < n)
-        for (int p = threadIdx.y; p < nparts; p += 8) a += part[(long)p * n + i];
+    if (i < n) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent loads per step (a serial chain over up to 1024
+        int p = threadIdx.y;                              // partials cost 14 us per depthwise filter gradient)
+        for (; p + 24 < nparts; p += 32) {
+            a0 += part[(long)p * n + i]; a1 += part[(long)(p + 8) * n + i];
+            a2 += part[(long)(p + 16) * n + i]; a3 += part[(long)(p + 24) * n + i];
+        }
+        for (; p < nparts; p += 8) a0 += part[(long)p * n + i];
+        a = (a0 + a1) + (a2 + a3);
+    }
     __shared__ float sm[8][33];
     sm[threadIdx.y][threadIdx.x] = a;
     __syncthreads();
@@ -217,6 +339,16 @@ int dw_parts(long rows, int C) {
     if (p > 1024) p = 1024;
     return (int)p;
 }
+// the strip kernels serve 3x3, stride 1, pad == dil in {1, 2} (0 otherwise); SEGMI_DW_STRIP=0 keeps the one-output-per-thread kernels
+int g_dw_strip = -1;
+int dw_strip(const segmi_conv_desc* d) {
+    if (g_dw_strip < 0) {
+        const char* e = getenv("SEGMI_DW_STRIP");
+        g_dw_strip = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!g_dw_strip || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || d->dil > 2) return 0;
+    return d->dil;
+}
 
 }  // namespace
 
@@ -226,6 +358,12 @@ int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_
     if (!dw_ok(d) || !x || !w_rsc || !y) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     const long rows = (long)d->N * d->P * d->Q;
+    if (const int D = dw_strip(d)) {
+        RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
+        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, false>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C);
+        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, false>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C);
+        return segmi_launch_status();
+    }
     RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((dwconv_fwd_kernel<9>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, dw_geom(d));
     return segmi_launch_status();
@@ -235,6 +373,12 @@ int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float*
     if (!dw_ok(d) || !dy || !w_rsc || !dx) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     const long rows = (long)d->N * d->H * d->W;
+    if (const int D = dw_strip(d)) {          // dx = dy (*) rot180(w): the forward strip kernel with the filter read flipped
+        RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
+        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C);
+        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C);
+        return segmi_launch_status();
+    }
     RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((dwconv_dgrad_kernel<9>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, dw_geom(d));
     return segmi_launch_status();
@@ -255,6 +399,10 @@ int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* 
     RowGeom g = row_geom(rows, d->C, 1, 1);
     g.grid.y = parts;
     hipStream_t st = (hipStream_t)stream;
+    if (const int D = dw_strip(d)) {
+        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<1>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C);
+        else        hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<2>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C);
+    } else
     hipLaunchKernelGGL((dwconv_wgrad_kernel<9>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, dw_geom(d));
     const int n = d->R * d->S * d->C;
     hipLaunchKernelGGL(dw_sum_parts_kernel, dim3(segmi_cdiv(n, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, n, dw_rsc);

@@ -198,87 +198,82 @@ __global__ __launch_bounds__(256) void segsort_scan_kernel(unsigned* __restrict_
     }
 }
 
-// stable scatter of one tile.  Each WAVE owns a contiguous quarter of the tile (1024 keys = 16 rounds of 64), so after one
-// block-level histogram phase the placement needs no block barrier at all: position = first slot of the digit in the tile
-// + keys of that digit in earlier waves' quarters + keys of that digit this wave has already placed + rank among the wave's
-// lanes holding the digit in this round (ballots).  The tile is assembled digit by digit in LDS, then every digit's run is
-// written to its global position as consecutive elements.
+// stable scatter of one tile.  Each WAVE owns a contiguous quarter of the tile (1024 keys = 16 rounds of 64).  ONE read of the
+// tile: a lane keeps its 16 keys in registers and, per key, its position among the wave's keys of the same digit (keys of that
+// digit in the wave's earlier rounds + rank among the lanes of this round holding it: ballots) — 16 bits.  After the block has
+// turned the four per-wave histograms into first slots (exclusive scan over digits, then over waves), placement is one LDS
+// read + one LDS write per key with no ballots and no second pass over the tile (round 3 recomputed the ballots while re-reading
+// the tile from L2: 2.09 ms per pass for cfg5's 314 M keys).  The tile is assembled digit by digit in LDS, then every digit's
+// run is written to its global position as consecutive elements.
+template <int R0>
+__device__ __forceinline__ void seg_rank_rounds(const unsigned long long* __restrict__ k, long i0, int nk, int w, int lane, int shift,
+                                                unsigned mask, unsigned* wrow, unsigned long long (&kq)[ST / 256], unsigned (&pre)[ST / 256 / 2]) {
+    constexpr int WQ = ST / 4;
+    bool vq[SEG_MLP];
+#pragma unroll
+    for (int u = 0; u < SEG_MLP; ++u) {                  // SEG_MLP 512-byte loads per wave in flight
+        const int i = w * WQ + (R0 + u) * 64 + lane;
+        vq[u] = i < nk;
+        kq[R0 + u] = vq[u] ? k[i0 + i] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < SEG_MLP; ++u) {
+        const unsigned d = seg_digit(kq[R0 + u], shift, mask);
+        unsigned rank, n;
+        wave_peers(d, vq[u], lane, rank, n);
+        const unsigned before = wrow[d];                 // every lane reads before the digit's first lane adds this round's count
+        if (vq[u] && rank == 0) wrow[d] = before + n;    // (a wave's LDS operations execute in order)
+        const unsigned pos = before + rank;              // < 1024
+        if (((R0 + u) & 1) == 0) pre[(R0 + u) >> 1] = pos; else pre[(R0 + u) >> 1] |= pos << 16;
+        __builtin_amdgcn_sched_barrier(0);               // one round's ballot masks at a time (SGPRs)
+    }
+}
+
 __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                               long rows, int ntiles, int shift, unsigned mask,
                                                               const unsigned* __restrict__ counts, const unsigned* __restrict__ hist) {
     const int c = blockIdx.y, tile = blockIdx.x;
     if (counts[c] == 0) return;
     constexpr int WQ = ST / 4;                         // keys per wave
+    constexpr int RW = WQ / 64;                        // rounds per wave
+    static_assert(RW == 2 * SEG_MLP, "two load groups per wave");
     __shared__ unsigned long long sorted[ST];
-    __shared__ unsigned wbase[4][256], wrun[4][256], gbase[256];
+    __shared__ unsigned wbase[4][256], scan_s[256], gbase[256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long* k = in + (long)c * rows;
     const long i0 = (long)tile * ST;
     const int nk = (int)(rows - i0 < (long)ST ? rows - i0 : (long)ST);
     wbase[0][tid] = 0; wbase[1][tid] = 0; wbase[2][tid] = 0; wbase[3][tid] = 0;
-    wrun[0][tid] = 0; wrun[1][tid] = 0; wrun[2][tid] = 0; wrun[3][tid] = 0;
     gbase[tid] = hist[((long)c * ntiles + tile) * 256 + tid];
     __syncthreads();
-    // phase 1: per-wave digit histograms of the wave's quarter (one lane per distinct digit adds: no atomics, a wave's LDS
-    // operations execute in order).  The tile is read twice (here and in phase 2, from L2) instead of being held in registers:
-    // a rolled loop keeps one round's 64-bit ballot masks in SGPRs (the unrolled form spilled them through 512 VGPRs).
-#pragma unroll 1
-    for (int r0 = 0; r0 < WQ / 64; r0 += SEG_MLP) {      // SEG_MLP loads per wave in flight
-        unsigned long long kq[SEG_MLP];
-        bool vq[SEG_MLP];
-#pragma unroll
-        for (int u = 0; u < SEG_MLP; ++u) {
-            const int i = w * WQ + (r0 + u) * 64 + lane;
-            vq[u] = i < nk;
-            kq[u] = vq[u] ? k[i0 + i] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < SEG_MLP; ++u) {
-            const unsigned d = seg_digit(kq[u], shift, mask);
-            unsigned rank, n;
-            wave_peers(d, vq[u], lane, rank, n);
-            if (vq[u] && rank == 0) wbase[w][d] += n;
-        }
-    }
+    // phase 1: keys -> registers, per-wave digit histograms, position of every key among its wave's keys of the same digit
+    unsigned long long kq[RW];
+    unsigned pre[RW / 2];
+    seg_rank_rounds<0>(k, i0, nk, w, lane, shift, mask, wbase[w], kq, pre);
+    seg_rank_rounds<SEG_MLP>(k, i0, nk, w, lane, shift, mask, wbase[w], kq, pre);
     __syncthreads();
     {   // wbase[w][d] <- first slot of (wave w, digit d) in the tile: exclusive scan of the tile histogram over digits, then over waves
         const unsigned h0 = wbase[0][tid], h1 = wbase[1][tid], h2 = wbase[2][tid], h3 = wbase[3][tid];
         const unsigned v = h0 + h1 + h2 + h3;
-        unsigned* sc = &wrun[3][0];                    // scan scratch (wrun[3] is re-zeroed below)
-        sc[tid] = v;
+        scan_s[tid] = v;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
-            const unsigned y = tid >= o ? sc[tid - o] : 0u;
+            const unsigned y = tid >= o ? scan_s[tid - o] : 0u;
             __syncthreads();
-            sc[tid] += y;
+            scan_s[tid] += y;
             __syncthreads();
         }
-        const unsigned start = sc[tid] - v;
-        __syncthreads();
+        const unsigned start = scan_s[tid] - v;
         wbase[0][tid] = start; wbase[1][tid] = start + h0; wbase[2][tid] = start + h0 + h1; wbase[3][tid] = start + h0 + h1 + h2;
-        wrun[3][tid] = 0;
     }
     __syncthreads();
-    // phase 2: placement, wave by wave, no block barrier
-#pragma unroll 1
-    for (int r0 = 0; r0 < WQ / 64; r0 += SEG_MLP) {
-        unsigned long long kq[SEG_MLP];
-        bool vq[SEG_MLP];
+    // phase 2: placement from registers
 #pragma unroll
-        for (int u = 0; u < SEG_MLP; ++u) {
-            const int i = w * WQ + (r0 + u) * 64 + lane;
-            vq[u] = i < nk;
-            kq[u] = vq[u] ? k[i0 + i] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < SEG_MLP; ++u) {
-            const unsigned d = seg_digit(kq[u], shift, mask);
-            unsigned rank, n;
-            wave_peers(d, vq[u], lane, rank, n);
-            const unsigned before = wrun[w][d];        // every lane reads before the digit's first lane adds this round's count
-            if (vq[u]) sorted[wbase[w][d] + before + rank] = kq[u];
-            if (vq[u] && rank == 0) wrun[w][d] = before + n;
-        }
+    for (int r = 0; r < RW; ++r) {
+        const int i = w * WQ + r * 64 + lane;
+        const unsigned d = seg_digit(kq[r], shift, mask);
+        const unsigned pos = (r & 1) ? pre[r >> 1] >> 16 : pre[r >> 1] & 0xFFFFu;
+        if (i < nk) sorted[wbase[w][d] + pos] = kq[r];
     }
     __syncthreads();
     unsigned long long* o = out + (long)c * rows;

@@ -1,1 +1,2 @@
-from .synth import Synth  # noqa: F401
+from .synth import Synth, SynthImages  # noqa: F401
+from .voc import VOC  # noqa: F401

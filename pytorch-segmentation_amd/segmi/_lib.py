@@ -103,9 +103,9 @@ SIGNATURES = {
     "segmi_pyramid_up_workspace": (sz, [i32, i32, i32, i32, i32, vp, vp]),
     "segmi_pyramid_up_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_pyramid_up_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
-    "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp]),
-    "segmi_aug_rotate": (i32, [vp, vp, i32, i32, C.POINTER(f32), vp, vp, vp]),
-    "segmi_aug_blur": (i32, [vp, i32, i32, i32, C.POINTER(f32), vp, vp, vp]),
+    "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
+    "segmi_aug_rotate": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+    "segmi_aug_blur": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "segmi_aug_finish": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
     "segmi_ce_workspace": (sz, [i64]),
     "segmi_ce_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, vp, vp, sz, vp]),

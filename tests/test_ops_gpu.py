@@ -430,7 +430,8 @@ def test_conv_transpose2x2(cuda, case):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 9, 11, 3, 1, 1, 1), (2, 64, 16, 16, 3, 2, 1, 1), (1, 128, 13, 13, 3, 1, 2, 2),
-                                  (2, 32, 10, 12, 3, 1, 4, 4), (2, 728, 8, 8, 3, 1, 1, 1), (1, 16, 7, 7, 3, 2, 2, 2)])
+                                  (2, 32, 10, 12, 3, 1, 4, 4), (2, 728, 8, 8, 3, 1, 1, 1), (1, 16, 7, 7, 3, 2, 2, 2),
+                                  (2, 64, 33, 37, 3, 1, 1, 1), (2, 256, 32, 32, 3, 1, 2, 2), (1, 12, 3, 2, 3, 1, 1, 1), (1, 8, 5, 70, 3, 1, 2, 2)])
 def test_depthwise_conv(cuda, case):
     """nn.Conv2d(C, C, 3, groups=C) of Xception's SeparableConv2d (models/deeplabv3_plus.py:80), stride/dilation variants."""
     from segmi import ops
@@ -853,6 +854,7 @@ def test_cross_entropy_fused_with_final_upsample(cuda, case):
 def test_winograd_keeps_no_transformed_input_under_no_grad(cuda):
     """validation under torch.no_grad() with trainable weights must not allocate the 4x-size Winograd V buffer
     that only a filter gradient would use."""
+    from segmi import ops
     prev = ops.get_conv_winograd()
     ops.set_conv_winograd(True, wgrad=True, keep_v=True)
     try:

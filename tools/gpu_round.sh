@@ -252,5 +252,30 @@ r4b)
     ( env $e timeout 400 python bench.py --config $c --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4b_bench_${c}_$v.log
     python -c "import json; d=json.loads(open('gpurun_out/r4b_bench_${c}_$v.log').read()); print('$c $v', d['value'], d['ms_per_step'])" 2>&1 | tail -1
   done; done ;;
+r4c)
+  # round 4, call 3: single-read Lovasz scatter, strip-tiled depthwise kernels: tests, then cfg5 A/B
+  ( timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -rf -x -p no:cacheprovider -k "depthwise or lovasz or losses_match or winograd_keeps or colsum or conv_transpose" 2>&1 | tail -12 ) > gpurun_out/r4c_tests.log
+  tail -5 gpurun_out/r4c_tests.log
+  ( timeout 300 python -m pytest tests/test_fullsize_golden_gpu.py tests/test_deeplab_gpu.py -m gpu -q -rf -x -p no:cacheprovider -k "cfg5 or xception" 2>&1 | tail -12 ) > gpurun_out/r4c_tests_cfg5.log
+  tail -4 gpurun_out/r4c_tests_cfg5.log
+  for v in default nostrip rocprim; do
+    case $v in default) e="";; nostrip) e="SEGMI_DW_STRIP=0";; rocprim) e="SEGMI_LOVASZ_SORT=rocprim";; esac
+    ( env $e timeout 400 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4c_bench_cfg5_$v.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4c_bench_cfg5_$v.log').read()); print('cfg5 $v', d['value'], d['ms_per_step'])" 2>&1 | tail -1
+  done
+  rm -rf gpurun_out/prof_cfg5
+  ( SEGMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg5 -o r -- python bench.py --config cfg5 --steps 7 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r4c_prof_cfg5.log
+  find gpurun_out/prof_cfg5 -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof_cfg5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4c_cfg5_kernel_stats.csv
+  rm -rf gpurun_out/prof_cfg5
+  head -14 gpurun_out/r4c_cfg5_kernel_stats.csv | cut -c1-150
+  ( timeout 300 python bench.py --config cfg1 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 | cut -c1-200 ) ;;
+r4d)
+  # round 4, call 4: the input pipeline (f4) on hardware, then the whole suite on the current tree
+  ( timeout 600 python -m pytest tests/test_augment.py -m gpu -q -rf -x -p no:cacheprovider 2>&1 | tail -25 ) > gpurun_out/r4d_augment.log
+  tail -8 gpurun_out/r4d_augment.log
+  ( timeout 1800 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r4d_pytest_gpu.log
+  tail -6 gpurun_out/r4d_pytest_gpu.log | cut -c1-400
+  ( timeout 300 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 | cut -c1-200 ) ;;
 esac
 done
