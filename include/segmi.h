@@ -320,6 +320,28 @@ int segmi_pyramid_up_fwd(const float* const* T, int N, int H, int W, int K, int 
 int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, int nlevels, const int* bins_h, const int* bins_w,
                          float* const* G, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 
+/* ------------------------------------------------------------------ RCCL exchange steps (comm_{init,allreduce_async,wait})
+ * One process per GPU over xGMI.  Replaces nn.DataParallel's gather / reduce_add onto GPU 0 (base/base_trainer.py:33-38) and the
+ * SyncBN master/slave exchange (utils/sync_batchnorm/batchnorm.py:105-126: torch.cuda.comm.reduce_add / broadcast_coalesced at
+ * :117,120; comm.py:102-133) for hosts that do not use torch.distributed (the Python drop-in's default transport is
+ * torch.distributed "nccl" = the same RCCL; SEGMI_COMM=abi routes its gradient buckets through these entry points instead).
+ * RCCL is bound at run time (dlopen; segmi_comm_available() == 0 when no librccl can be found): no link-time dependency.
+ *   rank 0: segmi_comm_get_unique_id -> ship the segmi_comm_unique_id_bytes() bytes to every rank by any means -> all ranks:
+ *   segmi_comm_init(&c, world, rank, id) on their current HIP device.
+ *   segmi_comm_allreduce_async / _allgather_async: the communicator's side stream waits for everything enqueued on `stream` so
+ *   far (the buffer is complete), runs the collective (sum, or average when `average`; all-gather of count_per_rank floats per rank)
+ *   and records an event; segmi_comm_wait(c, s) makes stream s wait for the communicator's LAST collective.  No host sync. */
+typedef struct segmi_comm segmi_comm;
+int segmi_comm_available(void);
+int segmi_comm_unique_id_bytes(void);
+int segmi_comm_get_unique_id(void* id_out, size_t bytes);
+int segmi_comm_init(segmi_comm** comm_out, int world, int rank, const void* unique_id, size_t bytes);
+int segmi_comm_world(const segmi_comm* comm);
+int segmi_comm_allreduce_async(segmi_comm* comm, const float* send, float* recv, size_t count, int average, segmi_stream_t stream);
+int segmi_comm_allgather_async(segmi_comm* comm, const float* send, float* recv, size_t count_per_rank, segmi_stream_t stream);
+int segmi_comm_wait(segmi_comm* comm, segmi_stream_t stream);
+int segmi_comm_destroy(segmi_comm* comm);
+
 /* ------------------------------------------------------------------ training-time augmentation */
 /* The cv2 / PIL sequence of BaseDataSet._augmentation, _val_augmentation and __getitem__ (base/base_dataset.py:40-136) on the
  * device, one call per stage and sample; images are uint8 HWC (3 channels), labels int32 HW, all device memory; the random

@@ -72,7 +72,7 @@ def build(force=False, verbose=True):
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        cmd = ["g++", "-shared", "-o", LIB] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64"]
+        cmd = ["g++", "-shared", "-o", LIB] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)

@@ -329,6 +329,7 @@ class DeepLab(BaseModel):
             low_level_channels = 128
         self.ASSP = ASSP(in_channels=2048, output_stride=output_stride)
         self.decoder = Decoder(low_level_channels, num_classes)
+        snn.link_conv_bn(self)        # conv -> BN pairs: BN statistics from the convolution's epilogue from the first step on
         if freeze_bn:
             self.freeze_bn()
         if freeze_backbone:

@@ -97,6 +97,7 @@ class PSPNet(BaseModel):
             snn.Conv2d(width // 4, num_classes, 1))
 
         initialize_weights(self.master_branch, self.auxiliary_branch)
+        snn.link_conv_bn(self)        # conv -> BN pairs: BN statistics from the convolution's epilogue from the first step on
         if freeze_bn:
             self.freeze_bn()
         if freeze_backbone:

@@ -65,6 +65,7 @@ class UNet(BaseModel):
         self.up4 = decoder(128, 64)
         self.final_conv = snn.Conv2d(64, num_classes, kernel_size=1)
         self._initialize_weights()
+        snn.link_conv_bn(self)        # conv -> BN pairs: BN statistics from the convolution's epilogue from the first step on
         if freeze_bn:
             self.freeze_bn()
 

@@ -103,6 +103,15 @@ SIGNATURES = {
     "segmi_pyramid_up_workspace": (sz, [i32, i32, i32, i32, i32, vp, vp]),
     "segmi_pyramid_up_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_pyramid_up_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "segmi_comm_available": (i32, []),
+    "segmi_comm_unique_id_bytes": (i32, []),
+    "segmi_comm_get_unique_id": (i32, [vp, sz]),
+    "segmi_comm_init": (i32, [C.POINTER(vp), i32, i32, vp, sz]),
+    "segmi_comm_world": (i32, [vp]),
+    "segmi_comm_allreduce_async": (i32, [vp, vp, vp, sz, i32, vp]),
+    "segmi_comm_allgather_async": (i32, [vp, vp, vp, sz, vp]),
+    "segmi_comm_wait": (i32, [vp, vp]),
+    "segmi_comm_destroy": (i32, [vp]),
     "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "segmi_aug_rotate": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     "segmi_aug_blur": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),

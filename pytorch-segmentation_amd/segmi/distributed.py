@@ -11,9 +11,13 @@ along N across ranks instead; the only exchange steps per iteration are
     in forward and all-reduce of [sum dy, sum dy*xhat] in backward
     (utils/sync_batchnorm/batchnorm.py:70-93,105-126 of the reference).
 
-xGMI is point-to-point (7 links per GPU), so ring collectives are per-link bound: buckets are large
-(64 MiB default -> 4 collectives for PSPNet-R50's 206 MB of gradients) to amortise the ring latency
-while still leaving the first bucket's transfer overlapped with ~3/4 of backward.
+xGMI is point-to-point (7 links per GPU), so collectives are per-link bound: buckets are large where
+their transfer hides behind the rest of backward and small where it cannot.  Gradients arrive in
+reverse parameter order; every bucket takes HALF of the bytes that are still to come, clamped to
+[4 MiB, 64 MiB] (`bucket_schedule`): PSPNet-R50's 206 MB go out as 64 / 64 / 39 / 20 / 10 / 5 / 5 MB, so
+the collective that starts when backward ends — the stem and layer1 gradients, which nothing can
+overlap — moves 5 MB instead of the 14 MB remainder of a uniform 64 MiB split, and the early, large
+ones still amortise the launch latency (DESIGN.md §7 has the expected-scaling model).
 
 Everything here is device-agnostic torch.distributed code (tests run it on CPU with gloo, world 2);
 on the GPU box backend "nccl" IS RCCL.
@@ -48,6 +52,19 @@ def global_batch_mean(local_sum, local_den, group=None):
     return local_sum / den, den
 
 
+def bucket_schedule(total_bytes, max_bytes=64 << 20, min_bytes=4 << 20):
+    """Capacities (bytes) of the gradient buckets in FILL order (= the order backward produces gradients): each bucket holds half
+    of what remains, clamped to [min_bytes, max_bytes]; the last one takes the rest."""
+    caps, left = [], int(total_bytes)
+    while left > 0:
+        c = min(max(left // 2, min_bytes), max_bytes)
+        if left - c < min_bytes // 2:          # do not leave a sliver behind
+            c = left
+        caps.append(c)
+        left -= c
+    return caps
+
+
 class GradAllReducer:
     """Bucketed, overlapped gradient averaging for the parameters of one model replica.
 
@@ -56,7 +73,8 @@ class GradAllReducer:
     Usage per iteration:  zero_grad() -> forward -> loss.backward() -> finish() -> optimizer.step().
     """
 
-    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True, always_reduce=False):
+    def __init__(self, params, process_group=None, bucket_bytes=None, average=True, always_reduce=False):
+        """bucket_bytes: None = the backward-order schedule (`bucket_schedule`); an int = uniform buckets of that size."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if _is_dist() else 1
         self.average = average
@@ -72,10 +90,12 @@ class GradAllReducer:
         order = list(reversed(self.params))
         self.buckets = []          # dict(buf, params, pending, launched, work)
         self._where = {}           # id(param) -> (bucket index, view)
+        caps = bucket_schedule(sum(p.numel() * p.element_size() for p in order)) if bucket_bytes is None else None
         cur, cur_bytes = [], 0
         for p in order:
             nb = p.numel() * p.element_size()
-            if cur and cur_bytes + nb > bucket_bytes:
+            cap = bucket_bytes if caps is None else caps[min(len(self.buckets), len(caps) - 1)]
+            if cur and cur_bytes + nb > cap:
                 self._make_bucket(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
@@ -93,6 +113,12 @@ class GradAllReducer:
             _ops.mark_reducer_hooks(self._slot_params)
             for p in self._slot_params:
                 p.grad = None
+        # SEGMI_COMM=abi: the buckets travel through libsegmi's own RCCL entry points (include/segmi.h segmi_comm_*, segmi/comm.py)
+        # instead of torch.distributed's communicator — the transport of a non-torch host, selectable here for A/B
+        self._abi = None
+        if self.collective and os.environ.get("SEGMI_COMM") == "abi" and dev.type == "cuda":
+            from .comm import AbiCommunicator
+            self._abi = AbiCommunicator(group=process_group, device=dev)
         self.counters = {"adopted": 0, "copied": 0}      # gradients found in place in their slot / copied into it (diagnostics, tests)
         self._fired = set()        # id(param) of the parameters whose gradient arrived in the current iteration
         self.check_unused = os.environ.get("SEGMI_DDP_CHECK_UNUSED", "0") == "1"
@@ -152,6 +178,12 @@ class GradAllReducer:
         if not self.collective:
             return
         op = dist.ReduceOp.SUM
+        if self._abi is not None:
+            if self._ops is not None:
+                self._ops.wgrad_stream_join()
+            self._abi.all_reduce_async(b["buf"], average=self.average)     # on the communicator's side stream, behind the compute stream
+            b["work"], b["scale"] = self._abi, False
+            return
         if self.side is not None:
             if self._ops is not None:
                 self._ops.wgrad_stream_join()     # filter gradients launched on the wgrad side stream belong to this bucket too
@@ -199,7 +231,7 @@ class GradAllReducer:
         for i, b in enumerate(self.buckets):
             w = b["work"]
             if w is not None:
-                w.wait()                      # nccl: current stream waits for the collective's stream
+                w.wait()                      # nccl / abi: current stream waits for the collective's stream
                 if b.get("scale"):
                     b["buf"].div_(self.world)
                 b["work"] = None
@@ -325,7 +357,7 @@ class DistributedModel(torch.nn.Module):
     base/base_trainer.py:47-51, trainer.py:41-43) plus the gradient reducer.  Parameters are
     broadcast from rank 0 at construction so all replicas start identical."""
 
-    def __init__(self, module, process_group=None, bucket_bytes=64 << 20, always_reduce=False):
+    def __init__(self, module, process_group=None, bucket_bytes=None, always_reduce=False):
         super().__init__()
         self.module = module
         if _is_dist() and dist.get_world_size(process_group) > 1:

@@ -105,6 +105,43 @@ class Dropout(nn.Dropout):
         return ops.dropout(x, self.p, self.training, channelwise=False)
 
 
+def link_conv_bn(root):
+    """Mark every dense Conv2d whose output a BatchNorm2d consumes (`_bn_consumer`), from the module REGISTRATION order: inside
+    one parent, a BatchNorm2d child pairs with the last convolution registered before it — `conv1, bn1, conv2, bn2, ...` of the
+    residual blocks (models/resnet.py:80-99), `Sequential(conv, bn, relu, ...)` (models/unet.py:12-21, models/pspnet.py:17-30), a
+    container whose LAST leaf is a convolution followed by a BatchNorm2d of the parent (the deep-base stem + bn1,
+    SeparableConv2d.pointwise + the Block's BatchNorm2d, models/deeplabv3_plus.py:70-132).  A marked convolution emits the BN
+    statistics partials from its epilogue from the FIRST training step on (ops._BN_FUSE); a wrong mark only costs an unused
+    epilogue (the BN layer takes partials only from the very tensor it receives), a missed pair is found at run time
+    (ops._note_bn_consumer) from the second step on.  Returns the number of marked convolutions."""
+    marked = 0
+
+    def last_leaf(m):
+        kids = list(m.children())
+        return last_leaf(kids[-1]) if kids else m
+
+    def walk(parent):
+        nonlocal marked
+        last = None
+        for child in parent.children():
+            if isinstance(child, BatchNorm2d):
+                if isinstance(last, Conv2d) and not last.depthwise:
+                    if not last._bn_consumer:
+                        marked += 1
+                    last._bn_consumer = True
+                last = None
+                continue
+            if isinstance(child, Conv2d):
+                last = child
+                continue
+            if any(True for _ in child.children()):
+                walk(child)
+                leaf = last_leaf(child)
+                last = leaf if isinstance(leaf, Conv2d) else None
+    walk(root)
+    return marked
+
+
 def sync_tail(bn, downsample):
     """True when `bn` and the BN of a projection shortcut `downsample` = Sequential(conv, BN) are SyncBN layers that can share
     their collectives (ops.sync_batch_norm_residual_tail): the block then evaluates relu(bn(.) + BN(conv(x))) as one node."""

@@ -160,7 +160,7 @@ def _filter_krsc(w, Ce):
 # in-place add) and the reducer's hook finds the gradient already in place — no per-parameter copy in the N > 1 path.
 # A slot is handed out once per iteration (a filter used twice in one graph accumulates through the ordinary path).
 _GRAD_SLOTS = {}          # id(parameter) -> [view into the bucket, taken this iteration, weakref to the parameter]
-_HOOK_SAFE = weakref.WeakSet()   # parameters whose post-accumulate hook is a GradAllReducer's (it joins the side stream itself)
+_HOOK_SAFE = {}           # id(parameter) -> weakref: parameters whose post-accumulate hook is a GradAllReducer's (it joins the side stream itself)
 
 
 def register_grad_slots(views):
@@ -172,7 +172,6 @@ def register_grad_slots(views):
             e = _GRAD_SLOTS.get(id(p))
             if e is not None and e[2]() is p:
                 del _GRAD_SLOTS[id(p)]
-            _HOOK_SAFE.discard(p)
         else:
             _GRAD_SLOTS[id(p)] = [v, False, weakref.ref(p)]
     for k in [k for k, e in _GRAD_SLOTS.items() if e[2]() is None]:
@@ -183,7 +182,15 @@ def mark_reducer_hooks(params, on=True):
     """A GradAllReducer declares that the post-accumulate hook on these parameters is its own (it waits for the filter-gradient
     side stream before it reads a gradient): such a hook does not force the filter gradient in order (see _on_wgrad_stream)."""
     for p in params:
-        (_HOOK_SAFE.add if on else _HOOK_SAFE.discard)(p)
+        if on:
+            _HOOK_SAFE[id(p)] = weakref.ref(p)
+        else:
+            _HOOK_SAFE.pop(id(p), None)
+
+
+def _hook_safe(p):
+    r = _HOOK_SAFE.get(id(p))
+    return r is not None and r() is p
 
 
 def reset_grad_slots(params=None):
@@ -473,7 +480,7 @@ def _on_wgrad_stream(weight, tensors, fn):
         wgrad_stream_join()
         _WGRAD_SIDE["in_order_reuse"] += 1
         return fn()
-    if weight._backward_hooks or (getattr(weight, "_post_accumulate_grad_hooks", None) and weight not in _HOOK_SAFE):
+    if weight._backward_hooks or (getattr(weight, "_post_accumulate_grad_hooks", None) and not _hook_safe(weight)):
         _WGRAD_SIDE["in_order_hooks"] += 1
         return fn()
     if task >= 0:

@@ -267,3 +267,24 @@ def test_syncbn_collectives_of_parallel_layers_are_batched():
     for r in range(world):
         ok, n_one, n_many = ret[r]
         assert ok and n_one == 6 and n_many == 2, ret[r]
+
+
+def test_bucket_schedule_follows_backward_order():
+    """segmi.distributed.bucket_schedule: every bucket holds half of the bytes still to come, clamped to [4, 64] MiB — large
+    collectives while the rest of backward can hide them, a small one for the gradients produced last."""
+    from segmi.distributed import GradAllReducer, bucket_schedule
+    mb = 1 << 20
+    caps = bucket_schedule(206 * mb)
+    assert sum(caps) == 206 * mb and caps[0] == caps[1] == 64 * mb and caps[-1] <= 6 * mb and all(a >= b for a, b in zip(caps, caps[1:]))
+    assert bucket_schedule(3 * mb) == [3 * mb] and sum(bucket_schedule(26 * mb)) == 26 * mb and len(bucket_schedule(26 * mb)) == 4
+    assert all(c >= 2 * mb for c in bucket_schedule(1000 * mb)) and max(bucket_schedule(1000 * mb)) == 64 * mb
+    # the reducer lays its buckets out accordingly (reverse parameter order = the order backward produces gradients)
+    net = torch.nn.Sequential(*[torch.nn.Linear(1024, 1024, bias=False) for _ in range(24)])          # 24 x 4 MiB
+    red = GradAllReducer(net.parameters())
+    sizes = [b["buf"].numel() * 4 // mb for b in red.buckets]
+    assert sum(sizes) == 96 and sizes[0] == 48 and sizes[-1] == 4 and all(a >= b for a, b in zip(sizes, sizes[1:])), sizes
+    assert red.buckets[0]["params"][0] is list(net.parameters())[-1]                                    # last layer's gradient arrives first
+    red.remove()
+    uni = GradAllReducer(net.parameters(), bucket_bytes=16 * mb)
+    assert [b["buf"].numel() * 4 // mb for b in uni.buckets] == [16] * 6
+    uni.remove()

@@ -132,7 +132,9 @@ def _worker(rank, world, port, ret):
         X = torch.randn(per * world, 3, 72, 88, generator=g)
         T = torch.randint(0, classes, (per * world, 72, 88), generator=g)
         crit = CrossEntropyLoss2d(ignore_index=255)
+        os.environ["SEGMI_DDP_CHECK_UNUSED"] = "1"        # every finish_gradients() also checks that the ranks agree on which parameters fired
         m = DataParallelWithCallback(convert_model(_build(classes, 3 + rank, dev)))   # different init per rank: broadcast must fix it
+        assert len(m.reducer.buckets) >= 6 and m.reducer.check_unused                   # backward-order schedule: 64 / 64 / 39 / ... MB
         m.zero_grad()
         out, aux = m(X[rank * per:(rank + 1) * per].to(dev))
         t = T[rank * per:(rank + 1) * per].to(dev)
@@ -140,8 +142,11 @@ def _worker(rank, world, port, ret):
         loss.backward()
         m.finish_gradients()
         torch.cuda.synchronize()
-        res = {"out": out.detach().cpu(), "loss": loss.item(),
-               "grads": {k: p.grad.detach().cpu().clone() for k, p in m.module.named_parameters()},
+        # (gradients travel as ONE flat tensor per run: every tensor in the manager dict costs a file descriptor per access)
+        names = [k for k, _ in m.module.named_parameters()]
+        sizes = [p.numel() for _, p in m.module.named_parameters()]
+        res = {"out": out.detach().cpu(), "loss": loss.item(), "names": names, "sizes": sizes,
+               "grads": torch.cat([p.grad.detach().reshape(-1) for _, p in m.module.named_parameters()]).cpu(),
                "rm": m.module.state_dict()["layer4.2.bn3.running_mean"].cpu(), "rv": m.module.state_dict()["initial.1.running_var"].cpu()}
         if rank == 0:
             # reference: ONE process, plain BN, the global batch
@@ -150,10 +155,28 @@ def _worker(rank, world, port, ret):
             crit1 = CrossEntropyLoss2d(ignore_index=255, process_group=None)     # single process: no collective
             rl = crit1(ro, T.to(dev)) + 0.4 * crit1(ra, T.to(dev))
             rl.backward()
-            res["ref"] = {"out": ro.detach().cpu(), "loss": rl.item(), "grads": {k: p.grad.detach().cpu() for k, p in ref.named_parameters()},
+            res["ref"] = {"out": ro.detach().cpu(), "loss": rl.item(), "grads": torch.cat([p.grad.detach().reshape(-1) for _, p in ref.named_parameters()]).cpu(),
                           "rm": ref.state_dict()["layer4.2.bn3.running_mean"].cpu(), "rv": ref.state_dict()["initial.1.running_var"].cpu()}
+        # second iteration with the fused SGD applied bucket by bucket right after each bucket's all-reduce (finish_gradients(opt)):
+        # the replicas must stay bit-identical and the update must be SGD on the averaged gradients
+        from segmi.optim import SGD
+        opt = SGD(m.module.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        assert m.attach_optimizer(opt)
+        before = {k: p.detach().clone() for k, p in m.module.named_parameters()}
+        m.zero_grad()
+        out, aux = m(X[rank * per:(rank + 1) * per].to(dev))
+        (crit(out, t) + 0.4 * crit(aux, t)).backward()
+        m.finish_gradients(opt)
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k, p in m.module.named_parameters():
+            want = before[k] - 0.05 * (p.grad + 1e-4 * before[k])          # first step: momentum buffer = gradient (+ weight decay)
+            worst = max(worst, (p.detach() - want).abs().max().item() / (want.abs().max().item() + 1e-12))
+        res["sgd_rel_err"] = worst
+        res["w_after"] = torch.cat([p.detach().reshape(-1) for _, p in m.module.named_parameters()]).cpu()
         ret[rank] = res
     finally:
+        os.environ.pop("SEGMI_DDP_CHECK_UNUSED", None)
         dist.destroy_process_group()
 
 
@@ -162,6 +185,7 @@ def test_two_rank_syncbn_step_equals_global_batch_step(cuda):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    ret = {r: ret[r] for r in range(world)}          # one fetch per rank
     ref = ret[0]["ref"]
     per = ret[0]["out"].shape[0]
     # forward: each shard's logits equal the corresponding rows of the global-batch run (same BN statistics)
@@ -179,12 +203,17 @@ def test_two_rank_syncbn_step_equals_global_batch_step(cuda):
     # this 50-layer net on 9x11 maps (batch-statistics gradients are ill conditioned, DESIGN.md §5: the two runs merge their
     # BN moments in a different order); the tight equality is asserted on the shallow net above.
     errs = []
-    for k, gref in ref["grads"].items():
-        g0, g1 = ret[0]["grads"][k], ret[1]["grads"][k]
-        assert torch.equal(g0, g1), k
+    assert torch.equal(ret[0]["grads"], ret[1]["grads"])
+    off = 0
+    for k, n in zip(ret[0]["names"], ret[0]["sizes"]):
+        g0, gref = ret[0]["grads"][off:off + n], ref["grads"][off:off + n]
+        off += n
         errs.append((g0.double() - gref.double()).norm().item() / (gref.double().norm().item() + 1e-30))
     errs.sort()
     assert errs[len(errs) // 2] <= 0.1 and errs[-1] <= 0.3, (errs[len(errs) // 2], errs[-1])
+    # per-bucket fused SGD after each bucket's all-reduce: SGD on the averaged gradient, replicas bit-identical afterwards
+    assert ret[0]["sgd_rel_err"] <= 1e-5 and ret[1]["sgd_rel_err"] <= 1e-5, (ret[0]["sgd_rel_err"], ret[1]["sgd_rel_err"])
+    assert torch.equal(ret[0]["w_after"], ret[1]["w_after"])
 
 
 def _nccl_worker(rank, world, port, ret):
@@ -228,6 +257,27 @@ def _nccl_worker(rank, world, port, ret):
             optr.step()
         seg_ok = len(red2.buckets) >= 2 and opt2.num_segments == len(red2.buckets) + 1 and all(
             torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(net2.parameters(), netr.parameters()))
+        # the same buckets through libsegmi's own RCCL entry points (SEGMI_COMM=abi; include/segmi.h segmi_comm_*)
+        from segmi.comm import AbiCommunicator
+        os.environ["SEGMI_COMM"] = "abi"
+        try:
+            net3 = copy.deepcopy(net)
+            red3 = GradAllReducer(net3.parameters(), bucket_bytes=16 << 10, always_reduce=True)
+            abi_used = red3._abi is not None and red3._abi.world == 1
+            red3.zero_grad()
+            net3(x).square().mean().backward()
+            red3.finish()
+            abi_ok = all(torch.allclose(got[k], p.grad, rtol=1e-6, atol=1e-8) for k, p in net3.named_parameters())
+            red3.remove()
+        finally:
+            os.environ.pop("SEGMI_COMM", None)
+        comm = AbiCommunicator(world=1, rank=0, device=dev)
+        v = torch.arange(1000.0, device=dev).square()                     # produced on the compute stream right before the collective
+        w = comm.all_reduce_async(v.clone(), average=True)
+        gathered = comm.all_gather_async(v)
+        comm.wait()
+        abi_ok = abi_ok and abi_used and torch.equal(w, v) and torch.equal(gathered, v)
+        comm.close()
         ctx = SyncBNContext()
         part = torch.arange(12.0, device=dev)
         parts, n = ctx.gather_stats(part)
@@ -235,7 +285,7 @@ def _nccl_worker(rank, world, port, ret):
         t = torch.ones(3, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         torch.cuda.synchronize()
-        ret[rank] = {"ok": ok, "nb": len(red.buckets), "gather": n, "seg_ok": seg_ok}
+        ret[rank] = {"ok": ok, "nb": len(red.buckets), "gather": n, "seg_ok": seg_ok, "abi_ok": abi_ok}
     finally:
         dist.destroy_process_group()
 
@@ -247,7 +297,7 @@ def test_rccl_call_path_single_rank(cuda):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
-    assert ret[0]["ok"] and ret[0]["nb"] >= 2 and ret[0]["gather"] == 1 and ret[0]["seg_ok"]
+    assert ret[0]["ok"] and ret[0]["nb"] >= 2 and ret[0]["gather"] == 1 and ret[0]["seg_ok"] and ret[0]["abi_ok"]
 
 
 def _trainer_worker(rank, world, port, tmp, ret):
@@ -497,3 +547,25 @@ def test_grad_slots_do_not_outlive_their_parameters(cuda):
     w2 = torch.nn.Parameter(torch.randn(16, 16, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last))
     ops._GRAD_SLOTS[id(w2)] = stale
     assert ops._take_grad_slot(w2) is None and id(w2) not in ops._GRAD_SLOTS
+
+
+def test_bench_launcher_two_ranks_on_one_gpu(cuda):
+    """`python bench.py --gpus 2` drives both ranks by itself (re-executes under torch.distributed.run).  On the one-GPU test box
+    the ranks share cuda:0 and the collectives go through gloo (RCCL needs one GPU per rank): the launcher path, the N > 1 step
+    (bucketed all-reduce + per-bucket SGD) and the JSON line's multi-rank semantics are what is checked — value = WHOLE-JOB img/s,
+    global_batch = ranks x per-GPU batch, rccl_ranks = 0 because no RCCL communicator exists."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg1", "--steps", "3", "--warmup", "1", "--no-cpu",
+                        "--no-roofline", "--no-alt"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    c = d["config"]
+    assert c["global_batch"] == 4 and c["parallelism"] == "dp2" and c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0
+    assert len(c["grad_buckets_mb"]) >= 3 and abs(sum(c["grad_buckets_mb"]) - 26.36 * 4 / 1.048576) < 6      # UNet: 26.36 M parameters
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) <= 0.02 * d["value"]
+    assert d["roofline"] is None and d["cpu_baseline"] is None and d["alt"] is None

@@ -277,5 +277,14 @@ r4d)
   ( timeout 1800 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r4d_pytest_gpu.log
   tail -6 gpurun_out/r4d_pytest_gpu.log | cut -c1-400
   ( timeout 300 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 | cut -c1-200 ) ;;
+r4e)
+  # round 4, call 5: re-run of the files that failed in r4d (WeakSet membership of tensors) + the new distributed-readiness tests
+  ( timeout 1500 python -m pytest tests/test_augment.py tests/test_ops_gpu.py tests/test_trainer_gpu.py tests/test_distributed_gpu.py tests/test_determinism_gpu.py tests/test_graph_gpu.py -m gpu -q -rf -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|Error|assert" | tail -40 ) > gpurun_out/r4e_tests.log
+  tail -12 gpurun_out/r4e_tests.log | cut -c1-400 ;;
+r4f)
+  ( timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_distributed_gpu.py tests/test_determinism_gpu.py tests/test_fullsize_golden_gpu.py -m gpu -q -rf -s -p no:cacheprovider -k "pairing or two_rank or reducer_waits or determinism or repeatable or fullsize or rccl or bench_launcher or grad_slots or side_stream" 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|Error|assert" | tail -40 ) > gpurun_out/r4f_tests.log
+  tail -14 gpurun_out/r4f_tests.log | cut -c1-700
+  ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4f_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4f_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1 ;;
 esac
 done
