@@ -275,11 +275,23 @@ def main():
         side = segmi_ops.get_wgrad_stream()["on"]
         segmi_ops.set_wgrad_stream(False)      # per-kernel durations are taken with every launch in order on ONE stream
         try:
-            with KernelTimer() as kt:      # every rank runs the instrumented step (it contains collectives)
+            with KernelTimer(membound=True) as kt:      # every rank runs the instrumented step (it contains collectives)
                 step()
         finally:
             segmi_ops.set_wgrad_stream(side)
-        summ = kt.summary()
+        every = kt.summary()
+        summ = {k: r for k, r in every.items() if not k.startswith("segmi_")}          # the convolution launches (MFMA-bound)
+        mem = {k: r for k, r in every.items() if k.startswith("segmi_")}               # the HBM-bound C-ABI calls (BN, depthwise, losses, resize, pooling)
+        mem_ms, mem_b = sum(r["total_ms"] for r in mem.values()), sum(r["bytes"] for r in mem.values())
+        hbm = {"bound": "hbm", "peak": 8.0, "unit": "TB/s", "ms_per_step": round(mem_ms, 3), "algorithmic_gb_per_step": round(mem_b / 1e9, 3),
+               "achieved": round(mem_b / (mem_ms * 1e-3) / 1e12, 3) if mem_ms else None,
+               "frac": round(mem_b / (mem_ms * 1e-3) / 8.0e12, 4) if mem_ms else None,
+               "scope": "every HBM-bound C-ABI call of the instrumented step (HIP events per call, event pairs add ~2 us to calls shorter than "
+                        "~10 us); bytes = algorithmic (each operand tensor once; Lovasz: 88 B per (class, pixel) = logits + 8-byte sort key "
+                        "through emit, 4 radix passes and the scan + G)",
+               "top": [{"call": k, "launches": r["launches"], "ms_per_step": round(r["total_ms"], 3), "gb": round(r["bytes"] / 1e9, 3),
+                        "tbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e12, 2), "frac": round(r["bytes"] / (r["total_ms"] * 1e-3) / 8.0e12, 3)}
+                       for k, r in sorted(mem.items(), key=lambda kv: -kv[1]["total_ms"])[:8]]}
         tot_ms = sum(r["total_ms"] for r in summ.values())
         tot_fl = sum(r["flops"] for r in summ.values())              # EXECUTED (Winograd: transform-domain) FLOPs
         tot_eff = sum(r["eff_flops"] for r in summ.values())         # algorithmic FLOPs of the direct convolutions they stand for
@@ -325,6 +337,7 @@ def main():
                 # executed_step_frac: FLOPs the matrix kernels actually executed in one step / step time / peak (a utilisation);
                 # effective_step_frac: the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as
                 # written) / step time / peak — an effective-throughput figure that may exceed what any fp32 kernel can execute
+                "hbm_bound_calls": hbm,
                 "executed_step_frac": round(tot_fl / step_s / 1e12 / peak, 4),
                 "effective_step_frac": round(value / world * flops_img / 1e12 / peak, 4),
                 "reference_formulation_flops_per_step": flops_img * nb,

@@ -221,18 +221,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// part: [gridDim.y][2][Cp]
+// part: [gridDim.y][2][Cp] DOUBLES.  The two sums cancel heavily (sum dy*xhat is orders of magnitude below sum |dy*xhat|), and
+// aten's CPU kernel — the reference — accumulates them in double (at::acc_type<float, false>): so does this one.  The kernel is
+// HBM-bound (2-3 fp32 tensor reads per element against 2 fp64 adds per element on a 64-lane fp64 pipe): the wider accumulators
+// are free, and d gamma / d beta / the dx correction terms carry no accumulation error beyond their final rounding to fp32.
+struct D4 { double x, y, z, w; };
+__device__ __forceinline__ D4 dzero4() { return D4{0.0, 0.0, 0.0, 0.0}; }
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                             int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ part) {
+                                                            double* __restrict__ part) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 < c4n;
-    float4 s0 = zero4(), s1 = zero4();
+    D4 s0 = dzero4(), s1 = dzero4();
     if (cok) {
-        const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
+        const float4 mu = ld4(mean + c4 * 4);
         float4 sc = zero4(), sh = zero4();
         if (RELU && !y) { sc = ld4(scale + c4 * 4); sh = ld4(shift + c4 * 4); }
         // four rows per trip: all 8 (12 with a saved output) loads are issued before the first use
@@ -241,9 +246,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             if (RELU) {
                 g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
             }
-            s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
-            s1.x += g.x * (v.x - mu.x) * is.x; s1.y += g.y * (v.y - mu.y) * is.y;
-            s1.z += g.z * (v.z - mu.z) * is.z; s1.w += g.w * (v.w - mu.w) * is.w;
+            s0.x += (double)g.x; s0.y += (double)g.y; s0.z += (double)g.z; s0.w += (double)g.w;
+            // sum dy * (x - mean) in double like aten (`dotp += (x - mean) * dy` with a double mean); invstd multiplies the block's sum
+            s1.x = fma((double)g.x, (double)v.x - (double)mu.x, s1.x); s1.y = fma((double)g.y, (double)v.y - (double)mu.y, s1.y);
+            s1.z = fma((double)g.z, (double)v.z - (double)mu.z, s1.z); s1.w = fma((double)g.w, (double)v.w - (double)mu.w, s1.w);
         };
         // ReLU mask: from the saved output, or (no residual) recomputed with the forward's own fmaf — bit-identical
         // to what bn_apply_kernel evaluated, and one full read of y less
@@ -266,13 +272,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             fold(g, v, RELU ? outv(r, v) : zero4());
         }
     }
-    __shared__ float4 sm0[256], sm1[256];
+    __shared__ D4 sm0[256], sm1[256];
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
     sm0[t] = s0; sm1[t] = s1;
     __syncthreads();
     for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
         if ((int)threadIdx.y < s) {
-            float4 a = sm0[t], b = sm0[t + s * blockDim.x];
+            D4 a = sm0[t], b = sm0[t + s * blockDim.x];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm0[t] = a;
             a = sm1[t]; b = sm1[t + s * blockDim.x];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm1[t] = a;
@@ -281,18 +287,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     if (threadIdx.y == 0 && cok) {
         const int Cp = c4n * 4;
-        float* o = part + (long)blockIdx.y * 2 * Cp;
-        st4(o + c4 * 4, sm0[t]);
-        st4(o + Cp + c4 * 4, sm1[t]);
+        double* o = part + (long)blockIdx.y * 2 * Cp + c4 * 4;
+        const D4 a = sm0[t], b = sm1[t];
+        const float4 is = ld4(invstd + c4 * 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+        o[Cp] = b.x * (double)is.x; o[Cp + 1] = b.y * (double)is.y; o[Cp + 2] = b.z * (double)is.z; o[Cp + 3] = b.w * (double)is.w;
     }
 }
 
-// out[i] = sum_p part[p][i]; block = (32 elements, 8 part lanes), LDS tree over the lanes
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+// out[i] = (float) sum_p part[p][i] in double; block = (32 elements, 8 part lanes), LDS tree over the lanes
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, int nparts, int n, float* __restrict__ out) {
     const int i = blockIdx.x * 32 + threadIdx.x;
-    float a = 0.f;
+    double a = 0.0;
     if (i < n) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent loads per step
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // four independent loads per step
         int p = threadIdx.y;
         for (; p + 24 < nparts; p += 32) {
             a0 += part[(long)p * n + i]; a1 += part[(long)(p + 8) * n + i];
@@ -301,14 +309,14 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
         for (; p < nparts; p += 8) a0 += part[(long)p * n + i];
         a = (a0 + a1) + (a2 + a3);
     }
-    __shared__ float sm[8][33];
+    __shared__ double sm[8][33];
     sm[threadIdx.y][threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.y == 0 && i < n) {
-        float t = 0.f;
+        double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
-        out[i] = t;
+        out[i] = (float)t;
     }
 }
 
@@ -529,7 +537,7 @@ static int bwd_parts(long rows, int C) {
 }
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
     const int Cp = (C + 3) & ~3;
-    return (size_t)bwd_parts(rows, C) * 2 * Cp * sizeof(float);
+    return (size_t)bwd_parts(rows, C) * 2 * Cp * sizeof(double);
 }
 
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
@@ -542,9 +550,10 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     const int parts = bwd_parts(rows, C);
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (float*)workspace);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (float*)workspace);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, 2 * C, sums);
+    if ((uintptr_t)workspace & 7) return SEGMI_ERR_ALIGN;
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const double*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
 

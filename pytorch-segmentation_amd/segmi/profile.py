@@ -19,6 +19,11 @@ def _b4(*elems):
     return 4 * sum(int(e) for e in elems)
 
 
+def _dw_bytes(d):
+    d = d._obj if hasattr(d, "_obj") else d          # ctypes byref() wrapper or the structure itself
+    return 4 * (d.N * d.H * d.W * d.C + d.N * d.P * d.Q * d.C)
+
+
 # HBM-bound entry points of the C ABI -> algorithmic bytes of one call, from its positional arguments (include/segmi.h order):
 # every tensor the call must read or write crosses HBM once.  Used by KernelTimer(membound=True), which times these calls
 # with HIP events exactly like the convolutions (tools/membound_ops.py prints the table).
@@ -43,6 +48,14 @@ MEMBOUND_BYTES = {
     "segmi_dropout": lambda a: _b4(2 * a[4] * a[5] * a[6]),
     "segmi_copy_rows": lambda a: _b4(2 * a[4] * a[5]),
     "segmi_nchw_to_nhwc": lambda a: _b4(2 * a[2] * a[3] * a[4] * a[5]),
+    # depthwise 3x3 (args: desc*, x, w, y, stream): input + output once; the filter gradient reads x and dy
+    "segmi_dwconv2d_fwd": lambda a: _dw_bytes(a[0]),
+    "segmi_dwconv2d_dgrad": lambda a: _dw_bytes(a[0]),
+    "segmi_dwconv2d_wgrad": lambda a: _dw_bytes(a[0]),
+    # Lovasz forward = softmax + per-class sort + Jaccard scan: logits read once (4 B), one 8-byte key per (class, pixel) written by
+    # the emit pass, read + written by each of the 4 radix passes and read by the scan (80 B), G written once (4 B)
+    "segmi_lovasz_fwd": lambda a: 88 * a[3] * a[4],
+    "segmi_lovasz_bwd": lambda a: _b4(3 * a[5] * a[6]),
     "segmi_relu_fwd": lambda a: _b4(2 * a[4] * a[5]),
     "segmi_add": lambda a: _b4(3 * a[6] * a[7]),
 }

@@ -286,5 +286,20 @@ r4f)
   tail -14 gpurun_out/r4f_tests.log | cut -c1-700
   ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4f_bench.log
   python -c "import json; d=json.loads(open('gpurun_out/r4f_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1 ;;
+r4g)
+  # fp64 accumulation in the BN backward reduction: re-run of the two fixed tests, BN / model tests, the four audits (distance from the
+  # fp64 gradient digests), cfg2 bench
+  ( timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_distributed_gpu.py tests/test_fullsize_golden_gpu.py tests/test_pspnet_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -s -p no:cacheprovider -k "pairing or two_rank_syncbn_step or fullsize or batch_norm or pspnet or unet" 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|Error|assert" | tail -40 ) > gpurun_out/r4g_tests.log
+  tail -6 gpurun_out/r4g_tests.log | cut -c1-300
+  python - <<'PY'
+import json
+d=json.load(open('gpurun_out/audit.json'))
+for k,v in sorted(d.items()):
+    if '/f32/' in k and 'grad_f64_rel_err_median' in v:
+        print(k, "grad f64 HIP med %.3e max %.3e | ref med %.3e max %.3e | ratio %.2f %.2f"%(v['grad_f64_rel_err_median'], v['grad_f64_rel_err_max'], v['ref_grad_f64_rel_err_median'], v['ref_grad_f64_rel_err_max'], v['grad_f64_rel_err_median']/v['ref_grad_f64_rel_err_median'], v['grad_f64_rel_err_max']/v['ref_grad_f64_rel_err_max']))
+PY
+  ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4g_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4g_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1
+  ( timeout 300 python tools/membound_ops.py cfg2 2>&1 | grep -v amdgpu.ids | head -8 ) ;;
 esac
 done
