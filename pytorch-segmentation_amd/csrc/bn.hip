@@ -13,6 +13,7 @@
 // (reference semantics: utils/sync_batchnorm/batchnorm.py:105-145, re-expressed with Chan's merge so
 // the multi-GPU result matches single-device global-batch F.batch_norm).
 #include "rowgeom.h"
+#include <cstdlib>
 
 namespace {
 
@@ -399,6 +400,91 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, i
     }
 }
 
+
+// ---- double-precision statistics (SEGMI_BN_STATS_F64=1, experiment / A-B): per-thread sums of x and x*x in double (aten's CPU
+// batch_norm accumulates in double), block tree in LDS, partial {n, sum, sumsq} doubles; the merge adds partials and finalizes with
+// var = sumsq / n - mean^2 in double.  part: [gridDim.y][3][C4*4] doubles.
+__global__ __launch_bounds__(256) void bn_stats_partial_f64_kernel(const float* __restrict__ x, int ld, long rows, int c4n, double* __restrict__ part) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool cok = c4 < c4n;
+    D4 s = dzero4(), q = dzero4();
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+    double cnt = 0.0;
+    if (cok)
+#pragma unroll 4
+        for (long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
+            const float4 v = ld4(x + r * ld + c4 * 4);
+            const double a = v.x, b = v.y, c = v.z, d = v.w;
+            s.x += a; s.y += b; s.z += c; s.w += d;
+            q.x = fma(a, a, q.x); q.y = fma(b, b, q.y); q.z = fma(c, c, q.z); q.w = fma(d, d, q.w);
+            cnt += 1.0;
+        }
+    __shared__ D4 ss[256], sq[256];
+    __shared__ double sn[256];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    ss[t] = s; sq[t] = q; sn[t] = cnt;
+    __syncthreads();
+    for (int k = blockDim.y >> 1; k > 0; k >>= 1) {
+        if ((int)threadIdx.y < k) {
+            D4 a = ss[t], b = ss[t + k * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; ss[t] = a;
+            a = sq[t]; b = sq[t + k * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sq[t] = a;
+            sn[t] += sn[t + k * blockDim.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const int C = c4n * 4;
+        double* o = part + (long)blockIdx.y * 3 * C + c4 * 4;
+        const D4 a = ss[t], b = sq[t];
+        o[0] = o[1] = o[2] = o[3] = sn[t];
+        o[C] = a.x; o[C + 1] = a.y; o[C + 2] = a.z; o[C + 3] = a.w;
+        o[2 * C] = b.x; o[2 * C + 1] = b.y; o[2 * C + 2] = b.z; o[2 * C + 3] = b.w;
+    }
+}
+template <bool FINAL>
+__global__ __launch_bounds__(256) void bn_stats_merge_f64_kernel(const double* __restrict__ part, int nparts, int Cp, float* __restrict__ out, FinalizeArgs fin) {
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    const bool cok = c < Cp;
+    double n = 0.0, s = 0.0, q = 0.0;
+    if (cok)
+        for (int i = threadIdx.y; i < nparts; i += 16) {
+            const double* p = part + (long)i * 3 * Cp;
+            n += p[c]; s += p[Cp + c]; q += p[2 * Cp + c];
+        }
+    __shared__ double sn[16][17], ss[16][17], sq[16][17];
+    sn[threadIdx.y][threadIdx.x] = n; ss[threadIdx.y][threadIdx.x] = s; sq[threadIdx.y][threadIdx.x] = q;
+    __syncthreads();
+    for (int k = 8; k > 0; k >>= 1) {
+        if ((int)threadIdx.y < k) {
+            sn[threadIdx.y][threadIdx.x] += sn[threadIdx.y + k][threadIdx.x];
+            ss[threadIdx.y][threadIdx.x] += ss[threadIdx.y + k][threadIdx.x];
+            sq[threadIdx.y][threadIdx.x] += sq[threadIdx.y + k][threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const double nn = sn[0][threadIdx.x], mean = ss[0][threadIdx.x] / nn;
+        const double m2 = fmax(sq[0][threadIdx.x] - mean * ss[0][threadIdx.x], 0.0);
+        if (FINAL) {
+            if (c == 0 && fin.num_batches_tracked) *fin.num_batches_tracked += 1;
+            finalize_channel(fin, c, (float)nn, (float)mean, (float)m2);
+        } else {
+            out[c] = (float)nn; out[Cp + c] = (float)mean; out[2 * Cp + c] = (float)m2;
+        }
+    }
+}
+int g_stats_f64 = -1;
+bool stats_f64() {
+    if (g_stats_f64 < 0) {
+        const char* e = getenv("SEGMI_BN_STATS_F64");
+        g_stats_f64 = (e && atoi(e) == 1) ? 1 : 0;
+    }
+    return g_stats_f64 == 1;
+}
+
 constexpr int STATS_MAX_PARTS = 512;
 int stats_parts(long rows) {
     long p = (rows + 127) / 128;  // >= 128 rows per partial block
@@ -414,7 +500,7 @@ extern "C" {
 
 size_t segmi_bn_stats_workspace(long rows, int C) {
     const int Cp = (C + 3) & ~3;
-    return (size_t)stats_parts(rows) * 3 * Cp * sizeof(float);
+    return (size_t)stats_parts(rows) * 3 * Cp * sizeof(double);      // (fp32 partials, or doubles under SEGMI_BN_STATS_F64)
 }
 
 int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, void* workspace, size_t workspace_bytes,
@@ -426,6 +512,11 @@ int segmi_bn_stats(const float* x, int ld, long rows, int C, float* partial, voi
     const int parts = stats_parts(rows);
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
+    if (stats_f64()) {
+        hipLaunchKernelGGL(bn_stats_partial_f64_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (double*)workspace);
+        hipLaunchKernelGGL((bn_stats_merge_f64_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const double*)workspace, parts, C, partial, FinalizeArgs{});
+        return segmi_launch_status();
+    }
     hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
     hipLaunchKernelGGL((bn_stats_merge_kernel<false>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, partial, FinalizeArgs{}, 0);
     return segmi_launch_status();
@@ -443,8 +534,13 @@ int segmi_bn_stats_finalize(const float* x, int ld, long rows, int C, const floa
     const int parts = stats_parts(rows);
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
-    hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
     const FinalizeArgs f = {gamma, beta, eps, momentum, clamp_mode, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
+    if (stats_f64()) {
+        hipLaunchKernelGGL(bn_stats_partial_f64_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (double*)workspace);
+        hipLaunchKernelGGL((bn_stats_merge_f64_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const double*)workspace, parts, C, (float*)nullptr, f);
+        return segmi_launch_status();
+    }
+    hipLaunchKernelGGL(bn_stats_partial_kernel, g.grid, g.block, 0, st, x, ld, rows, g.c4, (float*)workspace);
     hipLaunchKernelGGL((bn_stats_merge_kernel<true>), dim3(segmi_cdiv(C, 16)), dim3(16, 16), 0, st, (const float*)workspace, parts, C, (float*)nullptr, f, 0);
     return segmi_launch_status();
 }

@@ -652,7 +652,25 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
             phase_b(Bb);
         }
         if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
-    } else
+    } else {
+    // fp32 MFMA: the matrix instruction adds its 2 products onto the accumulator in k order, i.e. an fp32 chain as long as the
+    // reduction (up to 9 x 2048 terms) with a rounding error that grows like sqrt(length) — measured 2-5x the error of the
+    // reference's CPU kernels on the same operands (tools/probes/conv_error_vs_fp64.py, profiles/r04_conv_error_vs_fp64*.txt).
+    // Two-level summation: every FLUSH chunks (FLUSH * 32 reduction elements) the running tile is added into a second
+    // accumulator and restarted, so both chains stay short; reductions of <= FLUSH chunks (C <= 512 for a 1x1 layer) never
+    // flush.  Cost: the matrix pipe drains once per flush (64 VALU adds + 64 moves per lane behind the MFMA -> VALU hazard).
+    // Measured: flushing every 8 chunks brings the kernels' error to 1.2-1.5x torch-CPU's and the network-level gradient distance
+    // from fp64 from 1.29x to 1.10x of the reference's own (cfg2) for -2.6 % on the dominant kernel; rotating ONE tile per chunk
+    // gives errors BELOW torch-CPU's but costs 16 % (hazard stalls every chunk); every 16 chunks is the shipped compromise.
+    constexpr int FLUSH = 16;
+    f32x16 total[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) total[i][j][e] = 0.f;
+    int since = 0;
     for (int it = it0; it < T; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
         const float* Ab = smem + buf * STAGE;
@@ -675,9 +693,25 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        if (++since == FLUSH && it + 1 < T) {
+            since = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { total[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.f; }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
         __syncthreads();                                     // ... for every wave, and this stage is free again
         buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += total[i][j][e];
     }
 
     // ---- epilogue (same C/D mapping as the register-staged kernel)

@@ -301,5 +301,19 @@ PY
   ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4g_bench.log
   python -c "import json; d=json.loads(open('gpurun_out/r4g_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'])" 2>&1 | tail -1
   ( timeout 300 python tools/membound_ops.py cfg2 2>&1 | grep -v amdgpu.ids | head -8 ) ;;
+r4h)
+  # two-level fp32 accumulation in the conv K loop: error probe, conv / model / audit tests, noise breakdown, bench
+  ( timeout 300 python tools/probes/conv_error_vs_fp64.py 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -20 ) > gpurun_out/r4h_conv_error.txt; cat gpurun_out/r4h_conv_error.txt
+  ( timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_fullsize_golden_gpu.py tests/test_pspnet_gpu.py tests/test_unet_gpu.py tests/test_deeplab_gpu.py tests/test_fullsize_properties_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|ERROR|Error|assert" | tail -20 ) > gpurun_out/r4h_tests.log
+  tail -6 gpurun_out/r4h_tests.log | cut -c1-300
+  python - <<'PY'
+import json
+d=json.load(open('gpurun_out/audit.json'))
+for k,v in sorted(d.items()):
+    if '/f32/' in k and 'grad_f64_rel_err_median' in v:
+        print(k, "logit dist fp64 HIP %.3e ref %.3e | grad f64 HIP med %.3e max %.3e | ratio %.2f %.2f"%(v['hip_err_f64'], v['ref_err_f64'], v['grad_f64_rel_err_median'], v['grad_f64_rel_err_max'], v['grad_f64_rel_err_median']/v['ref_grad_f64_rel_err_median'], v['grad_f64_rel_err_max']/v['ref_grad_f64_rel_err_max']))
+PY
+  ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4h_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4h_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1 ;;
 esac
 done
