@@ -659,10 +659,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     // Two-level summation: every FLUSH chunks (FLUSH * 32 reduction elements) the running tile is added into a second
     // accumulator and restarted, so both chains stay short; reductions of <= FLUSH chunks (C <= 512 for a 1x1 layer) never
     // flush.  Cost: the matrix pipe drains once per flush (64 VALU adds + 64 moves per lane behind the MFMA -> VALU hazard).
-    // Measured: flushing every 8 chunks brings the kernels' error to 1.2-1.5x torch-CPU's and the network-level gradient distance
-    // from fp64 from 1.29x to 1.10x of the reference's own (cfg2) for -2.6 % on the dominant kernel; rotating ONE tile per chunk
-    // gives errors BELOW torch-CPU's but costs 16 % (hazard stalls every chunk); every 16 chunks is the shipped compromise.
-    constexpr int FLUSH = 16;
+    // Measured: flushing every 8 chunks brings the kernels' error from 2-5x to 1.2-1.5x torch-CPU's and the network-level gradient
+    // distance from fp64 from 1.29x to 1.10x of the reference's own (cfg2); every 16 chunks only reaches 1.7-2.1x (and never
+    // triggers on a C = 512 Winograd contraction); rotating ONE tile per chunk gives errors BELOW torch-CPU's but costs 16 % of the
+    // kernel (MFMA -> VALU hazard stalls every chunk).
+    constexpr int FLUSH = 8;
     f32x16 total[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -670,8 +671,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) total[i][j][e] = 0.f;
-    int since = 0;
-    for (int it = it0; it < T; ++it) {
+    // (groups of FLUSH chunks: the inner loop is the plain pipelined K loop, untouched by the flush logic — a flush test inside it
+    //  cost the ds_read / MFMA interleave 4 extra s_waitcnt per chunk and 3.7 % of the kernel)
+    for (int it = it0; it < T;) {
+    const int gend = min(T, it + FLUSH);
+    for (; it < gend; ++it) {
         if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
         const float* Ab = smem + buf * STAGE;
         const float* Bb = Ab + BM * BK;
@@ -693,8 +697,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (++since == FLUSH && it + 1 < T) {
-            since = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
+        __syncthreads();                                     // ... for every wave, and this stage is free again
+        buf ^= 1;
+    }
+        if (it < T) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -702,9 +709,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { total[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.f; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
-        __syncthreads();                                     // ... for every wave, and this stage is free again
-        buf ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -64,7 +64,11 @@ class Bottleneck(nn.Module):
             out, identity = self.conv1(x, with_skip=True)     # the skip gradient is accumulated by conv1's dgrad, no autograd add
         else:
             # (SyncBN: bn3 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
-            out, identity = self.conv1(x), (None if snn.sync_tail(self.bn3, self.downsample) else self.downsample(x))
+            if snn.sync_tail(self.bn3, self.downsample) or len(self.downsample) != 2:
+                out, identity = self.conv1(x), (None if snn.sync_tail(self.bn3, self.downsample) else self.downsample(x))
+            else:     # conv1 and the projection read the same x: one autograd node, their data gradients summed by the dgrad kernels
+                out, proj = snn.conv_fan(x, [self.conv1, self.downsample[0]])
+                identity = self.downsample[1](proj)
         out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         return snn.residual_out(self.conv3(out), self.bn3, self.downsample, x, identity)

@@ -105,6 +105,20 @@ class Dropout(nn.Dropout):
         return ops.dropout(x, self.p, self.training, channelwise=False)
 
 
+def conv_fan(x, convs):
+    """[conv(x) for conv in convs] for bias-free dense Conv2d modules sharing their input, as ONE autograd node whose backward sums
+    the branches' data gradients inside the dgrad kernels (ops.conv2d_fan) — conv1 and the projection shortcut of a residual
+    block.  Falls back to separate calls when a branch does not qualify."""
+    ok = all(isinstance(c, Conv2d) and not c.depthwise and c.bias is None for c in convs) and convs[0].stride[0] == 1
+    if not ok or not FAN_IN_FUSION:
+        return [c(x) for c in convs]
+    fuse = torch.is_grad_enabled()
+    return ops.conv2d_fan(x, [(c.weight, c.stride[0], c.padding[0], c.dilation[0], c._bn_consumer and fuse, c) for c in convs])
+
+
+FAN_IN_FUSION = __import__("os").environ.get("SEGMI_CONV_FAN", "1") == "1"      # A/B switch
+
+
 def link_conv_bn(root):
     """Mark every dense Conv2d whose output a BatchNorm2d consumes (`_bn_consumer`), from the module REGISTRATION order: inside
     one parent, a BatchNorm2d child pairs with the last convolution registered before it — `conv1, bn1, conv2, bn2, ...` of the

@@ -19,7 +19,7 @@ from ._lib import ConvDesc, FilterTx, SegmiError, check, lib
 from .profile import span
 
 __all__ = [
-    "conv2d", "conv2d_skip", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
+    "conv2d", "conv2d_skip", "conv2d_fan", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
     "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
 ]
 
@@ -355,7 +355,7 @@ def _winograd_wgrad_variant(d):
 # is discovered at run time: the convolution tags its output with its module, the BN layer that receives a tagged tensor marks
 # that module (`_bn_consumer`), and from the next step on the convolution emits the partials (`bn_stats=True`), attached to
 # its output as `_segmi_bn_stats` = (partials, nparts, tensor version).
-_BN_FUSE = {"on": os.environ.get("SEGMI_CONV_BN_STATS", "1") == "1", "emitted": 0, "consumed": 0, "last": None}
+_BN_FUSE = {"on": os.environ.get("SEGMI_CONV_BN_STATS", "1") == "1", "emitted": 0, "consumed": 0, "last": None, "fan": None}
 
 
 def set_conv_bn_stats(on):
@@ -737,6 +737,93 @@ def conv2d_skip(x, weight, stride=1, padding=0, dilation=1, bn_stats=False, prod
     _BN_FUSE["last"] = None
     y, skip = _Conv2dSkipFn.apply(x, weight, int(stride), int(padding), int(dilation), bool(bn_stats) and _BN_FUSE["on"])
     return _tag_bn_stats(y, producer), skip
+
+
+class _Conv2dFanFn(torch.autograd.Function):
+    """ys = [conv2d(x, w_i, stride_i, pad_i, dil_i) for i] — several bias-free convolutions of ONE input (conv1 and the projection
+    shortcut of a residual block, models/resnet.py:105-121) as one autograd node: the data gradients of all branches are summed by
+    the dgrad kernels themselves (accumulate=1 onto the first branch's dx) instead of by an autograd-engine `aten::add` over the
+    full-size input (4 per PSPNet-R50 step, 0.25 ms).  args: geoms = ((stride, pad, dil, bn_stats), ...), then the filters."""
+
+    @staticmethod
+    def forward(ctx, x, geoms, *weights):
+        x = to_nhwc(x, "conv2d")
+        N, C, H, W = x.shape
+        Ce = pad4(C)
+        ys, vs, gs, stats = [], [], [], []
+        for i, (weight, (stride, pad, dil, bn_stats)) in enumerate(zip(weights, geoms)):
+            _need_cuda(weight, "conv2d")
+            K, Cw, R, S = weight.shape
+            if Cw != C:
+                raise SegmiError("conv2d: input has %d channels, filter expects %d" % (C, Cw))
+            w = _filter_krsc(weight, Ce)
+            P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+            y = empty_nhwc(N, K, P, Q, x.device)
+            d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
+            _BN_FUSE["last"] = None
+            v = _conv_fwd(d, C, x, w, None, y, keep_v=ctx.needs_input_grad[2 + i] and _FWD["grad"], bn_stats=bn_stats)
+            stats.append(_BN_FUSE["last"])
+            _BN_FUSE["last"] = None
+            if ctx.needs_input_grad[0]:
+                _filter_transposes.note(weight, w, K, R, S, Ce, pad4(K))
+            ys.append(y)
+            vs.append(v)
+            gs.append((K, R, S, P, Q, stride, pad, dil))
+        ctx.save_for_backward(x, *weights, *[v for v in vs if v is not None])
+        ctx.has_v = [v is not None for v in vs]
+        ctx.geom = (N, C, H, W, tuple(gs))
+        _BN_FUSE["fan"] = stats
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = list(ctx.saved_tensors)
+        N, C, H, W, gs = ctx.geom
+        n = len(gs)
+        x, weights, rest = saved[0], saved[1:1 + n], saved[1 + n:]
+        vs = [rest.pop(0) if h else None for h in ctx.has_v]
+        Ce = pad4(C)
+        dx, dws = None, []
+        for i, (dy, weight, v, (K, R, S, P, Q, stride, pad, dil)) in enumerate(zip(dys, weights, vs, gs)):
+            if dy is None:
+                dws.append(None)
+                continue
+            dy = to_nhwc(dy, "conv2d.backward")
+            if ctx.needs_input_grad[0]:
+                w = _filter_krsc(weight, Ce)
+                wt = _filter_crsk(weight, w, K, R, S, Ce, pad4(K))
+                first = dx is None
+                if first:
+                    dx = empty_nhwc(N, C, H, W, x.device)
+                d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(dx), ld_of(dy))
+                _conv_dgrad(d, C, dy, wt, dx, accumulate=0 if first else 1)
+            dw = None
+            if ctx.needs_input_grad[2 + i]:
+                d = ConvDesc(N, H, W, Ce, K, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
+                dwb, dw_owned = _filter_grad_buffer(weight, Ce)
+                if dw_owned is not None:
+                    _conv_wgrad_param(weight, d, C, x, dy, dwb, v)
+                else:
+                    _conv_wgrad(d, C, x, dy, dwb, v)
+                dw = dw_owned if dw_owned is not None else _filter_grad_like(dwb, weight, Ce)
+            dws.append(dw)
+        return (dx, None) + tuple(dws)
+
+
+def conv2d_fan(x, branches):
+    """[conv2d(x, weight, None, stride, padding, dilation) for every branch] as ONE autograd node (see _Conv2dFanFn).
+    branches: [(weight, stride, padding, dilation, bn_stats, producer module or None), ...]; the FIRST branch must have stride 1
+    (its data gradient initialises dx, the others accumulate onto it)."""
+    if not branches or int(branches[0][1]) != 1:
+        raise SegmiError("conv2d_fan: the first branch must be a stride-1 convolution")
+    _FWD["grad"] = torch.is_grad_enabled()
+    geoms = tuple((int(s), int(p), int(d), bool(b) and _BN_FUSE["on"]) for _, s, p, d, b, _ in branches)
+    ys = _Conv2dFanFn.apply(x, geoms, *[b[0] for b in branches])
+    stats, _BN_FUSE["fan"] = _BN_FUSE.get("fan") or [None] * len(ys), None
+    for y, st, b in zip(ys, stats, branches):
+        _BN_FUSE["last"] = st
+        _tag_bn_stats(y, b[5])
+    return list(ys)
 
 
 # --------------------------------------------------------------------------- depthwise convolution

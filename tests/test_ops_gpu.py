@@ -1019,3 +1019,32 @@ def test_conv_to_batchnorm_pairing_static_link_and_runtime_discovery(cuda):
         assert c5["emitted"] == c4["emitted"] and not any(getattr(m, "_bn_consumer", False) for m in unet.modules())
     finally:
         ops.set_conv_bn_stats(prev)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 24, 24, 64, 512, 1), (2, 128, 33, 31, 64, 256, 2), (1, 64, 16, 16, 64, 256, 1)])
+def test_conv_fan_sums_the_branch_gradients_in_the_dgrad_kernels(cuda, case):
+    """snn.conv_fan([conv1, projection]) — two bias-free convolutions of one input as ONE autograd node (the residual blocks with a
+    projection shortcut, models/resnet.py:105-121) — is bit-identical to the two separate calls whose data gradients the autograd
+    engine adds: same outputs, same dx, same filter gradients; the BN statistics partials ride on both outputs."""
+    from segmi import nn as snn, ops
+    N, C, H, W, K1, K2, s2 = case
+    torch.manual_seed(1)
+    c1 = snn.Conv2d(C, K1, 1, bias=False).to(cuda)
+    c2 = snn.Conv2d(C, K2, 1, stride=s2, bias=False).to(cuda)
+    b1, b2 = snn.BatchNorm2d(K1).to(cuda), snn.BatchNorm2d(K2).to(cuda)
+    x0 = torch.randn(N, C, H, W, device=cuda)
+    res = []
+    for fan in (False, True):
+        for m in (c1, c2):
+            m.weight.grad = None
+            m._bn_consumer = True
+        x = x0.clone().requires_grad_(True)
+        c0 = ops.get_conv_bn_stats()
+        y1, y2 = snn.conv_fan(x, [c1, c2]) if fan else (c1(x), c2(x))
+        z = b1(y1, relu=True).square().mean() + b2(y2).abs().mean()
+        z.backward()
+        c3 = ops.get_conv_bn_stats()
+        res.append((y1.detach().clone(), y2.detach().clone(), x.grad.clone(), c1.weight.grad.clone(), c2.weight.grad.clone(), c3["consumed"] - c0["consumed"]))
+    for a, b in zip(res[0][:5], res[1][:5]):
+        assert torch.equal(a, b)
+    assert res[0][5] == res[1][5] == 2

@@ -315,5 +315,14 @@ for k,v in sorted(d.items()):
 PY
   ( timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4h_bench.log
   python -c "import json; d=json.loads(open('gpurun_out/r4h_bench.log').read()); r=d['roofline']; print('cfg2', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1 ;;
+r4j)
+  ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_pspnet_gpu.py tests/test_deeplab_gpu.py tests/test_distributed_gpu.py -m gpu -q -rf -p no:cacheprovider -k "fan or pspnet or deeplab or resnet or two_rank or filter_gradients or reducer" 2>&1 | grep -E "passed|failed|FAILED|ERROR|Error|assert" | tail -12 ) > gpurun_out/r4j_tests.log
+  tail -5 gpurun_out/r4j_tests.log | cut -c1-300
+  for v in default nofan; do
+    case $v in default) e="";; nofan) e="SEGMI_CONV_FAN=0";; esac
+    ( env $e timeout 400 python bench.py --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4j_bench_$v.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4j_bench_$v.log').read()); r=d['roofline']; print('cfg2 $v', d['value'], d['ms_per_step'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1
+  done
+  ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -14 ) ;;
 esac
 done
