@@ -1573,7 +1573,11 @@ WgradPlan plan_wgrad(const segmi_conv_desc* d, int batch = 1) {
     long max_split = chunks / 8 > 0 ? chunks / 8 : 1;            // >= 256 pixels per split
     if (max_split > 512) max_split = 512;
     const long ns_rounds = (8 * slots + tiles - 1) / tiles;       // >= 8 rounds of resident workgroups
-    const long ns_fill = (slots + tiles - 1) / tiles;             // at least one workgroup per slot
+    // at least one workgroup per slot — unless ONE FEWER split already fills >= 95 % of the slots: 36 tiles (728 -> 728, Xception's
+    // middle flow) x 14 splits = 504 of 512 slots is one full round; insisting on 15 made it 540 = two rounds, and the search below
+    // then went on to 26 splits of 10 chunks each (62 TF/s: prologue / epilogue dominated)
+    long ns_fill = (slots + tiles - 1) / tiles;
+    if (ns_fill > 1 && (ns_fill - 1) * tiles * 100 >= slots * 95) --ns_fill;
     const long ns_long = chunks / 64 > 0 ? chunks / 64 : 1;       // but keep >= 64 chunks (2048 pixels) of K loop per workgroup
     long lo = ns_fill > ns_long ? ns_fill : ns_long;              //   unless filling the chip needs more
     long hi = ns_rounds < max_split ? ns_rounds : max_split;

@@ -324,5 +324,45 @@ r4j)
     python -c "import json; d=json.loads(open('gpurun_out/r4j_bench_$v.log').read()); r=d['roofline']; print('cfg2 $v', d['value'], d['ms_per_step'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1
   done
   ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -14 ) ;;
+r4final)
+  # round 4, evidence run of the final tree
+  ( timeout 1800 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r4f_pytest_gpu.log
+  tail -3 gpurun_out/r4f_pytest_gpu.log | cut -c1-300
+  cp gpurun_out/audit.json gpurun_out/r4f_fullsize_audit.json 2>/dev/null
+  ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r4f_smoke.log; tail -1 gpurun_out/r4f_smoke.log | cut -c1-200
+  ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/r4f_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4f_bench.log').read()); r=d['roofline']; print('bench', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['executed_step_frac'], d['cpu_baseline']['value'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1
+  rm -rf gpurun_out/prof
+  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4f_kernel_stats_f32.csv
+  rm -rf gpurun_out/prof
+  ( SEGMI_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4f_kernel_stats_f32_inorder.csv; head -3 gpurun_out/r4f_kernel_stats_f32_inorder.csv | cut -c1-200
+  rm -rf gpurun_out/prof gpurun_out/pmc_f32
+  ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f32/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/pmc_f32.log
+  ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_f32/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) >> gpurun_out/pmc_f32.log
+  for d in fetch write; do f=$(find gpurun_out/pmc_f32/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_f32/$d/r_counter_collection.csv 2>/dev/null; done
+  python tools/traffic_json.py gpurun_out/pmc_f32 gpurun_out/r4f_cfg2_conv_traffic_f32.json
+  find gpurun_out/pmc_f32 -name "*kernel_trace*" -delete; find gpurun_out/pmc_f32 -name "*.csv" -size +8M -delete
+  ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4f_conv_layers.txt; tail -1 gpurun_out/r4f_conv_layers.txt
+  ( timeout 300 python tools/membound_ops.py cfg2 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4f_membound_ops.txt; tail -2 gpurun_out/r4f_membound_ops.txt
+  ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -20 ) > gpurun_out/r4f_stray_aten.txt
+  ( timeout 300 python tools/grad_noise.py cfg2 cfg3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4f_grad_noise.txt
+  for c in cfg1 cfg3 cfg4 cfg5; do
+    ( timeout 400 python bench.py --config $c --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4f_bench_$c.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4f_bench_$c.log').read()); r=d['roofline']; print('$c', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1
+    rm -rf gpurun_out/prof_$c
+    ( SEGMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$c -o r -- python bench.py --config $c --steps 7 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r4f_prof_$c.log
+    find gpurun_out/prof_$c -name "*kernel_trace*" -delete
+    f=$(find gpurun_out/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4f_${c}_kernel_stats.csv
+    rm -rf gpurun_out/prof_$c
+    ( timeout 300 python tools/membound_ops.py $c 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4f_${c}_membound_ops.txt
+  done
+  ( SEGMI_LOVASZ_SORT=rocprim timeout 300 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4f_bench_cfg5_rocprim.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4f_bench_cfg5_rocprim.log').read()); print('cfg5 rocprim', d['value'], d['ms_per_step'])" 2>&1 | tail -1
+  ( SEGMI_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_fullsize_golden_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|UNet grad|assert" | tail -30 ) > gpurun_out/r4f_bf16x3_audit.log
+  tail -3 gpurun_out/r4f_bf16x3_audit.log | cut -c1-300 ;;
 esac
 done
