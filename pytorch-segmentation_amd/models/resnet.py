@@ -63,15 +63,16 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             out, identity = self.conv1(x, with_skip=True)     # the skip gradient is accumulated by conv1's dgrad, no autograd add
         else:
+            # conv1 and the projection read the same x: one autograd node, their data gradients summed by the dgrad kernels
             # (SyncBN: bn3 and the projection's BN share one all-gather / one all-reduce — snn.sync_tail)
-            if snn.sync_tail(self.bn3, self.downsample) or len(self.downsample) != 2:
-                out, identity = self.conv1(x), (None if snn.sync_tail(self.bn3, self.downsample) else self.downsample(x))
-            else:     # conv1 and the projection read the same x: one autograd node, their data gradients summed by the dgrad kernels
-                out, proj = snn.conv_fan(x, [self.conv1, self.downsample[0]])
-                identity = self.downsample[1](proj)
+            out, proj = snn.conv_fan(x, [self.conv1, self.downsample[0]]) if len(self.downsample) == 2 else (self.conv1(x), None)
+            if snn.sync_tail(self.bn3, self.downsample):
+                identity = None
+            else:
+                identity = self.downsample[1](proj) if proj is not None else self.downsample(x)
         out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return snn.residual_out(self.conv3(out), self.bn3, self.downsample, x, identity)
+        return snn.residual_out(self.conv3(out), self.bn3, self.downsample, x, identity, proj if self.downsample is not None else None)
 
 
 class ResNet(nn.Module):

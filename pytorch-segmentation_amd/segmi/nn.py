@@ -163,10 +163,11 @@ def sync_tail(bn, downsample):
             and ops.sync_groupable([bn, downsample[1]]))
 
 
-def residual_out(x_last, bn, downsample, x, identity):
-    """Last step of a residual block: relu(bn(x_last) + identity), or — identity is None: see sync_tail — the fused SyncBN tail."""
+def residual_out(x_last, bn, downsample, x, identity, proj=None):
+    """Last step of a residual block: relu(bn(x_last) + identity), or — identity is None: see sync_tail — the fused SyncBN tail
+    (proj: the projection convolution's output when the block already computed it, see conv_fan)."""
     if identity is None:
-        return ops.sync_batch_norm_residual_tail(x_last, bn, downsample[0](x), downsample[1])
+        return ops.sync_batch_norm_residual_tail(x_last, bn, proj if proj is not None else downsample[0](x), downsample[1])
     return bn(x_last, residual=identity, relu=True)
 
 
