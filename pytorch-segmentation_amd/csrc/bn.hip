@@ -628,7 +628,7 @@ static int bwd_parts(long rows, int C) {
     const long cap = (rows + (long)g.ry * 16 - 1) / ((long)g.ry * 16);
     if (p > cap) p = cap;
     if (p < 1) p = 1;
-    if (p > STATS_MAX_PARTS) p = STATS_MAX_PARTS;
+    if (p > STATS_MAX_PARTS) p = STATS_MAX_PARTS;          // (1024 / 2048 partials measured at cfg2: 55.76 / 55.92 ms against 55.79: no gain)
     return (int)p;
 }
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
 __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys,
                                                               long rows, int nchunks, const unsigned* __restrict__ counts, int C, int PB,
                                                               const unsigned* __restrict__ chunk_fg, float* __restrict__ G,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, unsigned pix_lo, unsigned pix_hi) {
     // 1-D grid; block b runs on XCD b % 8 and takes class (b/8 / nchunks)*8 + b%8: all chunks of a class scatter into that
     // class's plane of G from ONE XCD, whose L2 (with the Infinity Cache behind it) merges the 4-byte writes into full lines.
     // (A pixel-major G[pixel][class] received its 32 dwords per line from 32 classes at 32 different times: 4.9 ms for cfg5.)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
             dot += e * grad;
             // d|fg - p| / dp = -sign(fg - p);  e == 0 -> 0 (torch's abs backward uses sign)
             const float sgn = invalid || e == 0.f ? 0.f : (fg ? -1.f : 1.f);
-            G[(long)c * rows + pix] = sgn * grad;
+            if (pix >= pix_lo && pix < pix_hi) G[(long)c * rows + pix] = sgn * grad;       // this launch's pixel window (see the caller)
             cum += fg;
         }
     }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) part[(long)c * nchunks + k] = (double)sd[0] + sd[1] + sd[2] + sd[3];
+    if (threadIdx.x == 0 && pix_lo == 0) part[(long)c * nchunks + k] = (double)sd[0] + sd[1] + sd[2] + sd[3];
 }
 
 // loss_out = {mean over present classes of loss_c, n_present}
@@ -598,9 +598,18 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
     hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
+    // The scatter of d loss / d p into a class plane of G is 4-byte writes at random pixels: with the whole plane (rows * 4 B =
+    // 8.4 MB at cfg5) in flight an XCD's 4 MB L2 evicts partially written lines.  The pass is therefore run once per PIXEL WINDOW of
+    // <= 4.5 MB (the sorted keys are re-read, the writes of a window merge into full lines in L2).  Measured at cfg5 in one call
+    // (SEGMI_LOVASZ_WINDOWS overrides): 1 window 69.2 ms/step, 2 windows 68.45, 3 windows 68.67, 4 windows 69.71.
     const dim3 grid1((unsigned)(8 * ((C + 7) / 8)) * (unsigned)L.nchunks);
-    hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid1, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
-                       (const unsigned*)chunk_fg, G, part);
+    int nwin = (int)(((size_t)rows * 4 + (9u << 19) - 1) / (9u << 19));
+    if (const char* e = getenv("SEGMI_LOVASZ_WINDOWS")) { const int v = atoi(e); if (v >= 1 && v <= 16) nwin = v; }
+    if (nwin < 1) nwin = 1;
+    const unsigned per = (unsigned)((rows + nwin - 1) / nwin);
+    for (int wdw = 0; wdw < nwin; ++wdw)
+        hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid1, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
+                           (const unsigned*)chunk_fg, G, part, (unsigned)wdw * per, wdw + 1 == nwin ? 0xFFFFFFFFu : (unsigned)(wdw + 1) * per);
     hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
     return segmi_launch_status();
 }
