@@ -87,12 +87,11 @@ def cpu_baseline(name, seconds_cap=240.0):
     allocator growth), a one-step sweep over {16, 32, 64, all} torch threads, then timed steps at the best thread count until
     three post-warm-up samples exist at it (the sweep step counts as one) or `seconds_cap` is spent.  `value` is the best
     (minimum-time) step, the median is reported beside it.  kind = "port": /root/reference does not exist on the GPU box and
-    nothing here may read it at run time, so the leg is the bit-exact restatement (oracle/pspnet_ref.py), not the trainer."""
-    from oracle import losses_ref, pspnet_ref
+    nothing here may read it at run time, so the leg is the bit-exact restatement (oracle/pspnet_ref.py, unet_ref.py,
+    deeplab_ref.py + losses_ref.py: every BASELINE config has one), not the trainer."""
+    from oracle import deeplab_ref, losses_ref, pspnet_ref, unet_ref
     import models
-    arch, kw, classes, n, h, w = CONFIGS[name][:6]
-    if arch != "PSPNet":
-        return None      # the oracle leg is wired for the bench line (cfg2 family) only
+    arch, kw, classes, n, h, w, _, loss_name, ign = CONFIGS[name]
     nb = n
     torch.manual_seed(0)
     sd = {k: v.detach().clone().contiguous() for k, v in getattr(models, arch)(classes, **kw).state_dict().items()}
@@ -102,15 +101,24 @@ def cpu_baseline(name, seconds_cap=240.0):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(nb, 3, h, w, generator=g)
     t = torch.randint(0, classes, (nb, h, w), generator=g)
-    t[:, : h // 20, :] = 255
+    t[:, : h // 20, :] = ign
+    loss_fn = {"CrossEntropyLoss2d": losses_ref.cross_entropy, "LovaszSoftmax": losses_ref.lovasz_softmax}[loss_name]
+
+    def forward_loss():
+        if arch == "PSPNet":
+            out, aux = pspnet_ref.pspnet_forward(ref, x, training=True, backbone=kw["backbone"])
+            return loss_fn(out, t, ign) + 0.4 * loss_fn(aux, t, ign)
+        if arch == "UNet":
+            return loss_fn(unet_ref.unet_forward(ref, x, training=True), t, ign)
+        return loss_fn(deeplab_ref.deeplab_forward(ref, x, kw["backbone"], kw["output_stride"], training=True), t, ign)
+
     all_threads = torch.get_num_threads()
     t_begin = time.perf_counter()
 
     def one_step():
         t0 = time.perf_counter()
         opt.zero_grad()
-        out, aux = pspnet_ref.pspnet_forward(ref, x, training=True, backbone=kw["backbone"])
-        loss = losses_ref.cross_entropy(out, t) + 0.4 * losses_ref.cross_entropy(aux, t)
+        loss = forward_loss()
         loss.backward()
         opt.step()
         return time.perf_counter() - t0

@@ -293,11 +293,12 @@ def _presplit(w, n, dev):
 
 # Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/conv_winograd.hip): the DEFAULT algorithm of the eligible layers for
 # all three passes since round 3 (the whole GPU suite runs under it; SEGMI_CONV_WINOGRAD=0 / set_conv_winograd(False) selects the
-# direct implicit-GEMM kernels everywhere); `min_channels` = smallest min(C, K) it is used for (below
-# ~256 channels the transform traffic eats the saved multiplications); `min_subgrid` = smallest ceil(H / dilation) it is used for
+# direct implicit-GEMM kernels everywhere); `min_channels` = smallest min(C, K) it is used for (128 since round 4: measured per
+# config in one call each, 256 -> 128 gives cfg1 7.74 -> 7.15 ms, cfg3 82.0 -> 80.9, cfg5 69.4 -> 68.7, cfg2 56.13 -> 56.22; at 64
+# the transform traffic eats the saved multiplications: cfg1 7.27, cfg3 83.5 vs 83.2, cfg5 70.6 vs 69.7); `min_subgrid` = smallest ceil(H / dilation) it is used for
 # (a dilated layer runs as dilation^2 dense sub-grids: ASPP's d = 12..36 on 33x33 maps would be 2x2 tiles of mostly padding).
 _WINOGRAD = {"on": os.environ.get("SEGMI_CONV_WINOGRAD", "1") == "1",
-             "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "256")),
+             "min_channels": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_CHANNELS", "128")),
              "min_subgrid": int(os.environ.get("SEGMI_CONV_WINOGRAD_MIN_SUBGRID", "8")),
              "wgrad": os.environ.get("SEGMI_CONV_WINOGRAD_WGRAD", "1") == "1", "calls": 0,
              # keep the forward pass's transformed input V (4x the layer input) for the filter gradient instead of transforming x

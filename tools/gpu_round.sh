@@ -364,5 +364,19 @@ r4final)
   python -c "import json; d=json.loads(open('gpurun_out/r4f_bench_cfg5_rocprim.log').read()); print('cfg5 rocprim', d['value'], d['ms_per_step'])" 2>&1 | tail -1
   ( SEGMI_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_fullsize_golden_gpu.py tests/test_unet_gpu.py -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|UNet grad|assert" | tail -30 ) > gpurun_out/r4f_bf16x3_audit.log
   tail -3 gpurun_out/r4f_bf16x3_audit.log | cut -c1-300 ;;
+r4z)
+  # round 4, last call: the whole suite + smoke + the bench lines on the final tree (Winograd from 128 channels, windowed Lovasz scatter)
+  ( timeout 1800 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider 2>&1 | grep -E "fullsize|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64" | tail -70 ) > gpurun_out/r4z_pytest_gpu.log
+  tail -3 gpurun_out/r4z_pytest_gpu.log | cut -c1-300
+  cp gpurun_out/audit.json gpurun_out/r4z_fullsize_audit.json 2>/dev/null
+  ( timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 ) > gpurun_out/r4z_smoke.log; tail -1 gpurun_out/r4z_smoke.log | cut -c1-200
+  ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/r4z_bench.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4z_bench.log').read()); r=d['roofline']; print('bench', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['executed_step_frac'], d['cpu_baseline']['value'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1
+  for c in cfg1 cfg3 cfg4 cfg5; do
+    ( timeout 400 python bench.py --config $c --no-cpu --no-alt 2>&1 | tail -1 ) > gpurun_out/r4z_bench_$c.log
+    python -c "import json; d=json.loads(open('gpurun_out/r4z_bench_$c.log').read()); r=d['roofline']; print('$c', d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['all_conv']['ms_per_step'], r['hbm_bound_calls']['ms_per_step'])" 2>&1 | tail -1
+  done
+  ( SEGMI_LOVASZ_SORT=rocprim timeout 300 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4z_bench_cfg5_rocprim.log
+  python -c "import json; d=json.loads(open('gpurun_out/r4z_bench_cfg5_rocprim.log').read()); print('cfg5 rocprim', d['value'], d['ms_per_step'])" 2>&1 | tail -1 ;;
 esac
 done
