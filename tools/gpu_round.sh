@@ -378,5 +378,29 @@ r4z)
   done
   ( SEGMI_LOVASZ_SORT=rocprim timeout 300 python bench.py --config cfg5 --no-cpu --no-alt --no-roofline 2>&1 | tail -1 ) > gpurun_out/r4z_bench_cfg5_rocprim.log
   python -c "import json; d=json.loads(open('gpurun_out/r4z_bench_cfg5_rocprim.log').read()); print('cfg5 rocprim', d['value'], d['ms_per_step'])" 2>&1 | tail -1 ;;
+r4y)
+  # profiles of the final tree (after the Winograd threshold change): rocprof stats (in order / side stream), PMC traffic, tables
+  rm -rf gpurun_out/prof
+  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4y_kernel_stats_f32.csv
+  rm -rf gpurun_out/prof
+  ( SEGMI_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4y_kernel_stats_f32_inorder.csv; head -3 gpurun_out/r4y_kernel_stats_f32_inorder.csv | cut -c1-200
+  rm -rf gpurun_out/prof gpurun_out/pmc_f32
+  ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f32/fetch -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/pmc_f32.log
+  ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_f32/write -o r -- python bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) >> gpurun_out/pmc_f32.log
+  for d in fetch write; do f=$(find gpurun_out/pmc_f32/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_f32/$d/r_counter_collection.csv 2>/dev/null; done
+  python tools/traffic_json.py gpurun_out/pmc_f32 gpurun_out/r4y_cfg2_conv_traffic_f32.json
+  find gpurun_out/pmc_f32 -name "*kernel_trace*" -delete; find gpurun_out/pmc_f32 -name "*.csv" -size +8M -delete
+  ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4y_conv_layers.txt; tail -1 gpurun_out/r4y_conv_layers.txt
+  ( timeout 300 python tools/membound_ops.py cfg2 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r4y_membound_ops.txt; tail -2 gpurun_out/r4y_membound_ops.txt
+  for c in cfg1 cfg5; do
+    ( SEGMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$c -o r -- python bench.py --config $c --steps 7 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r4y_prof_$c.log
+    find gpurun_out/prof_$c -name "*kernel_trace*" -delete
+    f=$(find gpurun_out/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r4y_${c}_kernel_stats.csv
+    rm -rf gpurun_out/prof_$c
+  done ;;
 esac
 done
