@@ -135,17 +135,21 @@ __device__ __forceinline__ void wave_peers(unsigned d, bool valid, int lane, uns
     count = (unsigned)__popcll(peers);
 }
 
-// hist[(c * ntiles + tile) * 256 + d] = number of keys of tile `tile` of class c whose digit is d
+// hist[(c * ntiles + tile) * 256 + d] = number of keys of tile `tile` of class c whose digit is d.
+// A histogram does not care about order: one LDS atomic per key into a per-WAVE histogram (four 1 KB rows, summed at the end)
+// instead of the ballot ranking the stable scatter needs — the ballots (9 per 64 keys) made this pass as compute-bound as it is
+// memory-bound (0.75 ms per pass for cfg5's 2.5 GB of keys = 3.3 TB/s); same-address atomics of a digit most keys share (the
+// exponent pass) serialise inside one ds instruction, which is still ~4x cheaper than the ballots.
 __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long long* __restrict__ keys, long rows, int ntiles, int shift,
                                                            unsigned mask, const unsigned* __restrict__ counts, unsigned* __restrict__ hist) {
     const int c = blockIdx.y, tile = blockIdx.x;
     if (counts[c] == 0) return;                          // absent class: never read downstream (classes='present')
-    __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
+    __shared__ unsigned h[4][256];
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0; h[2][threadIdx.x] = 0; h[3][threadIdx.x] = 0;
     __syncthreads();
     const unsigned long long* k = keys + (long)c * rows;
     const long i0 = (long)tile * ST;
-    const int lane = threadIdx.x & 63;
+    unsigned* hw = h[threadIdx.x >> 6];
 #pragma unroll 1
     for (int r0 = 0; r0 < ST / 256; r0 += SEG_MLP) {     // SEG_MLP 512-byte loads per wave in flight (one at a time is latency-bound: 1 TB/s)
         unsigned long long kq[SEG_MLP];
@@ -157,41 +161,52 @@ __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long l
             kq[u] = vq[u] ? k[i] : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < SEG_MLP; ++u) {
-            const unsigned d = seg_digit(kq[u], shift, mask);
-            unsigned rank, cnt;
-            wave_peers(d, vq[u], lane, rank, cnt);       // one LDS atomic per distinct digit and wave (the top digit is shared by most keys)
-            if (vq[u] && rank == 0) atomicAdd(&h[d], cnt);
-        }
+        for (int u = 0; u < SEG_MLP; ++u)
+            if (vq[u]) atomicAdd(&hw[seg_digit(kq[u], shift, mask)], 1u);
     }
     __syncthreads();
-    hist[((long)c * ntiles + tile) * 256 + threadIdx.x] = h[threadIdx.x];
+    hist[((long)c * ntiles + tile) * 256 + threadIdx.x] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
 }
 
 // in place: hist[c][tile][d] -> first output rank (inside the class segment) of that tile's keys with digit d:
-// exclusive scan in (digit, tile) order.  One block per class, thread d walks its digit's column (coalesced across threads).
-__global__ __launch_bounds__(256) void segsort_scan_kernel(unsigned* __restrict__ hist, int ntiles, const unsigned* __restrict__ counts) {
-    const int c = blockIdx.x, d = threadIdx.x;
+// exclusive scan in (digit, tile) order.  One block per class, 256 digits x SCAN_Q tile ranges: thread (d, q) walks its quarter
+// of digit d's column (coalesced across d), the quarters and the digits are combined through LDS.  (One thread per digit walking
+// all 512 tiles twice: 183 us per pass on 150 of the chip's 256 CUs.)
+constexpr int SCAN_Q = 4;
+__global__ __launch_bounds__(256 * SCAN_Q) void segsort_scan_kernel(unsigned* __restrict__ hist, int ntiles, const unsigned* __restrict__ counts) {
+    const int c = blockIdx.x, d = threadIdx.x, q = threadIdx.y;
     if (counts[c] == 0) return;
     unsigned* col = hist + (long)c * ntiles * 256 + d;
+    const int per = (ntiles + SCAN_Q - 1) / SCAN_Q;
+    const int tb = min(ntiles, q * per), te = min(ntiles, tb + per);
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    int t = 0;
-    for (; t + 3 < ntiles; t += 4) {
+    int t = tb;
+    for (; t + 3 < te; t += 4) {
         t0 += col[(long)t * 256]; t1 += col[(long)(t + 1) * 256]; t2 += col[(long)(t + 2) * 256]; t3 += col[(long)(t + 3) * 256];
     }
-    for (; t < ntiles; ++t) t0 += col[(long)t * 256];
-    const unsigned tot = (t0 + t1) + (t2 + t3);
-    __shared__ unsigned sm[256];
-    sm[d] = tot;
+    for (; t < te; ++t) t0 += col[(long)t * 256];
+    __shared__ unsigned part[SCAN_Q][256], sm[256];
+    part[q][d] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    unsigned tot = 0;
+    if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < SCAN_Q; ++k) tot += part[k][d];
+        sm[d] = tot;
+    }
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        const unsigned y = d >= o ? sm[d - o] : 0u;
+        unsigned y = 0;
+        if (q == 0 && d >= o) y = sm[d - o];
         __syncthreads();
-        sm[d] += y;
+        if (q == 0) sm[d] += y;
         __syncthreads();
     }
-    unsigned run = sm[d] - tot;                          // keys of this class with a smaller digit
-    for (t = 0; t < ntiles; ++t) {
+    if (q == 0) sm[d] -= tot;                            // keys of this class with a smaller digit
+    __syncthreads();
+    unsigned run = sm[d];
+    for (int k = 0; k < q; ++k) run += part[k][d];       // ... plus this digit's keys in the earlier tile ranges
+    for (t = tb; t < te; ++t) {
         const unsigned v = col[(long)t * 256];
         col[(long)t * 256] = run;
         run += v;
@@ -231,7 +246,8 @@ __device__ __forceinline__ void seg_rank_rounds(const unsigned long long* __rest
 
 __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                               long rows, int ntiles, int shift, unsigned mask,
-                                                              const unsigned* __restrict__ counts, const unsigned* __restrict__ hist) {
+                                                              const unsigned* __restrict__ counts, const unsigned* __restrict__ hist,
+                                                              unsigned* __restrict__ chunk_fg, int nchunks, int PB) {
     const int c = blockIdx.y, tile = blockIdx.x;
     if (counts[c] == 0) return;
     constexpr int WQ = ST / 4;                         // keys per wave
@@ -280,7 +296,11 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     for (int j = tid; j < nk; j += 256) {
         const unsigned long long kk = sorted[j];
         const unsigned d = seg_digit(kk, shift, mask);
-        o[(long)gbase[d] + (unsigned)(j - (int)wbase[0][d])] = kk;
+        const long pos = (long)gbase[d] + (unsigned)(j - (int)wbase[0][d]);
+        o[pos] = kk;
+        // last pass: pos is the key's final rank — count the foreground keys per scan chunk here (one integer atomic per fg key,
+        // i.e. per valid pixel: exact and order-independent) instead of re-reading all keys in lovasz_chunk_count_kernel
+        if (chunk_fg && ((kk >> PB) & 1ull)) atomicAdd(&chunk_fg[(long)c * nchunks + pos / CHUNK], 1u);
     }
 }
 
@@ -405,13 +425,20 @@ __global__ __launch_bounds__(256) void lovasz_finalize_kernel(const double* __re
     int present = 0;
     const long nv = counts[C];
     const int used = (int)((nv + CHUNK - 1) / CHUNK);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        if (counts[c] == 0) continue;
-        double s = 0.0;
-        for (int k = 0; k < used; ++k) s += part[(long)c * nchunks + k];
-        total += s;
-        ++present;
+    // the loss is the mean over present classes of their chunk sums = ONE sum over all (present class, chunk) entries: every
+    // thread strides over the flattened list (a thread per class walking its 1024 chunks serially took 125 us at cfg5)
+    for (int c = threadIdx.x; c < C; c += 256) present += counts[c] != 0;
+    const long entries = (long)C * used;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    auto term = [&](long idx) -> double {
+        if (idx >= entries) return 0.0;
+        const int c = (int)(idx / used), k = (int)(idx - (long)c * used);
+        return counts[c] != 0 ? part[(long)c * nchunks + k] : 0.0;
+    };
+    for (long idx = threadIdx.x; idx < entries; idx += 1024) {
+        t0 += term(idx); t1 += term(idx + 256); t2 += term(idx + 512); t3 += term(idx + 768);
     }
+    total = (t0 + t1) + (t2 + t3);
     sm[threadIdx.x] = total; np[threadIdx.x] = present;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -588,15 +615,17 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
             const int shift = L.PB + 1 + 8 * pass;
             const unsigned mask = pass < 3 ? 0xFFu : 0x7Fu;
             hipLaunchKernelGGL(segsort_hist_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, rows, L.ntiles, shift, mask, (const unsigned*)counts, hist);
-            hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, hist, L.ntiles, (const unsigned*)counts);
+            hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256, SCAN_Q), 0, st, hist, L.ntiles, (const unsigned*)counts);
+            if (pass == 3) hipMemsetAsync(chunk_fg, 0, (size_t)C * L.nchunks * sizeof(unsigned), st);
             hipLaunchKernelGGL(segsort_scatter_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, dst, rows, L.ntiles, shift, mask,
-                               (const unsigned*)counts, (const unsigned*)hist);
+                               (const unsigned*)counts, (const unsigned*)hist, pass == 3 ? chunk_fg : (unsigned*)nullptr, L.nchunks, L.PB);
             unsigned long long* t = src; src = dst; dst = t;
         }
         ks = src;                                          // == ka after an even number of passes
     }
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
-    hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
+    if (lovasz_use_rocprim())       // (the hand-written sort counts the foreground keys per chunk in its last scatter pass)
+        hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
     // The scatter of d loss / d p into a class plane of G is 4-byte writes at random pixels: with the whole plane (rows * 4 B =
     // 8.4 MB at cfg5) in flight an XCD's 4 MB L2 evicts partially written lines.  The pass is therefore run once per PIXEL WINDOW of
