@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     constexpr int RW = WQ / 64;                        // rounds per wave
     static_assert(RW == 2 * SEG_MLP, "two load groups per wave");
     __shared__ unsigned long long sorted[ST];
-    __shared__ unsigned wbase[4][256], scan_s[256], gbase[256];
+    __shared__ unsigned lds_u[6][256];                 // rows 0-3: wbase[w][d], 4: scan_s, 5: gbase — rows 1-4 are dead after the
+    unsigned (*wbase)[256] = lds_u;                    // placement and hold the last pass's SEG_FG_LDS chunk counters
+    unsigned* scan_s = lds_u[4];
+    unsigned* gbase = lds_u[5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long* k = in + (long)c * rows;
     const long i0 = (long)tile * ST;
@@ -293,16 +296,32 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     }
     __syncthreads();
     unsigned long long* o = out + (long)c * rows;
+    // last pass (chunk_fg != null): pos is the key's final rank — count the foreground keys per scan chunk here instead of
+    // re-reading all keys in lovasz_chunk_count_kernel.  Integer counts: exact and order-independent.  The fg keys of a tile
+    // share their top digits (their errors are the large ones), i.e. a handful of chunks: they are counted in LDS first and the
+    // block adds its non-zero counters to the global ones (one global atomic per fg key serialised on a few addresses:
+    // the pass went 1.0 -> 2.0 ms).
+    unsigned* cf = lds_u[1];
+    if (chunk_fg) {
+        for (int i = tid; i < nchunks; i += 256) cf[i] = 0u;
+        __syncthreads();
+    }
     for (int j = tid; j < nk; j += 256) {
         const unsigned long long kk = sorted[j];
         const unsigned d = seg_digit(kk, shift, mask);
         const long pos = (long)gbase[d] + (unsigned)(j - (int)wbase[0][d]);
         o[pos] = kk;
-        // last pass: pos is the key's final rank — count the foreground keys per scan chunk here (one integer atomic per fg key,
-        // i.e. per valid pixel: exact and order-independent) instead of re-reading all keys in lovasz_chunk_count_kernel
-        if (chunk_fg && ((kk >> PB) & 1ull)) atomicAdd(&chunk_fg[(long)c * nchunks + pos / CHUNK], 1u);
+        if (chunk_fg && ((kk >> PB) & 1ull)) atomicAdd(&cf[pos / CHUNK], 1u);
+    }
+    if (chunk_fg) {
+        __syncthreads();
+        for (int i = tid; i < nchunks; i += 256) {
+            const unsigned n = cf[i];
+            if (n) atomicAdd(&chunk_fg[(long)c * nchunks + i], n);
+        }
     }
 }
+constexpr int SEG_FG_LDS = 4 * 256;                     // chunk counters that fit the dead LDS rows; more chunks: separate count kernel
 
 // chunk_fg[c][k] = number of fg elements among ranks [k*CHUNK, (k+1)*CHUNK) (ranks < n_valid only)
 __global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned long long* __restrict__ keys, long rows, int nchunks,
@@ -417,31 +436,30 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
 }
 
 // loss_out = {mean over present classes of loss_c, n_present}
-__global__ __launch_bounds__(256) void lovasz_finalize_kernel(const double* __restrict__ part, int nchunks, const unsigned* __restrict__ counts,
-                                                              int C, long rows, float* __restrict__ loss_out) {
-    __shared__ double sm[256];
-    __shared__ int np[256];
+constexpr int FIN_T = 1024;
+__global__ __launch_bounds__(FIN_T) void lovasz_finalize_kernel(const double* __restrict__ part, int nchunks, const unsigned* __restrict__ counts,
+                                                                int C, long rows, float* __restrict__ loss_out) {
+    __shared__ double sm[FIN_T];
+    __shared__ int np[FIN_T];
     double total = 0.0;
     int present = 0;
     const long nv = counts[C];
     const int used = (int)((nv + CHUNK - 1) / CHUNK);
-    // the loss is the mean over present classes of their chunk sums = ONE sum over all (present class, chunk) entries: every
-    // thread strides over the flattened list (a thread per class walking its 1024 chunks serially took 125 us at cfg5)
-    for (int c = threadIdx.x; c < C; c += 256) present += counts[c] != 0;
-    const long entries = (long)C * used;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    auto term = [&](long idx) -> double {
-        if (idx >= entries) return 0.0;
-        const int c = (int)(idx / used), k = (int)(idx - (long)c * used);
-        return counts[c] != 0 ? part[(long)c * nchunks + k] : 0.0;
-    };
-    for (long idx = threadIdx.x; idx < entries; idx += 1024) {
-        t0 += term(idx); t1 += term(idx + 256); t2 += term(idx + 512); t3 += term(idx + 768);
+    // the loss is the mean over present classes of their chunk sums = ONE sum over all (present class, chunk) entries: the block
+    // strides over a class's chunks, class after class (no index division; the loads of the C classes are independent)
+    for (int c = threadIdx.x; c < C; c += FIN_T) present += counts[c] != 0;
+    double t0 = 0.0, t1 = 0.0;
+    for (int c = 0; c < C; ++c) {
+        if (counts[c] == 0) continue;
+        const double* pc = part + (long)c * nchunks;
+        int k = threadIdx.x;
+        for (; k + FIN_T < used; k += 2 * FIN_T) { t0 += pc[k]; t1 += pc[k + FIN_T]; }
+        if (k < used) t0 += pc[k];
     }
-    total = (t0 + t1) + (t2 + t3);
+    total = t0 + t1;
     sm[threadIdx.x] = total; np[threadIdx.x] = present;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = FIN_T / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { sm[threadIdx.x] += sm[threadIdx.x + o]; np[threadIdx.x] += np[threadIdx.x + o]; }
         __syncthreads();
     }
@@ -601,6 +619,7 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     hipLaunchKernelGGL(lovasz_emit_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ld, target, (const float*)lse,
                        rows, C, ignore_index, L.PB, ka);
     const unsigned long long* ks = ka;
+    const bool fused_fg = !lovasz_use_rocprim() && L.nchunks <= SEG_FG_LDS;   // chunk fg counts come out of the last scatter pass
     if (lovasz_use_rocprim()) {
         rocprim::double_buffer<unsigned long long> dk(ka, kb);
         size_t tb = L.temp_bytes;
@@ -616,15 +635,16 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
             const unsigned mask = pass < 3 ? 0xFFu : 0x7Fu;
             hipLaunchKernelGGL(segsort_hist_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, rows, L.ntiles, shift, mask, (const unsigned*)counts, hist);
             hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256, SCAN_Q), 0, st, hist, L.ntiles, (const unsigned*)counts);
-            if (pass == 3) hipMemsetAsync(chunk_fg, 0, (size_t)C * L.nchunks * sizeof(unsigned), st);
+            const bool count_fg = pass == 3 && fused_fg;
+            if (count_fg) hipMemsetAsync(chunk_fg, 0, (size_t)C * L.nchunks * sizeof(unsigned), st);
             hipLaunchKernelGGL(segsort_scatter_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, dst, rows, L.ntiles, shift, mask,
-                               (const unsigned*)counts, (const unsigned*)hist, pass == 3 ? chunk_fg : (unsigned*)nullptr, L.nchunks, L.PB);
+                               (const unsigned*)counts, (const unsigned*)hist, count_fg ? chunk_fg : (unsigned*)nullptr, L.nchunks, L.PB);
             unsigned long long* t = src; src = dst; dst = t;
         }
         ks = src;                                          // == ka after an even number of passes
     }
     dim3 grid((unsigned)L.nchunks, (unsigned)C);
-    if (lovasz_use_rocprim())       // (the hand-written sort counts the foreground keys per chunk in its last scatter pass)
+    if (!fused_fg)
         hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
     // The scatter of d loss / d p into a class plane of G is 4-byte writes at random pixels: with the whole plane (rows * 4 B =
@@ -639,7 +659,7 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     for (int wdw = 0; wdw < nwin; ++wdw)
         hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid1, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
                            (const unsigned*)chunk_fg, G, part, (unsigned)wdw * per, wdw + 1 == nwin ? 0xFFFFFFFFu : (unsigned)(wdw + 1) * per);
-    hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
+    hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
     return segmi_launch_status();
 }
 
