@@ -432,20 +432,25 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
 
 /* LovaszSoftmax (utils/losses.py:79-89 -> utils/lovasz_losses.py:153-218, lovasz_grad :19-31), classes='present',
  * per_image=False: softmax; ignored pixels dropped; per present class sort |fg - p_c| descending, Jaccard-gradient dot;
- * mean over present classes.  One device-wide radix sort of C*rows (class, error) keys replaces the C per-class sorts.
- * G (rows*ldg floats, ldg >= round_up(C,4); layout private to the library: class-major planes) receives d loss_c / d p
- * (un-normalised) and is consumed by the backward; loss_out[2] = {loss, n_present}.  At most 1820 classes.
+ * mean over present classes.  The C per-class sorts run as ONE segmented radix sort over the elements that can matter: an
+ * element ranked after its class's last foreground element has Jaccard difference exactly 0 (lovasz_grad :19-31), so only
+ * elements with error >= the class's smallest foreground error are sorted ("survivors", a prefix of the full order: loss and
+ * gradient are bit-identical to the full sort).
+ * G (rows*ldg floats, ldg >= round_up(C,4), pixel-major) receives d loss_c / d p (un-normalised) for SURVIVOR entries only; it
+ * is neither cleared nor read elsewhere: the backward re-derives the survivor set from logits, lse, target and the thresholds.
+ * loss_out[4 + C] = {loss, n_present, survivors, n_present * n_valid (= keys of the full sort), thr[C] (uint32 error bits)}
+ * must reach segmi_lovasz_bwd unchanged together with lse and G.  At most 1820 classes.
  * rows < 2^24 (the reference's fp32 cumsums are exact only below that) and log2(C) + log2(rows) <= 32.  workspace must be
- * 256-byte aligned. */
-/* Sort used by segmi_lovasz_fwd (process-wide; the workspace size depends on it, query it after the call): 0 = the hand-written
- * segmented radix sort (default), 1 = rocprim::radix_sort_keys over (class, error) — kept for A/B; both are stable, so the
- * results are bit-identical.  Also selectable with SEGMI_LOVASZ_SORT=rocprim at first use. */
-int segmi_lovasz_set_sort(int algorithm);
+ * 256-byte aligned; its size covers the worst case (every element survives). */
+/* Process-wide switch, 1 (default) = tail pruning as above, 0 = every valid pixel of every present class is sorted (A/B and the
+ * bit-identity reference of the tests).  Also SEGMI_LOVASZ_PRUNE=0 at first use. */
+int segmi_lovasz_set_prune(int on);
 size_t segmi_lovasz_workspace(long rows, int C);
 int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
                      float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
-int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float* G, int ldg, long rows, int C,
-                     const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream);
+int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ignore_index, const float* lse, const float* G,
+                     int ldg, long rows, int C, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
+                     segmi_stream_t stream);
 
 /* eval_metrics (utils/metrics.py:42-67; trainer.py:84-86,128-129): argmax (first maximal class) + pixel-accuracy counts +
  * per-class intersection / prediction / label areas, ACCUMULATED into acc[2 + 3*C] int64 =

@@ -3,40 +3,68 @@
 // lovasz_grad :19-31 of the reference, which run softmax + C x (torch.sort over all valid pixels, 2 cumsums, dot)
 // and whose backward scatters through C `probas[:, c]` selects (O(C^2 * P) traffic on the reference).
 //
-// MI355X formulation — all HBM-bound streaming, no host synchronisation:
-//   1. lovasz_prepare   per pixel: log-sum-exp; histogram of labels (class presence, |fg_c|), number of valid pixels
-//   2. lovasz_emit      one 64-bit word per (class, pixel):  [class | invalid | ~bits30(|fg - p_c|) | fg | pixel index]
-//                       (errors lie in [0, 2): their float bits fit 30 bits).  Ascending order of the upper field == classes
-//                       ascending, errors DESCENDING, ignored pixels last inside their class; the low PB + 1 bits are payload.
-//   3. a SEGMENTED least-significant-digit radix sort, hand-written (segsort_* below): the class is implicit in the segment
-//      (keys are emitted class-major), so only the 31-bit field [invalid | ~error] is sorted — four stable 8-bit passes
-//      (histogram per 4096-key tile -> per-class scan -> scatter through an LDS-sorted tile so that every digit's run leaves as
-//      one contiguous write), payload (fg bit, pixel index) riding inside the 64-bit key; absent classes are skipped on the
-//      device.  The per-class torch.sort calls of the reference become 12 bandwidth-bound launches.
-//      (SEGMI_LOVASZ_SORT=rocprim selects the former rocprim::radix_sort_keys over the 31 + log2(C) upper bits for A/B.)
-//   4. lovasz_chunk_count / lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index
-//      at every rank in the same float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels),
-//      first difference, dot with the sorted errors, and scatter of d loss / d p into the class-major G[class][pixel].
-//   5. lovasz_finalize  loss = mean over present classes.
-//   backward: dz_c = g * p_c * (G_c - sum_j G_j p_j) / n_present   (softmax Jacobian; G = 0 for absent classes / ignored pixels)
+// TAIL PRUNING (round 5).  In lovasz_grad (:19-31) every element ranked after the class's LAST foreground element has
+// jaccard[i] - jaccard[i-1] = 1 - 1 = 0 EXACTLY (intersection = gts - cumsum(fg) = 0 from there on): it adds 0 to the dot at
+// :198 and receives gradient 0.  With thr[c] = min over the foreground pixels of class c of their error, only elements with
+// err >= thr[c] (ties kept) can matter, and they are a PREFIX of the class's descending order — ranks, chunk boundaries and
+// the summation order of the survivors are those of the full sort, so loss and gradient are bit-identical to it.  On
+// random-init and on 80 %-accurate logits the survivors are ~0.7 % of the C x P elements (C = 150); a foreground pixel
+// with error 0 (p rounds to 1) keeps its whole class, i.e. the formulation degrades to the full sort.
 //
-// Ties: elements of one class with bit-equal errors may be ranked in any order (torch.sort is unstable too); the loss value
-// does not depend on that order, the per-pixel gradients inside a tie group do.
+// MI355X formulation — all HBM-bound streaming, no host synchronisation (grids are sized for the worst case; workgroups
+// beyond a class's survivor count leave at once):
+//   1. lovasz_prepare     per pixel: log-sum-exp; histogram of labels (class presence, |fg_c|), number of valid pixels,
+//                         thr[c] = atomicMin over fg pixels of the error bits (LDS first, then global)
+//   2. lovasz_keep_count  per (class, 256-pixel unit): number of survivors;  lovasz_keep_scan: exclusive scan per class
+//   3. lovasz_emit        one 64-bit word per SURVIVOR, compacted class-major in pixel order (deterministic: unit offsets +
+//                         ballot ranks):  [class | invalid(0) | ~bits30(|fg - p_c|) | fg | pixel index]
+//                         (errors lie in [0, 2): their float bits fit 30 bits).
+//   4. a SEGMENTED least-significant-digit radix sort, hand-written (segsort_* below) over each class's n_kept[c] keys: the
+//      class is implicit in the segment, so only the 31-bit field [invalid | ~error] is sorted — four stable 8-bit passes
+//      (histogram per 4096-key tile -> per-class scan -> scatter through an LDS-sorted tile so that every digit's run leaves as
+//      one contiguous write), payload (fg bit, pixel index) riding inside the 64-bit key.
+//   5. lovasz_chunk_scan / lovasz_grad_dot: two-level scan of the sorted fg bits -> Jaccard index at every rank in the same
+//      float32 arithmetic as lovasz_grad (integers are exact in fp32 below 2^24 pixels), first difference, dot with the
+//      sorted errors, and scatter of d loss / d p into the pixel-major G[pixel][class] — SURVIVOR entries only.
+//   6. lovasz_finalize    loss = mean over present classes; survivor statistics; effective thresholds for the backward.
+//   backward: dz_c = g * p_c * (G_c - sum_j G_j p_j) / n_present   (softmax Jacobian).  G is read ONLY where the forward's
+//   keep test (recomputed from logits, lse, target and the saved thresholds: same instructions, same bits) says an entry was
+//   written; everything else is 0 by the identity above — G is never cleared and never read densely.
+//
+// Ties: elements of one class with bit-equal errors are ranked in pixel order (stable sort of a pixel-ordered emission;
+// torch.sort is unstable); the loss value does not depend on that order, the per-pixel gradients inside a tie group do.
 #include "segmi_common.h"
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
 constexpr int CHUNK = 2048;   // ranks per scan block (256 threads x 8)
 
+constexpr int UPX = 256;     // pixels per compaction unit = one wave's contiguous share of a 1024-pixel block
+constexpr unsigned NO_THR = 0xFFFFFFFFu;   // threshold of a class without foreground: nothing survives (error bits are < 2^30)
+
+// bits of |fg - p_c| with p_c = exp(z - lse): the ONE expression prepare / count / emit / backward all evaluate (no contraction
+// across the subtractions), so that every pass takes the same keep decision for an element
+__device__ __forceinline__ unsigned lov_err_bits(float z, float l, bool fg) {
+    const float p = expf(__fsub_rn(z, l));
+    return __float_as_uint(fabsf(__fsub_rn(fg ? 1.f : 0.f, p)));
+}
+// effective threshold of class c: absent classes keep nothing; prune == 0 keeps every valid pixel of a present class (the
+// round-4 full sort, kept for A/B and as the bit-identity reference of the tests)
+__device__ __forceinline__ unsigned lov_thr_eff(const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int c, int prune) {
+    return counts[c] == 0 ? NO_THR : (prune ? thr[c] : 0u);
+}
+
 // 8 lanes share a pixel (float4 channel groups, xor-shuffle reductions): coalesced 128-byte row segments
 __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                              long rows, int C, long ignore, float* __restrict__ lse,
-                                                             unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */) {
-    extern __shared__ unsigned hist[];   // C + 1
+                                                             unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */,
+                                                             unsigned* __restrict__ thr /* [C], pre-set to NO_THR */) {
+    extern __shared__ unsigned hist[];   // C + 1 counters, C thresholds
+    unsigned* thr_s = hist + C + 1;
     for (int i = threadIdx.x; i <= C; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = NO_THR;
     __syncthreads();
     const int g = threadIdx.x & 7;
     const int c4n = (C + 3) >> 2;
@@ -63,61 +91,163 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         if (g == 0) {
-            lse[r] = m + logf(s);
+            const float l = m + logf(s);
+            lse[r] = l;
             const long t = target[r];
             if (t != ignore) {
                 atomicAdd(&hist[C], 1u);
-                if (t >= 0 && t < C) atomicAdd(&hist[(int)t], 1u);
+                if (t >= 0 && t < C) {
+                    atomicAdd(&hist[(int)t], 1u);
+                    atomicMin(&thr_s[(int)t], lov_err_bits(row[t], l, true));   // unsigned order == float order for errors >= 0
+                }
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= C; i += 256)
         if (hist[i]) atomicAdd(&counts[i], hist[i]);
+    for (int i = threadIdx.x; i < C; i += 256)
+        if (thr_s[i] != NO_THR) atomicMin(&thr[i], thr_s[i]);
 }
 
-// Block = 256 pixels.  The logits are pixel-major (a pixel's C classes are contiguous) and the keys class-major (a class's
-// pixels are contiguous): 32 classes at a time go through an LDS tile — read as 128-byte row segments (8 lanes x 16 B per
-// pixel), written as 2 KB runs of one class.  (Thread-per-pixel reads straight from HBM were 600-byte-strided dwords: 3.5 ms
-// for cfg5's 1.26 GB of logits, 4x the stream time.)
+// cnt[c][unit] = number of survivors of class c among the unit's UPX pixels.  Same thread layout as prepare (a wave reads 8
+// pixel rows per step as 128-byte segments); a survivor costs one LDS atomic on its wave's counter row.
+__global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                                const float* __restrict__ lse, long rows, int C, long ignore,
+                                                                const unsigned* __restrict__ thr, const unsigned* __restrict__ counts,
+                                                                int prune, long nunits, unsigned* __restrict__ cnt) {
+    extern __shared__ unsigned sh[];     // thr_s[C], run[4][C]
+    unsigned* thr_s = sh;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 7, pj = lane >> 3;
+    unsigned* run = sh + C + w * C;
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = lov_thr_eff(thr, counts, i, prune);
+    for (int i = threadIdx.x; i < 4 * C; i += 256) sh[C + i] = 0u;
+    __syncthreads();
+    const long unit = (long)blockIdx.x * 4 + w;
+    const int c4n = (C + 3) >> 2;
+    if (unit < nunits) {
+        const long r0 = unit * UPX;
+#pragma unroll 2
+        for (int it = 0; it < UPX / 8; ++it) {
+            const long r = r0 + it * 8 + pj;
+            if (r >= rows) continue;
+            const long t = target[r];
+            if (t == ignore) continue;
+            const float l = lse[r];
+            const float* row = logits + r * ld;
+            for (int q = g; q < c4n; q += 8) {
+                const float4 v = ld4(row + q * 4);
+                const int c = q * 4;
+                if (lov_err_bits(v.x, l, t == c) >= thr_s[c]) atomicAdd(&run[c], 1u);
+                if (c + 1 < C && lov_err_bits(v.y, l, t == c + 1) >= thr_s[c + 1]) atomicAdd(&run[c + 1], 1u);
+                if (c + 2 < C && lov_err_bits(v.z, l, t == c + 2) >= thr_s[c + 2]) atomicAdd(&run[c + 2], 1u);
+                if (c + 3 < C && lov_err_bits(v.w, l, t == c + 3) >= thr_s[c + 3]) atomicAdd(&run[c + 3], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (unit < nunits)
+        for (int c = lane; c < C; c += 64) cnt[(long)c * nunits + unit] = run[c];
+}
+
+// in place: cnt[c][:] -> exclusive prefix over the units (= first slot of the unit's survivors in the class segment);
+// nkept[c] = the class's survivor count.  One block per class; a thread owns a contiguous range of units.
+constexpr int KS_T = 1024;
+__global__ __launch_bounds__(KS_T) void lovasz_keep_scan_kernel(unsigned* __restrict__ cnt, long nunits, unsigned* __restrict__ nkept) {
+    const int c = blockIdx.x;
+    unsigned* a = cnt + (long)c * nunits;
+    const long per = (nunits + KS_T - 1) / KS_T;
+    const long b = min(nunits, (long)threadIdx.x * per), e = min(nunits, b + per);
+    unsigned s = 0;
+    for (long i = b; i < e; ++i) s += a[i];
+    __shared__ unsigned sm[KS_T];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < KS_T; o <<= 1) {
+        const unsigned y = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sm[threadIdx.x] += y;
+        __syncthreads();
+    }
+    unsigned run = sm[threadIdx.x] - s;
+    for (long i = b; i < e; ++i) {
+        const unsigned v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == KS_T - 1) nkept[c] = sm[KS_T - 1];
+}
+
+// Survivors -> keys[c * rows + slot], slot = unit offset + rank in pixel order inside the unit.  A wave walks its unit 8 pixels
+// at a time; the 8 lanes holding the same class (same lane & 7, same float4 component) rank themselves with one ballot, the
+// wave's running slot of the class lives in LDS (a wave's LDS operations execute in order: every lane reads the slot before
+// the group's first lane advances it).
 __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                           const float* __restrict__ lse, long rows, int C, long ignore, int PB,
-                                                          unsigned long long* __restrict__ keys) {
-    __shared__ float tile[256][33];
-    const long r0 = (long)blockIdx.x * 256;
-    const long r = r0 + threadIdx.x;
-    const bool rok = r < rows;
-    const long t = rok ? target[r] : ignore;
-    const bool valid = rok && t != ignore;
-    const float l = rok ? lse[r] : 0.f;
-    const int lr = threadIdx.x >> 3, lq = (threadIdx.x & 7) * 4;     // load role: pixel lr (+32 per pass), classes lq..lq+3 of the group
-    for (int cb = 0; cb < C; cb += 32) {
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int pl = pass * 32 + lr;
-            const long rr = r0 + pl;
+                                                          const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int prune,
+                                                          long nunits, const unsigned* __restrict__ cnt, unsigned long long* __restrict__ keys) {
+    extern __shared__ unsigned sh[];     // thr_s[C], slot[4][C]
+    unsigned* thr_s = sh;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 7, pj = lane >> 3;
+    volatile unsigned* slot = sh + C + w * C;
+    const long unit = (long)blockIdx.x * 4 + w;
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = lov_thr_eff(thr, counts, i, prune);
+    if (unit < nunits)
+        for (int c = lane; c < C; c += 64) slot[c] = cnt[(long)c * nunits + unit];
+    __syncthreads();
+    if (unit >= nunits) return;
+    const int c4n = (C + 3) >> 2;
+    const unsigned long long same = 0x0101010101010101ull << g;       // the lanes of my class group
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const long r0 = unit * UPX;
+#pragma unroll 1
+    for (int it = 0; it < UPX / 8; ++it) {
+        const long r = r0 + it * 8 + pj;
+        const bool rok = r < rows;
+        const long t = rok ? target[r] : ignore;
+        const bool valid = rok && t != ignore;
+        if (__ballot(valid) == 0ull) continue;
+        const float l = valid ? lse[r] : 0.f;
+        const float* row = logits + r * ld;
+        for (int q0 = 0; q0 < c4n; q0 += 8) {                          // uniform trip count: the ballots below see the whole wave
+            const int q = q0 + g, c = q * 4;
+            const bool qok = valid && q < c4n;
             float4 v = zero4();
-            if (rr < rows && cb + lq < ld) v = ld4(logits + rr * ld + cb + lq);      // ld is a multiple of 4: whole float4 or none
-            tile[pl][lq] = v.x; tile[pl][lq + 1] = v.y; tile[pl][lq + 2] = v.z; tile[pl][lq + 3] = v.w;
-        }
-        __syncthreads();
-        const int cn = min(32, C - cb);
-        if (rok)
-            for (int j = 0; j < cn; ++j) {
-                const int c = cb + j;
-                const float p = expf(tile[threadIdx.x][j] - l);
-                const bool fg = valid && t == c;
-                const float e = fabsf((fg ? 1.f : 0.f) - p);
-                const unsigned long long inv30 = (unsigned long long)((~__float_as_uint(e)) & 0x3FFFFFFFu);
-                keys[(long)c * rows + r] = ((((unsigned long long)c << 1 | (valid ? 0ull : 1ull)) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
-                                           (unsigned long long)r;
+            if (qok) v = ld4(row + c);
+            const float zs[4] = {v.x, v.y, v.z, v.w};
+            unsigned eb[4];
+            bool kp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                eb[j] = 0u;
+                kp[j] = false;
+                if (qok && c + j < C) {
+                    eb[j] = lov_err_bits(zs[j], l, t == c + j);
+                    kp[j] = eb[j] >= thr_s[c + j];
+                }
             }
-        __syncthreads();
+            if (__ballot(kp[0] || kp[1] || kp[2] || kp[3]) == 0ull) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long m = __ballot(kp[j]) & same;
+                if (kp[j]) {
+                    const int cc = c + j;
+                    const unsigned rank = (unsigned)__popcll(m & below), n = (unsigned)__popcll(m);
+                    const unsigned before = slot[cc];
+                    if (rank == 0) slot[cc] = before + n;
+                    const bool fg = t == cc;
+                    const unsigned long long inv30 = (unsigned long long)((~eb[j]) & 0x3FFFFFFFu);
+                    keys[(long)cc * rows + before + rank] = ((((unsigned long long)cc << 1) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
+                                                            (unsigned long long)r;
+                }
+            }
+        }
     }
 }
 
 // ---- segmented LSD radix sort of the class-major key array: keys[c * rows + i], i < rows, sorted per class by the digit field
 constexpr int ST = 4096;      // keys per sort tile: 256 threads x 16 rounds (8192-key tiles, 73 KB of LDS, two blocks per CU: 3 % slower)
+constexpr int SEG_GX = 64;    // tiles of a class walked concurrently (grid x extent of the sort passes and of the Jaccard pass)
 constexpr int SEG_MLP = 8;    // key loads a wave keeps in flight (16 rounds in groups of SEG_MLP; the ballots of a group stay in SGPRs)
 
 __device__ __forceinline__ unsigned seg_digit(unsigned long long k, int shift, unsigned mask) { return (unsigned)(k >> shift) & mask; }
@@ -135,21 +265,25 @@ __device__ __forceinline__ void wave_peers(unsigned d, bool valid, int lane, uns
     count = (unsigned)__popcll(peers);
 }
 
-// hist[(c * ntiles + tile) * 256 + d] = number of keys of tile `tile` of class c whose digit is d.
+// hist[(c * ntiles + tile) * 256 + d] = number of keys of tile `tile` of class c whose digit is d (tiles below the class's
+// survivor count nkept[c]; the grid is sized for the worst case, the other workgroups leave at once).
 // A histogram does not care about order: one LDS atomic per key into a per-WAVE histogram (four 1 KB rows, summed at the end)
 // instead of the ballot ranking the stable scatter needs — the ballots (9 per 64 keys) made this pass as compute-bound as it is
 // memory-bound (0.75 ms per pass for cfg5's 2.5 GB of keys = 3.3 TB/s); same-address atomics of a digit most keys share (the
 // exponent pass) serialise inside one ds instruction, which is still ~4x cheaper than the ballots.
 __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long long* __restrict__ keys, long rows, int ntiles, int shift,
-                                                           unsigned mask, const unsigned* __restrict__ counts, unsigned* __restrict__ hist) {
-    const int c = blockIdx.y, tile = blockIdx.x;
-    if (counts[c] == 0) return;                          // absent class: never read downstream (classes='present')
+                                                           unsigned mask, const unsigned* __restrict__ nkept, unsigned* __restrict__ hist) {
+    const int c = blockIdx.y;
+    const long n = nkept[c];                             // survivors of the class (0 for an absent class)
     __shared__ unsigned h[4][256];
+    const unsigned long long* k = keys + (long)c * rows;
+    unsigned* hw = h[threadIdx.x >> 6];
+    // the grid's x extent is capped (SEG_GX): a workgroup walks tiles blockIdx.x, + gridDim.x, ... below the survivor count — a
+    // worst-case (ntiles x C) grid cost ~0.5 ns per empty workgroup, 37 us per launch at cfg5 for ~500 tiles of work
+    for (int tile = blockIdx.x; (long)tile * ST < n; tile += gridDim.x) {
     h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0; h[2][threadIdx.x] = 0; h[3][threadIdx.x] = 0;
     __syncthreads();
-    const unsigned long long* k = keys + (long)c * rows;
     const long i0 = (long)tile * ST;
-    unsigned* hw = h[threadIdx.x >> 6];
 #pragma unroll 1
     for (int r0 = 0; r0 < ST / 256; r0 += SEG_MLP) {     // SEG_MLP 512-byte loads per wave in flight (one at a time is latency-bound: 1 TB/s)
         unsigned long long kq[SEG_MLP];
@@ -157,7 +291,7 @@ __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long l
 #pragma unroll
         for (int u = 0; u < SEG_MLP; ++u) {
             const long i = i0 + (r0 + u) * 256 + threadIdx.x;
-            vq[u] = i < rows;
+            vq[u] = i < n;
             kq[u] = vq[u] ? k[i] : 0ull;
         }
 #pragma unroll
@@ -166,6 +300,7 @@ __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long l
     }
     __syncthreads();
     hist[((long)c * ntiles + tile) * 256 + threadIdx.x] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    }
 }
 
 // in place: hist[c][tile][d] -> first output rank (inside the class segment) of that tile's keys with digit d:
@@ -173,10 +308,12 @@ __global__ __launch_bounds__(256) void segsort_hist_kernel(const unsigned long l
 // of digit d's column (coalesced across d), the quarters and the digits are combined through LDS.  (One thread per digit walking
 // all 512 tiles twice: 183 us per pass on 150 of the chip's 256 CUs.)
 constexpr int SCAN_Q = 4;
-__global__ __launch_bounds__(256 * SCAN_Q) void segsort_scan_kernel(unsigned* __restrict__ hist, int ntiles, const unsigned* __restrict__ counts) {
+__global__ __launch_bounds__(256 * SCAN_Q) void segsort_scan_kernel(unsigned* __restrict__ hist, int ntiles_max, const unsigned* __restrict__ nkept) {
     const int c = blockIdx.x, d = threadIdx.x, q = threadIdx.y;
-    if (counts[c] == 0) return;
-    unsigned* col = hist + (long)c * ntiles * 256 + d;
+    const long n = nkept[c];
+    if (n == 0) return;
+    unsigned* col = hist + (long)c * ntiles_max * 256 + d;
+    const int ntiles = (int)((n + ST - 1) / ST);         // tiles in use
     const int per = (ntiles + SCAN_Q - 1) / SCAN_Q;
     const int tb = min(ntiles, q * per), te = min(ntiles, tb + per);
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -246,10 +383,10 @@ __device__ __forceinline__ void seg_rank_rounds(const unsigned long long* __rest
 
 __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                               long rows, int ntiles, int shift, unsigned mask,
-                                                              const unsigned* __restrict__ counts, const unsigned* __restrict__ hist,
+                                                              const unsigned* __restrict__ nkept, const unsigned* __restrict__ hist,
                                                               unsigned* __restrict__ chunk_fg, int nchunks, int PB) {
-    const int c = blockIdx.y, tile = blockIdx.x;
-    if (counts[c] == 0) return;
+    const int c = blockIdx.y;
+    const long n = nkept[c];
     constexpr int WQ = ST / 4;                         // keys per wave
     constexpr int RW = WQ / 64;                        // rounds per wave
     static_assert(RW == 2 * SEG_MLP, "two load groups per wave");
@@ -260,8 +397,10 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     unsigned* gbase = lds_u[5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long* k = in + (long)c * rows;
+    for (int tile = blockIdx.x; (long)tile * ST < n; tile += gridDim.x) {     // capped grid, see segsort_hist_kernel
+    __syncthreads();                                   // the previous tile's LDS readers are done
     const long i0 = (long)tile * ST;
-    const int nk = (int)(rows - i0 < (long)ST ? rows - i0 : (long)ST);
+    const int nk = (int)(n - i0 < (long)ST ? n - i0 : (long)ST);
     wbase[0][tid] = 0; wbase[1][tid] = 0; wbase[2][tid] = 0; wbase[3][tid] = 0;
     gbase[tid] = hist[((long)c * ntiles + tile) * 256 + tid];
     __syncthreads();
@@ -302,8 +441,9 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     // block adds its non-zero counters to the global ones (one global atomic per fg key serialised on a few addresses:
     // the pass went 1.0 -> 2.0 ms).
     unsigned* cf = lds_u[1];
+    const int used = (int)((n + CHUNK - 1) / CHUNK);     // scan chunks of this class in use (<= nchunks <= SEG_FG_LDS)
     if (chunk_fg) {
-        for (int i = tid; i < nchunks; i += 256) cf[i] = 0u;
+        for (int i = tid; i < used; i += 256) cf[i] = 0u;
         __syncthreads();
     }
     for (int j = tid; j < nk; j += 256) {
@@ -315,21 +455,23 @@ __global__ __launch_bounds__(256) void segsort_scatter_kernel(const unsigned lon
     }
     if (chunk_fg) {
         __syncthreads();
-        for (int i = tid; i < nchunks; i += 256) {
-            const unsigned n = cf[i];
-            if (n) atomicAdd(&chunk_fg[(long)c * nchunks + i], n);
+        for (int i = tid; i < used; i += 256) {
+            const unsigned nf = cf[i];
+            if (nf) atomicAdd(&chunk_fg[(long)c * nchunks + i], nf);
         }
+    }
     }
 }
 constexpr int SEG_FG_LDS = 4 * 256;                     // chunk counters that fit the dead LDS rows; more chunks: separate count kernel
 
-// chunk_fg[c][k] = number of fg elements among ranks [k*CHUNK, (k+1)*CHUNK) (ranks < n_valid only)
+// chunk_fg[c][k] = number of fg elements among ranks [k*CHUNK, (k+1)*CHUNK) of the class's survivors (only when the scan
+// chunks do not fit the last scatter pass's LDS counters)
 __global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned long long* __restrict__ keys, long rows, int nchunks,
-                                                                 const unsigned* __restrict__ counts, int C, int PB,
+                                                                 const unsigned* __restrict__ nkept, int PB,
                                                                  unsigned* __restrict__ chunk_fg) {
     const int c = blockIdx.y, k = blockIdx.x;
-    if (counts[c] == 0) return;                          // absent class: skipped by classes='present'
-    const long nv = counts[C];
+    const long nv = nkept[c];
+    if ((long)k * CHUNK >= nv) return;
     const unsigned long long* v = keys + (long)c * rows;
     unsigned n = 0;
     for (int j = threadIdx.x; j < CHUNK; j += 256) {
@@ -343,16 +485,17 @@ __global__ __launch_bounds__(256) void lovasz_chunk_count_kernel(const unsigned 
     if (threadIdx.x == 0) chunk_fg[(long)c * nchunks + k] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// exclusive scan of chunk_fg[c][:] in place (one block per class)
-__global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_fg, int nchunks, const unsigned* __restrict__ counts) {
+// exclusive scan of the used part of chunk_fg[c][:] in place (one block per class)
+__global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_fg, int nchunks, const unsigned* __restrict__ nkept) {
     const int c = blockIdx.x;
-    if (counts[c] == 0) return;
+    const int used = (int)(((long)nkept[c] + CHUNK - 1) / CHUNK);
+    if (used == 0) return;
     unsigned* a = chunk_fg + (long)c * nchunks;
     __shared__ unsigned sm[256];
     unsigned carry = 0;
-    for (int base = 0; base < nchunks; base += 256) {
+    for (int base = 0; base < used; base += 256) {
         const int i = base + threadIdx.x;
-        const unsigned x = i < nchunks ? a[i] : 0u;
+        const unsigned x = i < used ? a[i] : 0u;
         sm[threadIdx.x] = x;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -361,26 +504,26 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
             sm[threadIdx.x] += y;
             __syncthreads();
         }
-        if (i < nchunks) a[i] = carry + sm[threadIdx.x] - x;
+        if (i < used) a[i] = carry + sm[threadIdx.x] - x;
         carry += sm[255];
         __syncthreads();
     }
 }
 
-// Jaccard gradient at every rank, dot product with the sorted errors, scatter of d loss_c / d p into G
+// Jaccard gradient at every rank of the class's survivors, dot product with the sorted errors, scatter of d loss_c / d p into
+// the pixel-major G (survivor entries only: everything else is 0 by the pruning identity and never read by the backward)
 __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned long long* __restrict__ keys,
-                                                              long rows, int nchunks, const unsigned* __restrict__ counts, int C, int PB,
-                                                              const unsigned* __restrict__ chunk_fg, float* __restrict__ G,
-                                                              double* __restrict__ part, unsigned pix_lo, unsigned pix_hi) {
-    // 1-D grid; block b runs on XCD b % 8 and takes class (b/8 / nchunks)*8 + b%8: all chunks of a class scatter into that
-    // class's plane of G from ONE XCD, whose L2 (with the Infinity Cache behind it) merges the 4-byte writes into full lines.
-    // (A pixel-major G[pixel][class] received its 32 dwords per line from 32 classes at 32 different times: 4.9 ms for cfg5.)
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int c = (jb / nchunks) * 8 + xcd, k = jb % nchunks;
-    if (c >= C || counts[c] == 0) return;
-    const long nv = counts[C];
+                                                              long rows, int nchunks, const unsigned* __restrict__ counts,
+                                                              const unsigned* __restrict__ nkept, int PB,
+                                                              const unsigned* __restrict__ chunk_fg, float* __restrict__ G, int ldg,
+                                                              double* __restrict__ part) {
+    const int c = blockIdx.y;
+    const long nv = nkept[c];
     const float gts = (float)counts[c];
     const unsigned long long* kk = keys + (long)c * rows;
+    __shared__ unsigned sm[256];
+    __shared__ float sd[4];
+    for (int k = blockIdx.x; (long)k * CHUNK < nv; k += gridDim.x) {          // capped grid, see segsort_hist_kernel
     // each thread owns 8 consecutive ranks
     const long i0 = (long)k * CHUNK + threadIdx.x * 8;
     unsigned long long vv[8];
@@ -391,7 +534,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
         local += (unsigned)((vv[j] >> PB) & 1ull);
     }
     // block exclusive scan of `local`
-    __shared__ unsigned sm[256];
+    __syncthreads();
     sm[threadIdx.x] = local;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -409,8 +552,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
             const unsigned long long key = vv[j];
             const unsigned fg = (unsigned)((key >> PB) & 1ull);
             const unsigned pix = (unsigned)(key & ((1ull << PB) - 1ull));
-            const bool invalid = (key >> (PB + 31)) & 1ull;       // cannot occur below n_valid (ignored pixels sort last); kept as a guard
-            const float e = invalid ? 0.f : __uint_as_float((~(unsigned)(key >> (PB + 1))) & 0x3FFFFFFFu);
+            const float e = __uint_as_float((~(unsigned)(key >> (PB + 1))) & 0x3FFFFFFFu);
             // lovasz_grad (utils/lovasz_losses.py:19-31) in the same fp32 arithmetic
             const float cum_prev = (float)cum, cum_now = (float)(cum + fg);
             const float inter = gts - cum_now, uni = gts + ((float)(i + 1) - cum_now);
@@ -422,50 +564,55 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
             }
             dot += e * grad;
             // d|fg - p| / dp = -sign(fg - p);  e == 0 -> 0 (torch's abs backward uses sign)
-            const float sgn = invalid || e == 0.f ? 0.f : (fg ? -1.f : 1.f);
-            if (pix >= pix_lo && pix < pix_hi) G[(long)c * rows + pix] = sgn * grad;       // this launch's pixel window (see the caller)
+            const float sgn = e == 0.f ? 0.f : (fg ? -1.f : 1.f);
+            G[(long)pix * ldg + c] = sgn * grad;
             cum += fg;
         }
     }
     dot = wave_sum(dot);
-    __shared__ float sd[4];
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0 && pix_lo == 0) part[(long)c * nchunks + k] = (double)sd[0] + sd[1] + sd[2] + sd[3];
+    if (threadIdx.x == 0) part[(long)c * nchunks + k] = (double)sd[0] + sd[1] + sd[2] + sd[3];
+    }
 }
 
-// loss_out = {mean over present classes of loss_c, n_present}
+// loss_out = {mean over present classes of loss_c, n_present, survivors, n_present * n_valid (the keys of the unpruned
+// formulation), thr_eff[C] (bits)}: the thresholds travel to the backward inside the caller's tensor
 constexpr int FIN_T = 1024;
 __global__ __launch_bounds__(FIN_T) void lovasz_finalize_kernel(const double* __restrict__ part, int nchunks, const unsigned* __restrict__ counts,
-                                                                int C, long rows, float* __restrict__ loss_out) {
-    __shared__ double sm[FIN_T];
+                                                                const unsigned* __restrict__ nkept, const unsigned* __restrict__ thr, int prune,
+                                                                int C, float* __restrict__ loss_out) {
+    __shared__ double sm[FIN_T], sk[FIN_T];
     __shared__ int np[FIN_T];
-    double total = 0.0;
     int present = 0;
-    const long nv = counts[C];
-    const int used = (int)((nv + CHUNK - 1) / CHUNK);
-    // the loss is the mean over present classes of their chunk sums = ONE sum over all (present class, chunk) entries: the block
-    // strides over a class's chunks, class after class (no index division; the loads of the C classes are independent)
-    for (int c = threadIdx.x; c < C; c += FIN_T) present += counts[c] != 0;
-    double t0 = 0.0, t1 = 0.0;
-    for (int c = 0; c < C; ++c) {
-        if (counts[c] == 0) continue;
-        const double* pc = part + (long)c * nchunks;
-        int k = threadIdx.x;
-        for (; k + FIN_T < used; k += 2 * FIN_T) { t0 += pc[k]; t1 += pc[k + FIN_T]; }
-        if (k < used) t0 += pc[k];
+    double kept = 0.0;
+    // the loss is the mean over present classes of their chunk sums = ONE sum over all (present class, used chunk) entries: the
+    // block strides over a class's chunks, class after class (no index division; the loads of the C classes are independent)
+    for (int c = threadIdx.x; c < C; c += FIN_T) {
+        present += counts[c] != 0;
+        kept += (double)nkept[c];
+        reinterpret_cast<unsigned*>(loss_out)[4 + c] = lov_thr_eff(thr, counts, c, prune);
     }
-    total = t0 + t1;
-    sm[threadIdx.x] = total; np[threadIdx.x] = present;
+    // wave w sums classes w, w + 16, ...: lane l takes chunks l, l + 64, ... of the class (fixed order -> deterministic)
+    double t0 = 0.0;
+    for (int c = threadIdx.x >> 6; c < C; c += FIN_T / 64) {
+        const int used = (int)(((long)nkept[c] + CHUNK - 1) / CHUNK);
+        const double* pc = part + (long)c * nchunks;
+        for (int k = threadIdx.x & 63; k < used; k += 64) t0 += pc[k];
+    }
+    const double t1 = 0.0;
+    sm[threadIdx.x] = t0 + t1; np[threadIdx.x] = present; sk[threadIdx.x] = kept;
     __syncthreads();
     for (int o = FIN_T / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sm[threadIdx.x] += sm[threadIdx.x + o]; np[threadIdx.x] += np[threadIdx.x + o]; }
+        if ((int)threadIdx.x < o) { sm[threadIdx.x] += sm[threadIdx.x + o]; np[threadIdx.x] += np[threadIdx.x + o]; sk[threadIdx.x] += sk[threadIdx.x + o]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         loss_out[0] = np[0] > 0 ? (float)(sm[0] / np[0]) : 0.f;
         loss_out[1] = (float)np[0];
+        loss_out[2] = (float)sk[0];
+        loss_out[3] = (float)((double)np[0] * (double)counts[C]);
     }
 }
 
@@ -474,82 +621,75 @@ __device__ __forceinline__ float grp_sum8(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
     return v;
 }
-// dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j).  G is class-major (G[c][pixel]); a block stages the [C][TP] slab of
-// its TP pixels in LDS (coalesced TP*4-byte runs per class), then 8 lanes share a pixel like the forward's prepare kernel.
-__global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ lse,
-                                                         const float* __restrict__ G, long rows, int C, int TP,
+// dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j), streaming: 8 lanes share a pixel like the forward's passes.  G_c is
+// fetched only where the forward's keep test holds (the same lov_err_bits against the thresholds the forward saved) — a
+// sparse gather of the survivor entries; every other G_c is exactly 0.
+__device__ __forceinline__ float lov_g(const float* __restrict__ grow, const unsigned* thr_s, float z, float l, long t, int c) {
+    return lov_err_bits(z, l, t == c) >= thr_s[c] ? grow[c] : 0.f;
+}
+__global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                         long ignore, const float* __restrict__ lse,
+                                                         const float* __restrict__ G, int ldg, long rows, int C,
                                                          const float* __restrict__ loss_out, const float* __restrict__ grad_out,
                                                          float* __restrict__ dl, int lddl) {
-    extern __shared__ float gs_tile[];                   // [C][TP + 1]
-    const int pitch = TP + 1;
+    extern __shared__ unsigned thr_s[];                  // C
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    __syncthreads();
     const int g = threadIdx.x & (LPP - 1);
     const int c4n = (C + 3) >> 2;
     const float np = loss_out[1];
     const float gs = np > 0.f ? grad_out[0] / np : 0.f;
-    const long ntiles = (rows + TP - 1) / TP;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long r0 = tile * TP;
-        __syncthreads();                                 // previous tile's readers are done
-        for (int idx = threadIdx.x; idx < C * TP; idx += 256) {
-            const int c = idx / TP, pl = idx - c * TP;
-            gs_tile[c * pitch + pl] = r0 + pl < rows ? G[(long)c * rows + r0 + pl] : 0.f;
+    for (long r = (long)blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += (long)gridDim.x * 32) {
+        const long t = target[r];
+        float* drow = dl + r * lddl;
+        if (t == ignore) {                               // whole 8-lane group: an ignored pixel has no survivor, dz = 0
+            for (int q = g; q < c4n; q += LPP) st4(drow + q * 4, zero4());
+            continue;
         }
-        __syncthreads();
-        for (int pl = threadIdx.x / LPP; pl < TP; pl += 256 / LPP) {
-            const long r = r0 + pl;
-            if (r >= rows) continue;                     // whole 8-lane group leaves together: the shuffles below stay matched
-            const float l = lse[r];
-            const float* row = logits + r * ld;
-            const float* gr = gs_tile + pl;
-            float s = 0.f;
-            for (int q = g; q < c4n; q += LPP) {
-                const float4 v = ld4(row + q * 4);
-                const int c = q * 4;
-                s += gr[c * pitch] * expf(v.x - l);
-                if (c + 1 < C) s += gr[(c + 1) * pitch] * expf(v.y - l);
-                if (c + 2 < C) s += gr[(c + 2) * pitch] * expf(v.z - l);
-                if (c + 3 < C) s += gr[(c + 3) * pitch] * expf(v.w - l);
-            }
-            s = grp_sum8(s);
-            for (int q = g; q < c4n; q += LPP) {
-                const float4 v = ld4(row + q * 4);
-                const int c = q * 4;
-                float4 d;
-                d.x = gs * expf(v.x - l) * (gr[c * pitch] - s);
-                d.y = c + 1 < C ? gs * expf(v.y - l) * (gr[(c + 1) * pitch] - s) : 0.f;
-                d.z = c + 2 < C ? gs * expf(v.z - l) * (gr[(c + 2) * pitch] - s) : 0.f;
-                d.w = c + 3 < C ? gs * expf(v.w - l) * (gr[(c + 3) * pitch] - s) : 0.f;
-                st4(dl + r * lddl + q * 4, d);
-            }
+        const float l = lse[r];
+        const float* row = logits + r * ld;
+        const float* grow = G + r * ldg;
+        float s = 0.f;
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            s += lov_g(grow, thr_s, v.x, l, t, c) * expf(v.x - l);
+            if (c + 1 < C) s += lov_g(grow, thr_s, v.y, l, t, c + 1) * expf(v.y - l);
+            if (c + 2 < C) s += lov_g(grow, thr_s, v.z, l, t, c + 2) * expf(v.z - l);
+            if (c + 3 < C) s += lov_g(grow, thr_s, v.w, l, t, c + 3) * expf(v.w - l);
+        }
+        s = grp_sum8(s);
+        for (int q = g; q < c4n; q += LPP) {
+            const float4 v = ld4(row + q * 4);
+            const int c = q * 4;
+            float4 d;
+            d.x = gs * expf(v.x - l) * (lov_g(grow, thr_s, v.x, l, t, c) - s);
+            d.y = c + 1 < C ? gs * expf(v.y - l) * (lov_g(grow, thr_s, v.y, l, t, c + 1) - s) : 0.f;
+            d.z = c + 2 < C ? gs * expf(v.z - l) * (lov_g(grow, thr_s, v.z, l, t, c + 2) - s) : 0.f;
+            d.w = c + 3 < C ? gs * expf(v.w - l) * (lov_g(grow, thr_s, v.w, l, t, c + 3) - s) : 0.f;
+            st4(drow + q * 4, d);
         }
     }
-}
-
-// pixels per backward tile: the [C][TP+1] fp32 slab must fit 64 KB of LDS
-int lovasz_bwd_tp(int C) {
-    for (int tp = 64; tp >= 8; tp >>= 1)
-        if ((size_t)C * (tp + 1) * sizeof(float) <= 64u * 1024u) return tp;
-    return 0;
 }
 
 struct LovaszLayout {
-    size_t keys_a, keys_b, chunk_fg, counts, part, temp, total;
-    int nchunks, begin_bit, end_bit, PB, ntiles;
-    size_t temp_bytes;
+    size_t keys_a, keys_b, chunk_fg, counts, thr, nkept, part, cnt, temp, total;
+    int nchunks, PB, ntiles;
+    long nunits;
 };
-// SEGMI_LOVASZ_SORT=rocprim: the device-wide rocPRIM sort over (class, error) instead of the hand-written segmented sort (A/B)
-int g_lovasz_sort = -1;       // 0 segmented (hand-written, default), 1 rocPRIM; segmi_lovasz_set_sort / SEGMI_LOVASZ_SORT
-bool lovasz_use_rocprim() {
-    if (g_lovasz_sort < 0) {
-        const char* e = getenv("SEGMI_LOVASZ_SORT");
-        g_lovasz_sort = (e && !strcmp(e, "rocprim")) ? 1 : 0;
+// SEGMI_LOVASZ_PRUNE=0 / segmi_lovasz_set_prune(0): keep every valid pixel of every present class (the full sort) — A/B and tests
+int g_lovasz_prune = -1;
+bool lovasz_prune() {
+    if (g_lovasz_prune < 0) {
+        const char* e = getenv("SEGMI_LOVASZ_PRUNE");
+        g_lovasz_prune = (e && !strcmp(e, "0")) ? 0 : 1;
     }
-    return g_lovasz_sort == 1;
+    return g_lovasz_prune == 1;
 }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 bool lovasz_layout(long rows, int C, LovaszLayout* L) {
-    if (rows <= 0 || C <= 0 || rows >= (1L << 31) || rows >= (1L << 24)) return false;   // fp32-exact cumsums like the reference
+    if (rows <= 0 || C <= 0 || C > 1820 || rows >= (1L << 24)) return false;   // fp32-exact cumsums like the reference
     const size_t n = (size_t)rows * C;
     L->nchunks = (int)((rows + CHUNK - 1) / CHUNK);
     int cb = 1;
@@ -558,24 +698,19 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
     while ((1L << pb) < rows) ++pb;
     if (cb + pb + 32 > 64) return false;                  // class | invalid | 30-bit error | fg | pixel must fit one 64-bit key
     L->PB = pb;
-    L->begin_bit = pb + 1;
-    L->end_bit = pb + 32 + cb;
+    L->nunits = (rows + UPX - 1) / UPX;
     size_t off = 0;
+    // the key buffers are sized for the worst case (every element survives); only the survivors' part of each class segment is touched
     L->keys_a = off; off += align256(n * 8);
     L->keys_b = off; off += align256(n * 8);
     L->chunk_fg = off; off += align256((size_t)C * L->nchunks * 4);
     L->counts = off; off += align256((size_t)(C + 1) * 4);
+    L->thr = off; off += align256((size_t)C * 4);
+    L->nkept = off; off += align256((size_t)C * 4);
     L->part = off; off += align256((size_t)C * L->nchunks * 8);
-    // scratch of the sort: per-tile digit histograms [C][ntiles][256] of the segmented sort, or rocPRIM's temporary storage
-    // (histograms / lookback state: a host-side size query, nothing is launched)
+    L->cnt = off; off += align256((size_t)C * L->nunits * 4);
     L->ntiles = (int)((rows + ST - 1) / ST);
-    size_t tb = (size_t)C * L->ntiles * 256 * sizeof(unsigned);
-    if (lovasz_use_rocprim()) {
-        rocprim::double_buffer<unsigned long long> dk(nullptr, nullptr);
-        if (rocprim::radix_sort_keys(nullptr, tb, dk, n, (unsigned)L->begin_bit, (unsigned)L->end_bit, (hipStream_t)0) != hipSuccess) tb = 64u << 20;
-    }
-    L->temp_bytes = tb;
-    L->temp = off; off += align256(tb);
+    L->temp = off; off += align256((size_t)C * L->ntiles * 256 * sizeof(unsigned));   // per-tile digit histograms [C][ntiles][256]
     L->total = off;
     return true;
 }
@@ -584,9 +719,9 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
 
 extern "C" {
 
-int segmi_lovasz_set_sort(int algorithm) {
-    if (algorithm != 0 && algorithm != 1) return SEGMI_ERR_BADARG;
-    g_lovasz_sort = algorithm;
+int segmi_lovasz_set_prune(int on) {
+    if (on != 0 && on != 1) return SEGMI_ERR_BADARG;
+    g_lovasz_prune = on;
     return SEGMI_OK;
 }
 
@@ -608,71 +743,60 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     unsigned long long* kb = (unsigned long long*)(ws + L.keys_b);
     unsigned* chunk_fg = (unsigned*)(ws + L.chunk_fg);
     unsigned* counts = (unsigned*)(ws + L.counts);
+    unsigned* thr = (unsigned*)(ws + L.thr);
+    unsigned* nkept = (unsigned*)(ws + L.nkept);
+    unsigned* cnt = (unsigned*)(ws + L.cnt);
     double* part = (double*)(ws + L.part);
+    const int prune = lovasz_prune() ? 1 : 0;
 
     hipMemsetAsync(counts, 0, (size_t)(C + 1) * 4, st);
-    hipMemsetAsync(G, 0, (size_t)rows * ldg * sizeof(float), st);
+    hipMemsetAsync(thr, 0xFF, (size_t)C * 4, st);
     long pb = (rows + 31) / 32;
     if (pb > SEGMI_MAX_GRID) pb = SEGMI_MAX_GRID;
-    hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(C + 1) * 4, st, logits, ld, target, rows, C,
-                       ignore_index, lse, counts);
-    hipLaunchKernelGGL(lovasz_emit_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ld, target, (const float*)lse,
-                       rows, C, ignore_index, L.PB, ka);
-    const unsigned long long* ks = ka;
-    const bool fused_fg = !lovasz_use_rocprim() && L.nchunks <= SEG_FG_LDS;   // chunk fg counts come out of the last scatter pass
-    if (lovasz_use_rocprim()) {
-        rocprim::double_buffer<unsigned long long> dk(ka, kb);
-        size_t tb = L.temp_bytes;
-        if (rocprim::radix_sort_keys(ws + L.temp, tb, dk, (size_t)rows * C, (unsigned)L.begin_bit, (unsigned)L.end_bit, st) != hipSuccess) return SEGMI_ERR_LAUNCH;
-        ks = dk.current();
-    } else {
-        // four stable 8-bit passes over the 31-bit field [invalid | ~error] above the fg bit: ka -> kb -> ka -> kb -> ka
-        unsigned* hist = (unsigned*)(ws + L.temp);
-        unsigned long long *src = ka, *dst = kb;
-        const dim3 tgrid((unsigned)L.ntiles, (unsigned)C);
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = L.PB + 1 + 8 * pass;
-            const unsigned mask = pass < 3 ? 0xFFu : 0x7Fu;
-            hipLaunchKernelGGL(segsort_hist_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, rows, L.ntiles, shift, mask, (const unsigned*)counts, hist);
-            hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256, SCAN_Q), 0, st, hist, L.ntiles, (const unsigned*)counts);
-            const bool count_fg = pass == 3 && fused_fg;
-            if (count_fg) hipMemsetAsync(chunk_fg, 0, (size_t)C * L.nchunks * sizeof(unsigned), st);
-            hipLaunchKernelGGL(segsort_scatter_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, dst, rows, L.ntiles, shift, mask,
-                               (const unsigned*)counts, (const unsigned*)hist, count_fg ? chunk_fg : (unsigned*)nullptr, L.nchunks, L.PB);
-            unsigned long long* t = src; src = dst; dst = t;
-        }
-        ks = src;                                          // == ka after an even number of passes
+    hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(2 * C + 1) * 4, st, logits, ld, target, rows, C,
+                       ignore_index, lse, counts, thr);
+    const unsigned ublocks = (unsigned)((L.nunits + 3) / 4);
+    hipLaunchKernelGGL(lovasz_keep_count_kernel, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C,
+                       ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt);
+    hipLaunchKernelGGL(lovasz_keep_scan_kernel, dim3((unsigned)C), dim3(KS_T), 0, st, cnt, L.nunits, nkept);
+    hipLaunchKernelGGL(lovasz_emit_kernel, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C,
+                       ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka);
+    const bool fused_fg = L.nchunks <= SEG_FG_LDS;         // chunk fg counts come out of the last scatter pass
+    // four stable 8-bit passes over the 31-bit field [invalid | ~error] above the fg bit: ka -> kb -> ka -> kb -> ka
+    unsigned* hist = (unsigned*)(ws + L.temp);
+    unsigned long long *src = ka, *dst = kb;
+    const dim3 tgrid((unsigned)(L.ntiles < SEG_GX ? L.ntiles : SEG_GX), (unsigned)C);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = L.PB + 1 + 8 * pass;
+        const unsigned mask = pass < 3 ? 0xFFu : 0x7Fu;
+        hipLaunchKernelGGL(segsort_hist_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, rows, L.ntiles, shift, mask, (const unsigned*)nkept, hist);
+        hipLaunchKernelGGL(segsort_scan_kernel, dim3((unsigned)C), dim3(256, SCAN_Q), 0, st, hist, L.ntiles, (const unsigned*)nkept);
+        const bool count_fg = pass == 3 && fused_fg;
+        if (count_fg) hipMemsetAsync(chunk_fg, 0, (size_t)C * L.nchunks * sizeof(unsigned), st);
+        hipLaunchKernelGGL(segsort_scatter_kernel, tgrid, dim3(256), 0, st, (const unsigned long long*)src, dst, rows, L.ntiles, shift, mask,
+                           (const unsigned*)nkept, (const unsigned*)hist, count_fg ? chunk_fg : (unsigned*)nullptr, L.nchunks, L.PB);
+        unsigned long long* t = src; src = dst; dst = t;
     }
-    dim3 grid((unsigned)L.nchunks, (unsigned)C);
+    const unsigned long long* ks = src;                    // == ka after an even number of passes
+    const dim3 grid((unsigned)L.nchunks, (unsigned)C), jgrid((unsigned)(L.nchunks < 2 * SEG_GX ? L.nchunks : 2 * SEG_GX), (unsigned)C);
     if (!fused_fg)
-        hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB, chunk_fg);
-    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)counts);
-    // The scatter of d loss / d p into a class plane of G is 4-byte writes at random pixels: with the whole plane (rows * 4 B =
-    // 8.4 MB at cfg5) in flight an XCD's 4 MB L2 evicts partially written lines.  The pass is therefore run once per PIXEL WINDOW of
-    // <= 4.5 MB (the sorted keys are re-read, the writes of a window merge into full lines in L2).  Measured at cfg5 in one call
-    // (SEGMI_LOVASZ_WINDOWS overrides): 1 window 69.2 ms/step, 2 windows 68.45, 3 windows 68.67, 4 windows 69.71.
-    const dim3 grid1((unsigned)(8 * ((C + 7) / 8)) * (unsigned)L.nchunks);
-    int nwin = (int)(((size_t)rows * 4 + (9u << 19) - 1) / (9u << 19));
-    if (const char* e = getenv("SEGMI_LOVASZ_WINDOWS")) { const int v = atoi(e); if (v >= 1 && v <= 16) nwin = v; }
-    if (nwin < 1) nwin = 1;
-    const unsigned per = (unsigned)((rows + nwin - 1) / nwin);
-    for (int wdw = 0; wdw < nwin; ++wdw)
-        hipLaunchKernelGGL(lovasz_grad_dot_kernel, grid1, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, C, L.PB,
-                           (const unsigned*)chunk_fg, G, part, (unsigned)wdw * per, wdw + 1 == nwin ? 0xFFFFFFFFu : (unsigned)(wdw + 1) * per);
-    hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts, C, rows, loss_out);
+        hipLaunchKernelGGL(lovasz_chunk_count_kernel, grid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)nkept, L.PB, chunk_fg);
+    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3((unsigned)C), dim3(256), 0, st, chunk_fg, L.nchunks, (const unsigned*)nkept);
+    hipLaunchKernelGGL(lovasz_grad_dot_kernel, jgrid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, (const unsigned*)nkept, L.PB,
+                       (const unsigned*)chunk_fg, G, ldg, part);
+    hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts,
+                       (const unsigned*)nkept, (const unsigned*)thr, prune, C, loss_out);
     return segmi_launch_status();
 }
 
-int segmi_lovasz_bwd(const float* logits, int ld, const float* lse, const float* G, int ldg, long rows, int C,
-                     const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
-    if (!logits || !lse || !G || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
+int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ignore_index, const float* lse, const float* G, int ldg,
+                     long rows, int C, const float* loss_out, const float* grad_out, float* dlogits, int lddl, segmi_stream_t stream) {
+    if (!logits || !target || !lse || !G || !loss_out || !grad_out || !dlogits || rows <= 0 || C <= 0 || C > 1820) return SEGMI_ERR_BADARG;
     if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
-    const int tp = lovasz_bwd_tp(C);
-    if (tp == 0) return SEGMI_ERR_BADARG;               // > 1820 classes
-    long b = (rows + tp - 1) / tp;
+    long b = (rows + 31) / 32;
     if (b > 4 * SEGMI_MAX_GRID) b = 4 * SEGMI_MAX_GRID;
-    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), (size_t)C * (tp + 1) * sizeof(float), (hipStream_t)stream, logits, ld,
-                       lse, G, rows, C, tp, loss_out, grad_out, dlogits, lddl);
+    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), (size_t)C * 4, (hipStream_t)stream, logits, ld, target, ignore_index,
+                       lse, G, ldg, rows, C, loss_out, grad_out, dlogits, lddl);
     return segmi_launch_status();
 }
 

@@ -130,10 +130,10 @@ SIGNATURES = {
     "segmi_dice_finalize": (i32, [vp, f32, vp, vp]),
     "segmi_focal_fwd": (i32, [vp, i32, vp, i64, i32, i64, f32, vp, vp, vp, vp, sz, vp]),
     "segmi_focal_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, f32, vp, vp, vp, vp, i32, vp]),
-    "segmi_lovasz_set_sort": (i32, [i32]),
+    "segmi_lovasz_set_prune": (i32, [i32]),
     "segmi_lovasz_workspace": (sz, [i64, i32]),
     "segmi_lovasz_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, i32, vp, vp, sz, vp]),
-    "segmi_lovasz_bwd": (i32, [vp, i32, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),
+    "segmi_lovasz_bwd": (i32, [vp, i32, vp, i64, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),
     "segmi_seg_metrics": (i32, [vp, i32, vp, i64, i32, vp, vp]),
     "segmi_sgd_chunk_elems": (i32, []),
     "segmi_sgd_step": (i32, [vp, i32, vp, vp, vp, i32, vp]),

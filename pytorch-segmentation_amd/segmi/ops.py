@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "conv2d_fan", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -1902,6 +1902,9 @@ def focal_loss(logits, target, ignore_index=255, gamma=2.0, alpha=None, size_ave
     return _FocalFn.apply(logits, target, int(ignore_index), float(gamma), alpha, bool(size_average), group)
 
 
+_LOVASZ_LAST = {"out": None}
+
+
 class _LovaszFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
@@ -1911,31 +1914,46 @@ class _LovaszFn(torch.autograd.Function):
         dev, st = logits.device, _stream()
         nws = lib.segmi_lovasz_workspace(rows, C)
         if nws == 0:
-            raise SegmiError("lovasz_softmax: unsupported size (needs 0 < pixels < 2^24, got %d)" % rows)
+            raise SegmiError("lovasz_softmax: unsupported size (needs 0 < pixels < 2^24 and at most 1820 classes, got %d x %d)" % (rows, C))
         ws = workspace(nws + 256, dev)
         wp = (ws.data_ptr() + 255) & ~255
         lse = torch.empty(rows, device=dev, dtype=torch.float32)
+        # G is written and read at the SURVIVOR entries only (see include/segmi.h): never cleared
         G = empty_nhwc(N, C, H, W, dev)
-        out = torch.empty(2, device=dev, dtype=torch.float32)
+        if os.environ.get("SEGMI_LOVASZ_POISON") == "1":          # tests: any read of an unwritten entry turns the gradient NaN
+            G.fill_(float("nan"))
+        out = torch.empty(4 + C, device=dev, dtype=torch.float32)
         check(lib.segmi_lovasz_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
                                    G.data_ptr(), ld_of(G), out.data_ptr(), wp, nws, st), "lovasz_fwd")
-        ctx.save_for_backward(logits, lse, G, out)
+        ctx.save_for_backward(logits, target, lse, G, out)
+        ctx.ignore_index = ignore_index
+        _LOVASZ_LAST["out"] = out
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        logits, lse, G, out = ctx.saved_tensors
+        logits, target, lse, G, out = ctx.saved_tensors
         N, C, H, W = logits.shape
         g = g.contiguous().float()
         dl = empty_nhwc(N, C, H, W, logits.device)
-        check(lib.segmi_lovasz_bwd(logits.data_ptr(), ld_of(logits), lse.data_ptr(), G.data_ptr(), ld_of(G), N * H * W, C,
-                                   out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "lovasz_bwd")
+        check(lib.segmi_lovasz_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), ctx.ignore_index, lse.data_ptr(), G.data_ptr(),
+                                   ld_of(G), N * H * W, C, out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "lovasz_bwd")
         return dl, None, None
 
 
 def lovasz_softmax(logits, target, ignore_index=255):
     """LovaszSoftmax.forward of the reference (softmax + lovasz_softmax(classes='present', per_image=False, ignore=...))."""
     return _LovaszFn.apply(logits, target, int(ignore_index))
+
+
+def lovasz_last_stats():
+    """(survivors, keys of the full sort) of the most recent lovasz_softmax call: how many (class, pixel) elements the tail
+    pruning kept out of n_present * n_valid.  Synchronises; for reporting only."""
+    out = _LOVASZ_LAST["out"]
+    if out is None:
+        return None
+    kept, full = out[2:4].tolist()
+    return int(kept), int(full)
 
 
 def seg_metrics_accumulate(logits, target, acc):

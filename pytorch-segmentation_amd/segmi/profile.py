@@ -52,10 +52,12 @@ MEMBOUND_BYTES = {
     "segmi_dwconv2d_fwd": lambda a: _dw_bytes(a[0]),
     "segmi_dwconv2d_dgrad": lambda a: _dw_bytes(a[0]),
     "segmi_dwconv2d_wgrad": lambda a: _dw_bytes(a[0]),
-    # Lovasz forward = softmax + per-class sort + Jaccard scan: logits read once (4 B), one 8-byte key per (class, pixel) written by
-    # the emit pass, read + written by each of the 4 radix passes and read by the scan (80 B), G written once (4 B)
-    "segmi_lovasz_fwd": lambda a: 88 * a[3] * a[4],
-    "segmi_lovasz_bwd": lambda a: _b4(3 * a[5] * a[6]),
+    # Lovasz forward, tail-pruned (round 5): the threshold of a class is a reduction over ALL its pixels, so the logits are read at
+    # least twice (4 B each: threshold pass, selection pass) — the survivors' sort traffic (~0.7 % of the elements x 88 B) is below
+    # 1 B per element and not counted.  The implementation reads them three times (threshold, count, emit).
+    "segmi_lovasz_fwd": lambda a: 8 * a[3] * a[4],
+    # backward: logits read, dlogits written (G only at the survivor entries)
+    "segmi_lovasz_bwd": lambda a: _b4(2 * a[7] * a[8]),
     "segmi_relu_fwd": lambda a: _b4(2 * a[4] * a[5]),
     "segmi_add": lambda a: _b4(3 * a[6] * a[7]),
 }

@@ -497,33 +497,57 @@ def test_lovasz_softmax_vs_oracle(cuda, case):
     assert float(xd.grad.cpu()[:, :, :2, :].abs().max()) == 0.0     # ignored pixels get no gradient
 
 
-@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255), (2, 19, 200, 210, 255), (1, 7, 5, 3, 255),
-                                  (2, 21, 256, 256, 255)])
-def test_lovasz_segmented_sort_equals_library_sort(cuda, case):
-    """The hand-written segmented radix sort of csrc/lovasz.hip (the default) and rocprim::radix_sort_keys (kept for A/B,
-    segmi_lovasz_set_sort) are both STABLE sorts of the same keys over the same bits, so loss and gradient must agree BIT FOR BIT —
-    on single-tile, multi-tile and ragged-last-tile segments (84 000 = 20.5 tiles of 4096 keys), with ignored pixels, absent
-    classes, and random (not block-constant) targets that put ties next to each other."""
-    import utils.losses as L
-    from segmi import lib
+def _lovasz_logits(case, mode, seed=23):
+    """random = random-init-like logits; trained = the target logit boosted on 80 % of the pixels (confident, mostly right);
+    saturated = a few foreground pixels whose probability rounds to 1 (error 0: their class keeps every element)."""
     N, C, H, W, ign = case
-    g = torch.Generator().manual_seed(23)
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, C, H, W, generator=g) * 3
     t = torch.randint(0, max(2, C - 2), (N, H, W), generator=g)
     t[:, :1, :] = ign
-    res = []
+    if mode in ("trained", "saturated"):
+        hit = torch.rand(N, H, W, generator=g) < 0.8
+        boost = 40.0 if mode == "saturated" else 6.0
+        x.scatter_add_(1, t.clamp(0, C - 1).unsqueeze(1), (hit & (t != ign)).float().unsqueeze(1) * boost)
+    return x, t
+
+
+@pytest.mark.parametrize("mode", ["random", "trained", "saturated"])
+@pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255), (2, 19, 200, 210, 255), (1, 7, 5, 3, 255),
+                                  (2, 21, 256, 256, 255)])
+def test_lovasz_tail_pruning_is_bit_identical_to_the_full_sort(cuda, case, mode, monkeypatch):
+    """Round 5: only elements with error >= their class's smallest foreground error are sorted (lovasz_grad gives every element
+    behind the last foreground one a Jaccard difference of exactly 0, utils/lovasz_losses.py:19-31).  The survivors are a prefix
+    of the full stable order, so loss AND gradient must agree BIT FOR BIT with segmi_lovasz_set_prune(0) (every valid pixel of
+    every present class sorted = the round-4 formulation) — on single-tile, multi-tile and ragged segments, with ignored pixels,
+    absent classes, random targets (ties next to each other), confident logits and saturated probabilities (error 0 keeps a
+    whole class).  G is poisoned with NaN first: the backward may only read entries the forward wrote."""
+    import utils.losses as L
+    from segmi import lib, ops
+    monkeypatch.setenv("SEGMI_LOVASZ_POISON", "1")
+    N, C, H, W, ign = case
+    x, t = _lovasz_logits(case, mode)
+    res, stats = [], []
     try:
-        for algo in (0, 1):
-            assert lib.segmi_lovasz_set_sort(algo) == 0
+        for prune in (1, 0):
+            assert lib.segmi_lovasz_set_prune(prune) == 0
             xd = x.to(cuda).requires_grad_(True)
             ld = L.LovaszSoftmax(ignore_index=ign)(xd, t.to(cuda))
             ld.backward()
             res.append((ld.detach().clone(), xd.grad.clone()))
+            stats.append(ops.lovasz_last_stats())
     finally:
-        lib.segmi_lovasz_set_sort(0)
+        lib.segmi_lovasz_set_prune(1)
+    assert lib.segmi_lovasz_set_prune(7) != 0
     assert torch.equal(res[0][0], res[1][0]), (res[0][0].item(), res[1][0].item())
     assert torch.equal(res[0][1], res[1][1]), (res[0][1] - res[1][1]).abs().max().item()
-    assert torch.isfinite(res[0][0]) and float(res[0][1].abs().max()) > 0
+    assert torch.isfinite(res[0][0]) and torch.isfinite(res[0][1]).all() and float(res[0][1].abs().max()) > 0
+    (kept, full), (kept_all, full_all) = stats
+    assert full == full_all and kept_all == full_all            # prune(0) sorts n_present * n_valid elements
+    n_valid = int((t != ign).sum())
+    assert n_valid <= kept <= full and full % n_valid == 0      # every valid pixel survives at least as the foreground of its class
+    if mode == "random" and C >= 19 and N * H * W > 1000:
+        assert kept < 0.5 * full, (kept, full)                  # the pruning actually prunes
 
 
 def test_fused_sgd_matches_torch_sgd(cuda):

@@ -112,20 +112,22 @@ def test_winograd_plans_are_consistent(d):
 @settings(max_examples=100, deadline=None)
 @given(st.integers(1, 1 << 22), st.sampled_from([2, 3, 19, 21, 150, 255]))
 def test_lovasz_workspace_layout(rows, C):
-    """segmi_lovasz_workspace under both sorts: two 64-bit key buffers + scan scratch + the sort's own scratch (per-tile digit
-    histograms [C][ceil(rows/4096)][256] for the hand-written segmented sort), 256-byte aligned pieces; set_sort is validated."""
+    """segmi_lovasz_workspace covers the worst case of the tail pruning (every element survives): two 64-bit key buffers +
+    the survivor counts per (class, 256-pixel unit) + scan scratch + per-tile digit histograms [C][ceil(rows/4096)][256] of the
+    segmented sort, 256-byte aligned pieces; it does not depend on the prune switch, which is validated."""
     from segmi import lib
-    assert lib.segmi_lovasz_set_sort(7) != 0
+    assert lib.segmi_lovasz_set_prune(7) != 0
     try:
-        assert lib.segmi_lovasz_set_sort(0) == 0
-        seg = lib.segmi_lovasz_workspace(rows, C)
-        assert lib.segmi_lovasz_set_sort(1) == 0
-        roc = lib.segmi_lovasz_workspace(rows, C)
+        assert lib.segmi_lovasz_set_prune(0) == 0
+        full = lib.segmi_lovasz_workspace(rows, C)
     finally:
-        lib.segmi_lovasz_set_sort(0)
+        assert lib.segmi_lovasz_set_prune(1) == 0
+    seg = lib.segmi_lovasz_workspace(rows, C)
+    assert seg == full
     keys = 2 * ((rows * C * 8 + 255) & ~255)
     hist = C * ((rows + 4095) // 4096) * 256 * 4
-    assert seg % 256 == 0 and roc % 256 == 0
-    assert seg >= keys + hist and seg - keys - ((hist + 255) & ~255) < (1 << 20) + C * ((rows + 2047) // 2048) * 12 + 2048
-    assert roc >= keys
+    units = C * ((rows + 255) // 256) * 4
+    assert seg % 256 == 0
+    assert seg >= keys + hist + units
+    assert seg - keys - ((hist + 255) & ~255) - ((units + 255) & ~255) < (1 << 20) + C * ((rows + 2047) // 2048) * 12 + 4096
     assert lib.segmi_lovasz_workspace(1 << 24, C) == 0          # fp32-exact rank arithmetic ends at 2^24 pixels, like the reference's cumsums
