@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
                                                          "one host call per step instead of ~800 launches")
+    ap.add_argument("--lovasz-boost", type=float, default=0.0,
+                    help="cfg5 A/B only: add this to the target logit on 80 %% of the pixels before the loss (trained-like, confident logits "
+                         "instead of random-init ones: more elements survive the Lovasz tail pruning); costs one extra elementwise add per step")
     ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
                     help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
                          "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
@@ -236,6 +239,12 @@ def main():
     crit = getattr(losses_mod, loss_name)(ignore_index=ign)
     x, t = synth_batch(args.config, device, rank)
     psp = arch[:3] == "PSP"          # the reference keys the (out, aux) convention on the arch name (trainer.py:57-62)
+    boost = None
+    if args.lovasz_boost and not psp:
+        gb = torch.Generator().manual_seed(99 + rank)
+        hit = (torch.rand(nb, h, w, generator=gb) < 0.8).to(device) & (t != ign)
+        boost = segmi_ops.to_nhwc(torch.zeros(nb, classes, h, w, device=device).scatter_(
+            1, t.clamp(0, classes - 1).unsqueeze(1), hit.float().unsqueeze(1) * args.lovasz_boost))
 
     def step():
         if dm is not None:
@@ -246,7 +255,8 @@ def main():
             out, aux = model(x)
             loss = crit(out, t) + 0.4 * crit(aux, t)
         else:
-            loss = crit(model(x), t)
+            out = model(x)
+            loss = crit(out if boost is None else out + boost, t)
         loss.backward()
         if bucket_step:
             dm.finish_gradients(opt)         # per bucket: wait for its all-reduce, then its fused SGD launch
@@ -295,8 +305,8 @@ def main():
                "achieved": round(mem_b / (mem_ms * 1e-3) / 1e12, 3) if mem_ms else None,
                "frac": round(mem_b / (mem_ms * 1e-3) / 8.0e12, 4) if mem_ms else None,
                "scope": "every HBM-bound C-ABI call of the instrumented step (HIP events per call, event pairs add ~2 us to calls shorter than "
-                        "~10 us); bytes = algorithmic (each operand tensor once; Lovasz: 88 B per (class, pixel) = logits + 8-byte sort key "
-                        "through emit, 4 radix passes and the scan + G)",
+                        "~10 us); bytes = algorithmic (each operand tensor once; Lovasz forward: 8 B per (class, pixel) = the logits read "
+                        "twice, threshold pass + selection pass, the survivors' sort traffic not counted; backward: logits read + dlogits written)",
                "top": [{"call": k, "launches": r["launches"], "ms_per_step": round(r["total_ms"], 3), "gb": round(r["bytes"] / 1e9, 3),
                         "tbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e12, 2), "frac": round(r["bytes"] / (r["total_ms"] * 1e-3) / 8.0e12, 3)}
                        for k, r in sorted(mem.items(), key=lambda kv: -kv[1]["total_ms"])[:8]]}
@@ -425,6 +435,14 @@ def main():
                 rccl_ranks = 0
         dist.barrier()
 
+    # Lovasz tail pruning: survivors of the last step's loss call out of the n_present * n_valid elements of the full sort
+    lovasz_stats = None
+    if loss_name == "LovaszSoftmax" and segmi_ops.lovasz_last_stats() is not None:
+        kept, full = segmi_ops.lovasz_last_stats()
+        lovasz_stats = {"survivors": kept, "full_sort_keys": full, "kept_frac": round(kept / max(full, 1), 5),
+                        "logits": "random-init model output" if boost is None else "model output + %.1f on the target class of 80 %% of the pixels" % args.lovasz_boost,
+                        "prune": os.environ.get("SEGMI_LOVASZ_PRUNE", "1") != "0"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(args.config)
@@ -450,7 +468,8 @@ def main():
                        "hip_graph": bool(args.graph), "wgrad_side_stream": bool(segmi_ops.get_wgrad_stream()["on"]),
                        "bn_stats_from_conv_epilogue": bool(segmi_ops.get_conv_bn_stats()["on"]),
                        "grad_buckets_mb": ([round(b["buf"].numel() * 4 / 2 ** 20, 1) for b in dm.reducer.buckets] if dm is not None else None),
-                       "syncbn_collectives_per_step": syncbn_per_step},
+                       "syncbn_collectives_per_step": syncbn_per_step,
+                       "lovasz": lovasz_stats},
             "roofline": roof, "cpu_baseline": cpu, "alt": alt, ("alt_direct" if wino_default else "alt_winograd"): alt_algo,
         }
         print(json.dumps(line), flush=True)
