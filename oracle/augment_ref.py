@@ -12,7 +12,8 @@ ToTensor, Normalize) step by step.  The cv2 calls are restated from OpenCV's PUB
       out :   uchar((((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2)
       exact 2x2 decimation (both scales == 2): OpenCV switches INTER_LINEAR to INTER_AREA: (a + b + c + d + 2) >> 2
   cv2.resize INTER_NEAREST (resizeNN)            s = min(floor(d * (1 / ((double)dst / src))), src - 1)
-  PIL Image.resize(NEAREST) (validation labels)  s = min(floor((d + 0.5) * src / dst), src - 1)         (Geometry.c nearest filter)
+  PIL Image.resize(NEAREST) (validation labels)  xo = 0.5 * a, s[d] = min((int)xo, src - 1), xo += a with a = (double)src / dst
+      (Geometry.c ImagingScaleAffine: the coordinate is accumulated; PINNED to the installed Pillow by tests/test_augment.py)
   cv2.getRotationMatrix2D(Point2f(w/2, h/2), angle, 1)   double alpha = cos, beta = sin of angle * pi / 180
   cv2.warpAffine (imgwarp.cpp WarpAffineInvoker + remapBilinear<FixedPtCast<int,uchar,15>>): M inverted in double as the code does,
       adelta[x] = rint(M0 * x * 1024), bdelta[x] = rint(M3 * x * 1024), X0 = rint((M1 * y + M2) * 1024) + delta, Y0 likewise
@@ -98,7 +99,15 @@ def resize_nearest(lab, dh, dw):
 
 
 def pil_nearest_axis_table(dst, src):
-    return np.minimum(np.floor((np.arange(dst, dtype=np.float64) + 0.5) * (float(src) / float(dst))).astype(np.int64), src - 1)
+    """Pillow's Image.resize(NEAREST) = ImagingScaleAffine (libImaging/Geometry.c): a = (double)src / dst; xo = a * 0.5; per output
+    index: xin = (int)xo, then xo += a — the source coordinate is ACCUMULATED in double, not computed as (d + 0.5) * a, so an exact
+    boundary such as (3 + 0.5) * 2 / 7 = 1.0 is reached as 0.999...: PINNED against the installed Pillow (12.2.0) by
+    tests/test_augment.py::test_pil_nearest_resize_is_pinned_to_the_installed_pillow (the closed form differs from the library
+    on 2 -> 7, 3 -> 7 and similar ratios)."""
+    a = float(src) / float(dst)
+    steps = np.full(dst, a, dtype=np.float64)
+    steps[0] = a * 0.5
+    return np.minimum(np.add.accumulate(steps).astype(np.int64), src - 1)
 
 
 def resize_nearest_pil(lab, dh, dw):

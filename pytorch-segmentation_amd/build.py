@@ -27,8 +27,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # profiles/r03_pk_two_process_ref.txt);
 # the scalar form never does.  These kernels are HBM-bound: no cost.
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize", "-fno-vectorize"] for f in ("pool_resize.hip", "conv_winograd.hip", "bn.hip", "loss.hip", "misc.hip", "optim.hip",
-                                                    "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip")}
-# (augment.hip is off the timed path and held to oracle/augment_ref.py at "one uint8 level": it keeps the default flags it was pinned with)
+                                                    "lovasz.hip", "dwconv_shuffle.hip", "pyramid_bottleneck.hip", "augment.hip")}
 
 
 def _sources():

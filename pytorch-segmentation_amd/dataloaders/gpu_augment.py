@@ -52,14 +52,22 @@ def _is_area_2x(dst, src):
     return isc == 2 and abs(inv - 1.0 / isc) < np.finfo(np.float64).eps
 
 
+def _pil_nearest_axis(dst, src):
+    """Source index per output index of Pillow's Image.resize(NEAREST) (libImaging/Geometry.c ImagingScaleAffine): the source
+    coordinate starts at 0.5 * src/dst and is ACCUMULATED in double, one addition per output index, then truncated."""
+    a = float(src) / float(dst)
+    steps = np.full(dst, a, dtype=np.float64)
+    steps[0] = a * 0.5
+    return np.minimum(np.add.accumulate(steps).astype(np.int64), src - 1)
+
+
 def resize_tables(sh, sw, dh, dw, label_filter="cv2"):
     """(int32 table xs | xa | ys | yb | lx | ly, area2x flag) for segmi_aug_resize.  label_filter: "cv2" = cv2.resize INTER_NEAREST
     (training, base_dataset.py:72), "pil" = PIL Image.resize(NEAREST) (validation, :49)."""
     xs, xa = _linear_axis(dw, sw, True)
     ys, yb = _linear_axis(dh, sh, False)
     if label_filter == "pil":
-        lx = np.minimum(np.floor((np.arange(dw, dtype=np.float64) + 0.5) * (float(sw) / float(dw))), sw - 1)
-        ly = np.minimum(np.floor((np.arange(dh, dtype=np.float64) + 0.5) * (float(sh) / float(dh))), sh - 1)
+        lx, ly = _pil_nearest_axis(dw, sw), _pil_nearest_axis(dh, sh)
     else:
         lx = np.minimum(np.floor(np.arange(dw, dtype=np.float64) * (1.0 / (float(dw) / float(sw)))), sw - 1)
         ly = np.minimum(np.floor(np.arange(dh, dtype=np.float64) * (1.0 / (float(dh) / float(sh)))), sh - 1)

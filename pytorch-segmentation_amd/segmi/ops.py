@@ -436,8 +436,11 @@ def _conv_wgrad(d, C, x, dy, dwb, v=None):
 # launching anything; an accumulating or bucket-view gradient keeps the in-order path).  Two more cases stay in order because
 # something on the compute stream reads dW before the end-of-backward join: a filter used MORE THAN ONCE in one graph (the engine
 # sums the two gradients in its input buffer — the second use first joins the side stream, then runs in order), and a parameter
-# carrying tensor hooks or post-accumulate hooks other than a GradAllReducer's (torch DDP, a clipping hook: they see dW during
-# backward; the reducer's own hook joins the side stream before it touches a gradient).
+# carrying tensor hooks or post-accumulate hooks other than a GradAllReducer's (a clipping hook: it sees dW during backward; the
+# reducer's own hook joins the side stream before it touches a gradient).  Hooks registered on the parameter's AccumulateGrad NODE
+# (torch DistributedDataParallel, FSDP, torch.autograd.graph hooks) cannot be enumerated from Python: whenever a process group is
+# initialised, only parameters a GradAllReducer has claimed (_HOOK_SAFE) take the side stream — under a foreign data-parallel
+# wrapper every filter gradient stays in order.  Node hooks installed by hand without torch.distributed need set_wgrad_stream(False).
 _WGRAD_SIDE = {"on": os.environ.get("SEGMI_WGRAD_STREAM", "1") == "1", "streams": {}, "armed": None, "launches": 0,
                "task": None, "inflight": set(), "in_order_reuse": 0, "in_order_hooks": 0}
 
@@ -481,7 +484,11 @@ def _on_wgrad_stream(weight, tensors, fn):
         wgrad_stream_join()
         _WGRAD_SIDE["in_order_reuse"] += 1
         return fn()
-    if weight._backward_hooks or (getattr(weight, "_post_accumulate_grad_hooks", None) and not _hook_safe(weight)):
+    if not _hook_safe(weight) and (weight._backward_hooks or getattr(weight, "_post_accumulate_grad_hooks", None)
+                                   or (torch.distributed.is_available() and torch.distributed.is_initialized())):
+        _WGRAD_SIDE["in_order_hooks"] += 1
+        return fn()
+    if weight._backward_hooks:
         _WGRAD_SIDE["in_order_hooks"] += 1
         return fn()
     if task >= 0:

@@ -46,6 +46,28 @@ def test_restatement_known_answers_of_the_fixed_point_formulas():
     assert ad.tolist() == [0, 0, 0, 0] and bd.tolist() == [0, 1024, 2048, 3072] and X0.tolist() == [4096, 3072, 2048, 1024]
 
 
+def test_pil_nearest_resize_is_pinned_to_the_installed_pillow():
+    """PINNED piece of f4: the validation label resize of the reference is PIL's `Image.fromarray(label).resize((w, h),
+    resample=Image.NEAREST)` (base/base_dataset.py:50), and Pillow IS installed here: the restatement's index table and resize are
+    held to the real library over a sweep of up- and down-scales, odd sizes and both label dtypes the reference produces."""
+    from PIL import Image
+    g = np.random.default_rng(3)
+    shapes = [(1, 1), (2, 3), (5, 7), (17, 31), (33, 33), (64, 48), (97, 61), (100, 200), (255, 256), (375, 500), (513, 513)]
+    targets = [(1, 1), (3, 2), (7, 5), (16, 16), (48, 48), (61, 97), (100, 50), (129, 257), (400, 400), (512, 683)]
+    for sh, sw in shapes:
+        lab = g.integers(0, 255, (sh, sw))
+        for dh, dw in targets:
+            for dt in (np.int32, np.uint8):
+                want = np.asarray(Image.fromarray(lab.astype(dt)).resize((dw, dh), resample=Image.NEAREST))
+                got = R.resize_nearest_pil(lab.astype(dt), dh, dw)
+                assert want.shape == got.shape and np.array_equal(want, got), (sh, sw, dh, dw, dt)
+    # the axis table alone, against a one-row ramp resized by the library (every source index visible in the output)
+    for src, dst in [(7, 3), (3, 7), (500, 375), (375, 500), (1024, 33), (33, 1024), (2049, 2048)]:
+        ramp = np.arange(src, dtype=np.int32)[None, :]
+        want = np.asarray(Image.fromarray(ramp).resize((dst, 1), resample=Image.NEAREST))[0]
+        assert np.array_equal(R.pil_nearest_axis_table(dst, src), want), (src, dst)
+
+
 def test_restatement_invariants():
     img, lab = _sample(60, 84, 1)
     assert np.array_equal(R.resize_linear(img, 60, 84), img) and np.array_equal(R.resize_nearest(lab, 60, 84), lab)   # identity size
@@ -139,8 +161,9 @@ CFGS = [dict(base_size=96, crop_size=80, scale=True, flip=True, rotate=True, blu
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("cfg", CFGS, ids=["cv2-unpinned-%d" % i for i in range(len(CFGS))])
 def test_gpu_augment_is_bit_exact_to_the_restatement(cuda, cfg):
+    """cv2-unpinned: the oracle side of this comparison is the restatement of OpenCV's published fixed-point algorithms, not cv2."""
     from dataloaders.gpu_augment import GPUAugment
     samples = [_sample(h, w, s) for (h, w, s) in ((60, 84, 1), (97, 61, 2), (50, 50, 3), (120, 40, 4), (200, 100, 5), (37, 64, 6))]
     for seed in (5, 6, 7):
@@ -161,7 +184,9 @@ def test_gpu_augment_is_bit_exact_to_the_restatement(cuda, cfg):
 
 
 @pytest.mark.gpu
-def test_gpu_validation_and_plain_paths_are_bit_exact(cuda):
+def test_gpu_validation_and_plain_paths_are_bit_exact_cv2_unpinned_pil_pinned(cuda):
+    """Validation path: image resize = cv2 INTER_LINEAR (restatement only: cv2-unpinned), label resize = PIL NEAREST (the restatement
+    of that piece is pinned to the installed Pillow by test_pil_nearest_resize_is_pinned_to_the_installed_pillow)."""
     from dataloaders.gpu_augment import GPUAugment
     samples = [_sample(h, w, s) for (h, w, s) in ((60, 84, 1), (97, 61, 2), (50, 50, 3), (120, 40, 4), (96, 192, 5))]
     aug = GPUAugment(MEAN, STD, crop_size=48, device=cuda)
@@ -180,7 +205,7 @@ def test_gpu_validation_and_plain_paths_are_bit_exact(cuda):
 
 
 @pytest.mark.gpu
-def test_loader_yields_device_batches_equal_to_the_restatement(cuda):
+def test_loader_yields_device_batches_equal_to_the_restatement_cv2_unpinned(cuda):
     """dataloaders.SynthImages end to end (host threads -> pinned staging -> device augmentation): the batches are what the
     reference's `__getitem__` would produce for the same raw samples and the same random draws."""
     import dataloaders

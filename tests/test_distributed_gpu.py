@@ -527,6 +527,26 @@ def test_side_stream_stays_in_order_for_reused_filters_and_foreign_hooks(cuda):
         c2 = ops.get_wgrad_stream()
         assert c2["in_order_hooks"] == c1["in_order_hooks"] + 1
         assert seen == [float(want[1].abs().sum())] and torch.equal(got[1], want[1])
+        # torch DDP / FSDP hook the parameter's AccumulateGrad NODE, which Python cannot enumerate.  With a
+        # process group initialised, a parameter no GradAllReducer has claimed keeps its filter gradient in order, so a node
+        # hook that reads the gradient on the compute stream (what DDP's bucket copy does) sees the finished values.
+        import tempfile
+        import torch.distributed as dist
+        assert not dist.is_initialized()
+        with tempfile.TemporaryDirectory() as tmp:
+            dist.init_process_group("gloo", init_method="file://" + os.path.join(tmp, "pg"), rank=0, world_size=1)
+            try:
+                seen2 = []
+                acc = other.weight.view_as(other.weight).grad_fn.next_functions[0][0]
+                h2 = acc.register_hook(lambda *a: seen2.append(float(other.weight.grad.abs().sum())))
+                c3 = ops.get_wgrad_stream()
+                got = run()
+                h2.remove()
+                c4 = ops.get_wgrad_stream()
+                assert c4["in_order_hooks"] >= c3["in_order_hooks"] + 2 and c4["launches"] == c3["launches"]      # both filters in order
+                assert seen2 == [float(want[1].abs().sum())] and torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
+            finally:
+                dist.destroy_process_group()
     finally:
         ops.set_wgrad_stream(prev)
 
