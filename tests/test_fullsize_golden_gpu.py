@@ -9,10 +9,10 @@ numbers of SURVEY.md §7 (pytest -s, or the captured stdout of a failure):
     mismatch count of the full-resolution masks, the largest oracle margin among mismatching pixels, max|dlogit|
 
 and asserts
-  * logits:  max|dlogit| <= 1e-3 * max|logit| for EVERY config (strided sample of the main head; aux head for PSPNet); where the
-             fp32 reference itself is further than 5e-4 * max|logit| from the fp64 oracle (cfg3), additionally the noise-floor
-             criterion of tests/test_pspnet_gpu.py: the HIP logits are at most 2x as far from the fp64 oracle as the reference's
-             own are.  Both distances are printed for every config.
+  * logits:  max|dlogit| <= 1e-3 * max|logit| for EVERY config (strided sample of the main head; aux head for PSPNet), and the
+             noise-floor criterion of tests/test_pspnet_gpu.py: the HIP logits are at most 2x as far from the fp64 oracle as the
+             reference's own fp32 run is.  Both distances are printed for every config.  cfg3's backbone oracle is the restated
+             torchvision ResNet-v1.5 (torchvision is absent): the audit line says "backbone oracle unpinned".
   * masks :  0 mismatches among pixels whose oracle top-2 margin exceeds 2*max|dlogit| — bit-identity on EVERY pixel is not
              attainable between two fp32 summation orders (torch-CPU NCHW vs channels_last already differ on 341 of 1 M
              pixels); every remaining mismatch is a numerical tie, and the count is printed
@@ -123,7 +123,8 @@ FIXTURE_BATCH = {"cfg2": 8, "cfg3": 16, "cfg4": 4, "cfg5": 8}
 
 def audit_line(r, algo):
     from segmi import ops
-    return ("[fullsize %s batch %d, conv math %s, %s] pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
+    note = " [backbone oracle unpinned (torchvision ResNet-v1.5 restated, oracle/tv_resnet.py)]" if r["config"] == "cfg3" else ""
+    return ("[fullsize %s batch %d, conv math %s, %s]" + note + " pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
             "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
             "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s) | "
             "grad-sample rel-L2 from the reference fp32 median %.2e max %.2e (%s) | from the fp64 oracle: HIP median %.2e max %.2e (%s), "
@@ -158,10 +159,8 @@ def test_fullsize_step_matches_reference_golden(cuda, name, conv_algorithm):
     print("\n" + record_audit(r, conv_algorithm or "default"))
     assert r["batch"] == FIXTURE_BATCH[name]
     assert r["max_abs_dlogit"] <= 1e-3 * r["logit_absmax"], r
-    if r["ref_err_f64"] > 5e-4 * r["logit_absmax"]:
-        # additionally, where the reference's own fp32 rounding noise is a sizeable part of that bar (cfg3, parity unpinned for the
-        # restated torchvision ResNet-v1.5 backbone): the HIP logits are no further from the fp64 oracle than twice the reference's
-        assert r["hip_err_f64"] <= 2.0 * r["ref_err_f64"] and r["max_abs_dlogit"] <= 3.0 * r["ref_err_f64"], r
+    # every config: the HIP logits are no further from the fp64 oracle than twice the reference's own fp32 run
+    assert r["hip_err_f64"] <= 2.0 * r["ref_err_f64"], r
     assert r["mismatches_outside_margin"] == 0, r
     if "max_abs_daux" in r:
         assert r["max_abs_daux"] <= 1e-3 * r["aux_absmax"], r

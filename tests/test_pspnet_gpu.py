@@ -16,6 +16,7 @@ import statistics
 import pytest
 import torch
 
+from _oracle_cache import oracle_once
 from oracle import losses_ref, pspnet_ref
 from oracle.weights import synth_batch, synth_state_dict
 
@@ -145,13 +146,17 @@ def test_pspnet_batch_stat_gradients_within_reference_noise_floor(cuda):
     m, sd = _build(cuda, man, classes, seed=5)
     x, t = synth_batch(shape[0], 3, shape[2], shape[3], classes, seed=78)
     out, aux, loss = _step(m, x, t, cuda)
-    runs = {}
-    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
-        ref = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()})
-        ro, ra = pspnet_ref.pspnet_forward(ref, x.to(dt), training=True)
-        rl = losses_ref.cross_entropy(ro, t) + 0.4 * losses_ref.cross_entropy(ra, t)
-        rl.backward()
-        runs[name] = (ro.detach(), rl.item(), {k: v.grad for k, v in ref.items() if v.grad is not None})
+    def oracle_runs():
+        runs = {}
+        for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            ref = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()})
+            ro, ra = pspnet_ref.pspnet_forward(ref, x.to(dt), training=True)
+            rl = losses_ref.cross_entropy(ro, t) + 0.4 * losses_ref.cross_entropy(ra, t)
+            rl.backward()
+            runs[name] = (ro.detach(), rl.item(), {k: v.grad for k, v in ref.items() if v.grad is not None})
+        return runs
+
+    runs = oracle_once(("pspnet_batch_stat_noise_floor", classes, shape, 5, 78), oracle_runs)      # shared by both conv algorithms
     o64, l64, g64 = runs["f64"]
     o32, l32, g32 = runs["f32"]
     # forward: well conditioned, tight

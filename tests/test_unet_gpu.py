@@ -5,6 +5,7 @@ import os
 import pytest
 import torch
 
+from _oracle_cache import oracle_once
 from oracle import losses_ref, pspnet_ref, unet_ref
 from oracle.weights import synth_batch, synth_state_dict
 
@@ -65,19 +66,24 @@ def test_unet_frozen_bn_all_gradients_match_oracle(cuda):
     out = m(x.to(cuda))
     loss = CrossEntropyLoss2d(ignore_index=255)(out, t.to(cuda))
     loss.backward()
-    ref = pspnet_ref.clone_state(sd)
-    ro = unet_ref.unet_forward(ref, x, training=True, bn_training=False)
-    rl = losses_ref.cross_entropy(ro, t)
-    rl.backward()
-    d, n_mis, bad = _margin_audit(out.detach().cpu(), ro.detach())
+    def oracle_f32_f64():
+        ref = pspnet_ref.clone_state(sd)
+        ro = unet_ref.unet_forward(ref, x, training=True, bn_training=False)
+        rl = losses_ref.cross_entropy(ro, t)
+        rl.backward()
+        # fp64 run of the same oracle: the yardstick for "how far apart may two fp32 evaluations be" (see below)
+        r64 = pspnet_ref.clone_state({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()})
+        losses_ref.cross_entropy(unet_ref.unet_forward(r64, x.double(), training=True, bn_training=False), t).backward()
+        return ref, ro.detach(), rl.item(), r64
+
+    ref, ro, rl, ref64 = oracle_once(("unet_frozen", 2, 99), oracle_f32_f64)      # shared by both conv algorithms
+    d, n_mis, bad = _margin_audit(out.detach().cpu(), ro)
     assert d <= 1e-3 * ro.abs().max().item() and bad == 0, (d, n_mis, bad)
-    assert abs(loss.item() - rl.item()) < 1e-4
+    assert abs(loss.item() - rl) < 1e-4
     from segmi import ops
     # fp64 run of the same oracle: the yardstick for "how far apart may two fp32 evaluations be" (ReLU flips at |pre-activation|
     # ~1e-7 move the 16x16-map gradients of down4 / middle by ~1e-3: the torch-CPU fp32 oracle itself is 7-9e-4 from fp64 there,
     # tools/probes/unet_grad_noise.py)
-    ref64 = pspnet_ref.clone_state({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()})
-    losses_ref.cross_entropy(unet_ref.unet_forward(ref64, x.double(), training=True, bn_training=False), t).backward()
     floor = max(((ref[k].grad.double() - ref64[k].grad).norm() / (ref64[k].grad.norm() + 1e-30)).item() for k, _ in m.named_parameters())
     worst32 = worst64 = 0.0
     for k, p in m.named_parameters():
