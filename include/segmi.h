@@ -112,7 +112,13 @@ int segmi_filter_krsc_to_crsk_multi(const segmi_filter_tx* table_dev, int n, lon
 int segmi_conv2d_winograd_ok(const segmi_conv_desc* d, int op);
 size_t segmi_conv2d_winograd_workspace(const segmi_conv_desc* d, int op);
 int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
-                              int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+                              int accumulate, float* v_keep, float* stats_partials, void* workspace, size_t workspace_bytes,
+                              segmi_stream_t stream);
+/* stats_partials (optional; needs accumulate == 0 and K % 4 == 0): the output transform also emits the BN-statistics partials
+ * of y — segmi_conv2d_winograd_fwd_stats_parts(d) blocks of {count, mean, M2}[K] floats, the layout segmi_conv2d_fwd_stats
+ * writes and segmi_bn_finalize_from_parts / segmi_bn_stats_from_parts consume — so the following BatchNorm never reads y for
+ * its statistics.  _parts() returns 0 when the problem has no such epilogue. */
+int segmi_conv2d_winograd_fwd_stats_parts(const segmi_conv_desc* d);
 /* v_keep (optional, segmi_conv2d_winograd_v_bytes(d) bytes, 16-byte aligned, caller-owned): the forward pass writes its
  * transformed input V = B^T x B there instead of into the workspace, so that segmi_conv2d_winograd_wgrad(v_kept = that buffer)
  * contracts it again without re-reading x and re-writing 4x its size (memory for traffic: 288 GB of HBM per GPU). */
@@ -236,10 +242,15 @@ int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, floa
 /* sums[2*C] = {sum dy', sum dy'*xhat},  dy' = relu ? dy*[y>0] : dy  */
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C);
 /* ReLU mask source: y (the saved output) when given; y == NULL (allowed when no residual was added) recomputes
- * fmaf(x, scale, shift) > 0 exactly as bn_apply evaluated it, saving one full read of y per pass. */
+ * fmaf(x, scale, shift) > 0 exactly as bn_apply evaluated it, saving one full read of y per pass.
+ * tickets (optional): SEGMI_BN_TICKETS uint32 the caller keeps per stream, ZERO before their first use; every call leaves
+ * them zero.  With tickets the row partials are added by the last workgroup of each channel column (fixed order: the result
+ * does not depend on which one that is) and the call is ONE launch; NULL keeps the separate summation launch.  sums must be
+ * 16-byte aligned for the one-launch form. */
+#define SEGMI_BN_TICKETS 256
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                         const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
-                        float* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+                        float* sums, void* workspace, size_t workspace_bytes, unsigned* tickets, segmi_stream_t stream);
 /* dgamma = sums[C:2C], dbeta = sums[0:C];
  * training: dx = scale*(dy' - sums0/count - xhat*sums1/count); eval (frozen): dx = scale*dy'.
  * d_residual (optional) = dy'.  `count` is the (global) element count per channel; when count_dev != NULL it is read

@@ -13,39 +13,10 @@
 // (reference semantics: utils/sync_batchnorm/batchnorm.py:105-145, re-expressed with Chan's merge so
 // the multi-GPU result matches single-device global-batch F.batch_norm).
 #include "rowgeom.h"
+#include "welford.h"
 #include <cstdlib>
 
 namespace {
-
-struct Wf4 {  // Welford state for 4 channels sharing one count
-    float n;
-    float4 mean, m2;
-};
-__device__ __forceinline__ void wf_init(Wf4& w) { w.n = 0.f; w.mean = zero4(); w.m2 = zero4(); }
-__device__ __forceinline__ void wf_push(Wf4& w, float4 x) {
-    w.n += 1.f;
-    const float inv = 1.f / w.n;
-    float d;
-    d = x.x - w.mean.x; w.mean.x += d * inv; w.m2.x += d * (x.x - w.mean.x);
-    d = x.y - w.mean.y; w.mean.y += d * inv; w.m2.y += d * (x.y - w.mean.y);
-    d = x.z - w.mean.z; w.mean.z += d * inv; w.m2.z += d * (x.z - w.mean.z);
-    d = x.w - w.mean.w; w.mean.w += d * inv; w.m2.w += d * (x.w - w.mean.w);
-}
-__device__ __forceinline__ void chan1(float na, float& ma, float& qa, float nb, float mb, float qb, float n) {
-    const float d = mb - ma;
-    const float f = nb / n;
-    ma += d * f;
-    qa += qb + d * d * na * f;
-}
-__device__ __forceinline__ void wf_merge(Wf4& a, const Wf4& b) {
-    const float n = a.n + b.n;
-    if (n == 0.f) return;
-    chan1(a.n, a.mean.x, a.m2.x, b.n, b.mean.x, b.m2.x, n);
-    chan1(a.n, a.mean.y, a.m2.y, b.n, b.mean.y, b.m2.y, n);
-    chan1(a.n, a.mean.z, a.m2.z, b.n, b.mean.z, b.m2.z, n);
-    chan1(a.n, a.mean.w, a.m2.w, b.n, b.mean.w, b.m2.w, n);
-    a.n = n;
-}
 
 // part: [gridDim.y][3][C4*4] = {n, mean, m2}
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int ld, long rows, int c4n,
@@ -233,7 +204,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part, unsigned* __restrict__ tickets,
+                                                            float* __restrict__ sums) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 < c4n;
     D4 s0 = dzero4(), s1 = dzero4();
@@ -294,6 +266,49 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
         o[Cp] = b.x * (double)is.x; o[Cp + 1] = b.y * (double)is.y; o[Cp + 2] = b.z * (double)is.z; o[Cp + 3] = b.w * (double)is.w;
     }
+    if (!tickets) return;                                // two-launch form: sum_parts_kernel adds the row partials
+    // Last workgroup of this channel column adds the column's row partials itself — one launch instead of two (the ~5 us
+    // sum_parts launch was a third of a call on 24 MB tensors: 141 BN layers per DeepLab-Xception step).  Release: every
+    // thread's partial is written back before the ticket is taken; acquire: the last workgroup invalidates its caches before it
+    // reads the other workgroups' partials (they ran on other XCDs, each with its own L2).  The partials are added in a FIXED
+    // order (row partial p by thread row p % ry, then a tree over the thread rows), so the result does not depend on which
+    // workgroup happens to be last: deterministic.  The counter is handed back at 0 for the next call.
+    __threadfence();
+    __shared__ unsigned last;
+    __syncthreads();
+    if (t == 0) last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    D4 a0 = dzero4(), a1 = dzero4();
+    if (cok) {
+        const int Cp = c4n * 4;
+        for (int p = threadIdx.y; p < (int)gridDim.y; p += blockDim.y) {
+            const double* q = part + (long)p * 2 * Cp + c4 * 4;
+            a0.x += __builtin_nontemporal_load(q); a0.y += __builtin_nontemporal_load(q + 1);
+            a0.z += __builtin_nontemporal_load(q + 2); a0.w += __builtin_nontemporal_load(q + 3);
+            a1.x += __builtin_nontemporal_load(q + Cp); a1.y += __builtin_nontemporal_load(q + Cp + 1);
+            a1.z += __builtin_nontemporal_load(q + Cp + 2); a1.w += __builtin_nontemporal_load(q + Cp + 3);
+        }
+    }
+    sm0[t] = a0; sm1[t] = a1;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            D4 a = sm0[t], b = sm0[t + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm0[t] = a;
+            a = sm1[t]; b = sm1[t + s * blockDim.x];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm1[t] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const int C = c4n * 4;
+        const D4 a = sm0[t], b = sm1[t];
+        st4(sums + c4 * 4, make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w));
+        st4(sums + C + c4 * 4, make_float4((float)b.x, (float)b.y, (float)b.z, (float)b.w));
+    }
+    if (t == 0) tickets[blockIdx.x] = 0u;
 }
 
 // out[i] = (float) sum_p part[p][i] in double; block = (32 elements, 8 part lanes), LDS tree over the lanes
@@ -638,7 +653,7 @@ size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
 
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                         const float* mean, const float* invstd, const float* scale, const float* shift, int relu, float* sums,
-                        void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+                        void* workspace, size_t workspace_bytes, unsigned* tickets, segmi_stream_t stream) {
     if (!dy || !x || !mean || !invstd || !sums || rows <= 0 || C <= 0 || (relu && !y && (!scale || !shift))) return SEGMI_ERR_BADARG;
     if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && y && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_bn_bwd_reduce_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
@@ -647,9 +662,13 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     if ((uintptr_t)workspace & 7) return SEGMI_ERR_ALIGN;
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const double*)workspace, parts, 2 * C, sums);
+    // one launch when the caller lends a ticket array (SEGMI_BN_TICKETS uint32, zero before its first use, left zero by every call,
+    // never shared by calls that may run concurrently: one per stream); two launches otherwise
+    if (tickets && ((int)g.grid.x > SEGMI_BN_TICKETS || ((uintptr_t)sums & 15) || parts < 2)) tickets = nullptr;
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, tickets, sums);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, tickets, sums);
+    if (!tickets)
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const double*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
 

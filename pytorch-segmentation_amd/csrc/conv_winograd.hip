@@ -25,6 +25,7 @@
 // The transforms are HBM streams (V is 4x the input, M 4x the output); the contraction is MFMA-bound and 2.25x shorter.
 #include "conv_internal.h"
 #include "rowgeom.h"
+#include "welford.h"
 #include <cstdio>
 
 namespace {
@@ -120,10 +121,20 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // y[tile] = A^T m A (+ bias) (+ y), m = M[:, t, k]
+// STATS: the BN-statistics partials of y while its values are in registers (the output transform is the last kernel that holds
+// them: its 2x2 tile is the only place a Winograd layer's y exists before HBM) — per thread a Welford run over the outputs it
+// writes, a Chan tree over the block's thread rows, ONE {n, mean, M2} partial per (blockIdx.y, channel) in the layout of the
+// implicit-GEMM kernel's epilogue (conv_igemm.hip): stats[blockIdx.y][3][K].  K % 4 == 0, no accumulate (host side).
+template <bool STATS>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mm, int ldm, int K, WinoGeom g,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy, int accumulate) {
+                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy, int accumulate,
+                                                          float* __restrict__ stats) {
     const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k4 * 4 >= ((K + 3) & ~3)) return;
+    const bool kok = k4 * 4 < ((K + 3) & ~3);
+    if (!STATS && !kok) return;
+    Wf4 wf;
+    wf_init(wf);
+    if (kok) {
     const long plane = g.T * (long)ldm;
     float4 bv = zero4();
     if (bias) {
@@ -156,7 +167,30 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 float4 o = add4(b ? o1 : o0, bv);
                 if (accumulate) o = add4(o, ld4(dst));
                 st4(dst, o);
+                if (STATS) wf_push(wf, o);
             }
+        }
+    }
+    }
+    if (STATS) {
+        __shared__ Wf4 sm[256];
+        const int t = threadIdx.y * blockDim.x + threadIdx.x;
+        sm[t] = wf;
+        __syncthreads();
+        for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+            if ((int)threadIdx.y < s) {
+                Wf4 a = sm[t];
+                wf_merge(a, sm[t + s * blockDim.x]);
+                sm[t] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.y == 0 && kok) {
+            const Wf4 a = sm[t];
+            float* o = stats + (long)blockIdx.y * 3 * K + k4 * 4;
+            st4(o, make_float4(a.n, a.n, a.n, a.n));
+            st4(o + K, a.mean);
+            st4(o + 2 * K, a.m2);
         }
     }
 }
@@ -282,8 +316,15 @@ bool wino_plan(const segmi_conv_desc* d, int op, WinoPlan* pl) {
     return true;
 }
 
+// partials the output transform emits when asked for BN statistics: <= WINO_STATS_PARTS thread-row blocks walk the tiles
+constexpr int WINO_STATS_PARTS = 256;
+int wino_stats_parts(const WinoPlan& pl) {
+    const RowGeom rg = row_geom(pl.g.T, pl.ldm, 1, WINO_STATS_PARTS);
+    return (int)rg.grid.y;
+}
+
 int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, int flip, const float* bias, float* dst, int ldd,
-             int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, hipStream_t st) {
+             int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, hipStream_t st, float* stats = nullptr) {
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < pl.u_bytes + pl.v_bytes + pl.m_bytes) return SEGMI_ERR_WORKSPACE;
     if (v_keep && ((uintptr_t)v_keep & 15)) return SEGMI_ERR_ALIGN;
     float* U = (float*)workspace;
@@ -307,8 +348,13 @@ int wino_run(const WinoPlan& pl, const float* src, int lds, const float* filt, i
     }
     if (rc != SEGMI_OK) return rc;
     {
-        RowGeom rg = row_geom(T, pl.ldm, 1, SEGMI_MAX_GRID * 4);
-        hipLaunchKernelGGL(wino_output_kernel, rg.grid, rg.block, 0, st, (const float*)Mm, pl.ldm, pl.Cout, pl.g, bias, dst, ldd, accumulate);
+        if (stats) {
+            RowGeom rg = row_geom(T, pl.ldm, 1, WINO_STATS_PARTS);
+            hipLaunchKernelGGL(wino_output_kernel<true>, rg.grid, rg.block, 0, st, (const float*)Mm, pl.ldm, pl.Cout, pl.g, bias, dst, ldd, 0, stats);
+        } else {
+            RowGeom rg = row_geom(T, pl.ldm, 1, SEGMI_MAX_GRID * 4);
+            hipLaunchKernelGGL(wino_output_kernel<false>, rg.grid, rg.block, 0, st, (const float*)Mm, pl.ldm, pl.Cout, pl.g, bias, dst, ldd, accumulate, (float*)nullptr);
+        }
     }
     return segmi_launch_status();
 }
@@ -335,14 +381,22 @@ size_t segmi_conv2d_winograd_v_bytes(const segmi_conv_desc* d) {
     return wino_plan(d, 0, &pl) ? (size_t)16 * pl.Tpad * pl.Cin * sizeof(float) : 0;
 }
 
+int segmi_conv2d_winograd_fwd_stats_parts(const segmi_conv_desc* d) {
+    WinoPlan pl;
+    if (!wino_plan(d, 0, &pl) || (d->K & 3)) return 0;
+    return wino_stats_parts(pl);
+}
+
 int segmi_conv2d_winograd_fwd(const segmi_conv_desc* d, const float* x, const float* w_krsc, const float* bias, float* y,
-                              int accumulate, float* v_keep, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+                              int accumulate, float* v_keep, float* stats_partials, void* workspace, size_t workspace_bytes,
+                              segmi_stream_t stream) {
     WinoPlan pl;
     if (!x || !w_krsc || !y || !wino_plan(d, 0, &pl)) return SEGMI_ERR_BADARG;
+    if (stats_partials && (accumulate || (d->K & 3) || ((uintptr_t)stats_partials & 15))) return SEGMI_ERR_BADARG;
     if ((d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < pl.ldm || ((uintptr_t)x & 15) || ((uintptr_t)w_krsc & 15) ||
         ((uintptr_t)y & 15))
         return SEGMI_ERR_ALIGN;
-    return wino_run(pl, x, d->ldx, w_krsc, 0, bias, y, d->ldy, accumulate, v_keep, workspace, workspace_bytes, (hipStream_t)stream);
+    return wino_run(pl, x, d->ldx, w_krsc, 0, bias, y, d->ldy, accumulate, v_keep, workspace, workspace_bytes, (hipStream_t)stream, stats_partials);
 }
 
 int segmi_conv2d_winograd_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,

@@ -47,7 +47,8 @@ SIGNATURES = {
     "segmi_filter_krsc_to_crsk": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "segmi_conv2d_winograd_ok": (i32, [PD, i32]),
     "segmi_conv2d_winograd_workspace": (sz, [PD, i32]),
-    "segmi_conv2d_winograd_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_conv2d_winograd_fwd": (i32, [PD, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "segmi_conv2d_winograd_fwd_stats_parts": (i32, [PD]),
     "segmi_conv2d_winograd_v_bytes": (sz, [PD]),
     "segmi_conv2d_winograd_dgrad": (i32, [PD, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_conv2d_winograd_variant": (i32, [PD, i32, C.c_char_p, sz]),
@@ -85,7 +86,7 @@ SIGNATURES = {
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),
-    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp, vp]),
     "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "segmi_relu_fwd": (i32, [vp, i32, vp, i32, i64, i32, vp]),
     "segmi_relu_bwd": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),

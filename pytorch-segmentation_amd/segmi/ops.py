@@ -54,6 +54,22 @@ def workspace(nbytes, device):
     return buf
 
 
+_BN_TICKETS = {}
+_BN_TICKETS_ON = os.environ.get("SEGMI_BN_TICKETS", "1") == "1"      # A/B hook: 0 = separate summation launch in bn_bwd_reduce
+
+
+def _bn_tickets(device):
+    """Per-(device, stream) ticket counters of segmi_bn_bwd_reduce's one-launch form: zero at creation, every call leaves them zero;
+    calls on one stream run in order, so they never share a counter concurrently.  None switches to the two-launch form."""
+    if not _BN_TICKETS_ON:
+        return None
+    key = (device.index, _stream())
+    t = _BN_TICKETS.get(key)
+    if t is None:
+        t = _BN_TICKETS[key] = torch.zeros(256, dtype=torch.int32, device=device)
+    return t.data_ptr()
+
+
 # --------------------------------------------------------------------------- layout helpers
 def empty_nhwc(N, C, H, W, device, ld=None):
     ld = ld or pad4(C)
@@ -381,10 +397,19 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
         v = None
         if keep_v and _WINOGRAD["keep_v"] and _WINOGRAD["wgrad"] and lib.segmi_conv2d_winograd_wgrad_ok(d) == 1:
             v = torch.empty(lib.segmi_conv2d_winograd_v_bytes(d) // 4, device=dev, dtype=torch.float32)
+        part, parts = None, 0
+        if bn_stats and not accumulate:
+            parts = lib.segmi_conv2d_winograd_fwd_stats_parts(d)         # the output transform's BN-statistics epilogue
+            if parts > 0:
+                part = torch.empty(parts * 3 * d.K, device=dev, dtype=torch.float32)
         with span(lambda: _winograd_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d), inner=lambda: _winograd_inner(d, C)):
             check(lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                y.data_ptr(), accumulate, v.data_ptr() if v is not None else None, ws.data_ptr(), nws, st),
+                                                y.data_ptr(), accumulate, v.data_ptr() if v is not None else None,
+                                                part.data_ptr() if part is not None else None, ws.data_ptr(), nws, st),
                   "conv2d_winograd_fwd")
+        if part is not None:
+            _BN_FUSE["last"] = (part, parts)
+            _BN_FUSE["emitted"] += 1
         return v
     bp = bias.data_ptr() if bias is not None else None
     pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
@@ -1062,7 +1087,7 @@ class _BatchNormActFn(torch.autograd.Function):
         yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
         check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                      1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, st), "bn_bwd_reduce")
+                                      1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, _bn_tickets(dev), st), "bn_bwd_reduce")
         dgamma = sums[C:2 * C] if ctx.needs_input_grad[1] else None
         dbeta = sums[0:C] if ctx.needs_input_grad[2] else None
         gsums = sums
@@ -1150,7 +1175,7 @@ def _bn_member_bwd_reduce(dy, x, y, coef, relu):
     yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
     check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C, coef.data_ptr(),
                                   coef.data_ptr() + 4 * C, coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0,
-                                  sums.data_ptr(), ws.data_ptr(), nws, _stream()), "bn_bwd_reduce")
+                                  sums.data_ptr(), ws.data_ptr(), nws, _bn_tickets(dev), _stream()), "bn_bwd_reduce")
     return sums
 
 

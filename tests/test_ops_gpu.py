@@ -259,6 +259,40 @@ def test_batch_norm_act(cuda, shape, relu, res, training):
         assert int(nbt.item()) == 1
 
 
+@pytest.mark.parametrize("shape", [(8, 256, 64, 64), (8, 728, 32, 32), (2, 64, 256, 256), (4, 2048, 8, 8), (2, 16, 33, 35)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_backward_reduction_in_one_launch_equals_the_two_launch_form(cuda, shape, relu, monkeypatch):
+    """Round 5: the last workgroup of a channel column adds the column's fp64 row partials itself (ticket counters, release /
+    acquire fences across the XCDs' L2s) instead of a second launch.  Both forms add the same fp64 partials and round once to fp32:
+    gradients agree to the last bit or two; repeated calls are bit-identical (the order of the additions is fixed, whichever
+    workgroup comes last) and every call hands its counters back at zero."""
+    from segmi import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(cuda)
+    gy = torch.randn(N, C, H, W, generator=g).to(cuda)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+
+    def run():
+        xd, gd, bd = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+        y = ops.batch_norm_act(xd, gd, bd, rm, rv, None, training=True, relu=relu)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return xd.grad.clone(), gd.grad.clone(), bd.grad.clone()
+
+    monkeypatch.setattr(ops, "_BN_TICKETS_ON", True)
+    one = [run() for _ in range(4)]
+    tick = ops._BN_TICKETS[(cuda.index, ops._stream())]
+    assert int(tick.abs().sum()) == 0
+    for r in one[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(one[0], r))
+    monkeypatch.setattr(ops, "_BN_TICKETS_ON", False)
+    two = run()
+    for a, b, what in zip(one[0], two, ("dx", "dgamma", "dbeta")):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7 * float(b.abs().max())), (what, (a - b).abs().max().item())
+
+
 def test_batch_norm_large_mean_is_stable(cuda):
     """Welford/Chan statistics: a channel with |mean| >> std must not lose its variance."""
     from segmi import ops
@@ -975,6 +1009,53 @@ def test_conv_bn_stats_epilogue_matches_the_statistics_pass(cuda, case):
     assert outs[0][3] == outs[1][3] == 1
     for a, c in zip(outs[0][:3], outs[1][:3]):
         torch.testing.assert_close(a, c, rtol=2e-5, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("case", [(8, 128, 32, 32, 128, 1, False), (2, 256, 33, 33, 256, 1, True), (1, 128, 40, 40, 136, 2, False),
+                                  (2, 512, 16, 24, 512, 4, False), (8, 512, 64, 64, 512, 1, False)])
+def test_winograd_output_transform_emits_the_bn_statistics(cuda, case):
+    """Round 5: the Winograd output transform is the last kernel that holds a 3x3 layer's y in registers — with stats_partials it
+    also writes {count, mean, M2} partials (segmi_conv2d_winograd_fwd_stats_parts blocks), so the BatchNorm behind a Winograd layer
+    needs no pass over y either.  y is bit-identical with and without the epilogue; the merged partials agree with the streaming
+    statistics pass exactly in the counts and to fp32 merge-order rounding in mean / M2 (both held to fp64 statistics of y)."""
+    from segmi import ops
+    from segmi._lib import ConvDesc, lib
+    N, C, H, W, K, dil, bias = case
+    g = torch.Generator().manual_seed(9)
+    x = ops.to_nhwc((torch.randn(N, C, H, W, generator=g) + 0.3).to(cuda))
+    wf = (torch.randn(K, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(cuda).contiguous()
+    b = (torch.randn(K, generator=g) * 2).to(cuda) if bias else None
+    st = torch.cuda.current_stream().cuda_stream
+    y0, y1 = ops.empty_nhwc(N, K, H, W, cuda), ops.empty_nhwc(N, K, H, W, cuda)
+    d = ConvDesc(N, H, W, C, K, 3, 3, H, W, 1, dil, dil, ops.ld_of(x), ops.ld_of(y0))
+    assert lib.segmi_conv2d_winograd_ok(d, 0) == 1
+    parts = lib.segmi_conv2d_winograd_fwd_stats_parts(d)
+    assert 0 < parts <= 256
+    nwsw = lib.segmi_conv2d_winograd_workspace(d, 0)
+    wsw = torch.empty(nwsw + 16, dtype=torch.uint8, device=cuda)
+    bp = b.data_ptr() if bias else None
+    assert lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), wf.data_ptr(), bp, y0.data_ptr(), 0, None, None, wsw.data_ptr(), nwsw, st) == 0
+    part = torch.full((parts * 3 * K,), float("nan"), device=cuda)
+    assert lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), wf.data_ptr(), bp, y1.data_ptr(), 0, None, part.data_ptr(), wsw.data_ptr(), nwsw, st) == 0
+    assert torch.equal(y0, y1) and not torch.isnan(part).any()
+    rows = N * H * W
+    cnt = part.view(parts, 3, K)[:, 0].sum(0)
+    assert float(cnt.min()) == rows == float(cnt.max())
+    nws = max(lib.segmi_bn_stats_workspace(rows, K), lib.segmi_bn_parts_workspace(parts, K))
+    ws = torch.empty(nws + 16, dtype=torch.uint8, device=cuda)
+    ref, got = torch.empty(3 * K, device=cuda), torch.empty(3 * K, device=cuda)
+    assert lib.segmi_bn_stats(y0.data_ptr(), ops.ld_of(y0), rows, K, ref.data_ptr(), ws.data_ptr(), nws, st) == 0
+    assert lib.segmi_bn_stats_from_parts(part.data_ptr(), parts, K, got.data_ptr(), ws.data_ptr(), nws, st) == 0
+    ref, got = ref.view(3, K).cpu().double(), got.view(3, K).cpu().double()
+    assert torch.equal(ref[0], got[0])
+    y64 = y0.detach().cpu().double().permute(0, 2, 3, 1).reshape(rows, K)
+    mean64, m264 = y64.mean(0), ((y64 - y64.mean(0)) ** 2).sum(0)
+    scale = y64.abs().max().item()
+    for name, t in (("statistics pass", ref), ("winograd output transform", got)):
+        assert (t[1] - mean64).abs().max().item() <= 2e-6 * scale, name
+        assert ((t[2] - m264).abs() / m264).max().item() <= 2e-5, name
+    # accumulate and K % 4 != 0 have no such epilogue
+    assert lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), wf.data_ptr(), bp, y1.data_ptr(), 1, None, part.data_ptr(), wsw.data_ptr(), nwsw, st) != 0
 
 
 def test_conv_to_batchnorm_pairing_static_link_and_runtime_discovery(cuda):
