@@ -263,32 +263,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         double* o = part + (long)blockIdx.y * 2 * Cp + c4 * 4;
         const D4 a = sm0[t], b = sm1[t];
         const float4 is = ld4(invstd + c4 * 4);
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-        o[Cp] = b.x * (double)is.x; o[Cp + 1] = b.y * (double)is.y; o[Cp + 2] = b.z * (double)is.z; o[Cp + 3] = b.w * (double)is.w;
+        const double v[8] = {a.x, a.y, a.z, a.w, b.x * (double)is.x, b.y * (double)is.y, b.z * (double)is.z, b.w * (double)is.w};
+        if (tickets) {
+            // device-scope stores (write through the XCD's L2): the workgroup that sums them may run on another XCD
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __hip_atomic_store(o + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + Cp + i, v[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+            o[Cp] = v[4]; o[Cp + 1] = v[5]; o[Cp + 2] = v[6]; o[Cp + 3] = v[7];
+        }
     }
     if (!tickets) return;                                // two-launch form: sum_parts_kernel adds the row partials
     // Last workgroup of this channel column adds the column's row partials itself — one launch instead of two (the ~5 us
-    // sum_parts launch was a third of a call on 24 MB tensors: 141 BN layers per DeepLab-Xception step).  Release: every
-    // thread's partial is written back before the ticket is taken; acquire: the last workgroup invalidates its caches before it
-    // reads the other workgroups' partials (they ran on other XCDs, each with its own L2).  The partials are added in a FIXED
-    // order (row partial p by thread row p % ry, then a tree over the thread rows), so the result does not depend on which
-    // workgroup happens to be last: deterministic.  The counter is handed back at 0 for the next call.
-    __threadfence();
+    // sum_parts launch was a third of a call on 24 MB tensors: 141 BN layers per DeepLab-Xception step).  The XCDs' L2s are not
+    // coherent with each other for ordinary accesses, and agent-scope fences (__threadfence: L2 write-back + invalidate in
+    // every workgroup) cost 160 us per call — measured, cfg2 56.7 -> 66.5 ms.  So the partials themselves travel as DEVICE-SCOPE
+    // relaxed atomic stores / loads (sc1: through the L2 to the coherence point, no cache maintenance): a workgroup waits for
+    // its stores to be acknowledged (vmcnt), then takes its ticket; the last one reads the partials with device-scope loads.
+    // They are added in a FIXED order (row partial p by thread row p % ry, then a tree over the thread rows), so the result does
+    // not depend on which workgroup happens to be last: deterministic.  The counter is handed back at 0 for the next call.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ unsigned last;
     __syncthreads();
     if (t == 0) last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
     __syncthreads();
     if (!last) return;
-    __threadfence();
     D4 a0 = dzero4(), a1 = dzero4();
     if (cok) {
         const int Cp = c4n * 4;
+        auto ldc = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         for (int p = threadIdx.y; p < (int)gridDim.y; p += blockDim.y) {
             const double* q = part + (long)p * 2 * Cp + c4 * 4;
-            a0.x += __builtin_nontemporal_load(q); a0.y += __builtin_nontemporal_load(q + 1);
-            a0.z += __builtin_nontemporal_load(q + 2); a0.w += __builtin_nontemporal_load(q + 3);
-            a1.x += __builtin_nontemporal_load(q + Cp); a1.y += __builtin_nontemporal_load(q + Cp + 1);
-            a1.z += __builtin_nontemporal_load(q + Cp + 2); a1.w += __builtin_nontemporal_load(q + Cp + 3);
+            a0.x += ldc(q); a0.y += ldc(q + 1); a0.z += ldc(q + 2); a0.w += ldc(q + 3);
+            a1.x += ldc(q + Cp); a1.y += ldc(q + Cp + 1); a1.z += ldc(q + Cp + 2); a1.w += ldc(q + Cp + 3);
         }
     }
     sm0[t] = a0; sm1[t] = a1;

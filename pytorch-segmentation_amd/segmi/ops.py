@@ -55,7 +55,13 @@ def workspace(nbytes, device):
 
 
 _BN_TICKETS = {}
-_BN_TICKETS_ON = os.environ.get("SEGMI_BN_TICKETS", "1") == "1"      # A/B hook: 0 = separate summation launch in bn_bwd_reduce
+# SEGMI_BN_TICKETS=1: bn_bwd_reduce sums its row partials in the last workgroup of each channel column (one launch) instead of a
+# second launch.  OFF by default — measured negative in one call each (profiles/r05_bn_tickets_ab.txt): with agent-scope fences
+# cfg2 56.7 -> 66.5 ms (every workgroup's __threadfence writes back / invalidates its XCD's L2: +160 us per call); with
+# device-scope (sc1) atomic stores / loads and no cache maintenance cfg2 56.6 -> 58.8, cfg5 54.3 -> 55.1, cfg3 82.8 -> 85.2 ms:
+# the last workgroup's serial walk over up to 512 partials (one CU, ~2 us per dependent round trip) is longer than the ~5 us
+# launch it replaces, and nothing else runs beside it.  Kept as a tested opt-in.
+_BN_TICKETS_ON = os.environ.get("SEGMI_BN_TICKETS", "0") == "1"
 
 
 def _bn_tickets(device):
