@@ -340,16 +340,22 @@ int segmi_pyramid_up_bwd(const float* dy, int lddy, int N, int H, int W, int K, 
  *   rank 0: segmi_comm_get_unique_id -> ship the segmi_comm_unique_id_bytes() bytes to every rank by any means -> all ranks:
  *   segmi_comm_init(&c, world, rank, id) on their current HIP device.
  *   segmi_comm_allreduce_async / _allgather_async: the communicator's side stream waits for everything enqueued on `stream` so
- *   far (the buffer is complete), runs the collective (sum, or average when `average`; all-gather of count_per_rank floats per rank)
- *   and records an event; segmi_comm_wait(c, s) makes stream s wait for the communicator's LAST collective.  No host sync. */
+ *   far (the buffer is complete), the collective is enqueued on the side stream, an event OF THIS CALL is recorded and its
+ *   ticket (>= 1, increasing) returned through ticket_out (may be NULL).  segmi_comm_wait_ticket(c, t, s) makes stream s wait for
+ *   exactly that collective (bucket i's optimizer step can start while buckets i+1... are in flight); segmi_comm_wait(c, s)
+ *   for the communicator's LAST collective.  No host sync.  A communicator belongs to the HIP device that was current at
+ *   segmi_comm_init: calls made with another current device return SEGMI_ERR_BADARG. */
 typedef struct segmi_comm segmi_comm;
 int segmi_comm_available(void);
 int segmi_comm_unique_id_bytes(void);
 int segmi_comm_get_unique_id(void* id_out, size_t bytes);
 int segmi_comm_init(segmi_comm** comm_out, int world, int rank, const void* unique_id, size_t bytes);
 int segmi_comm_world(const segmi_comm* comm);
-int segmi_comm_allreduce_async(segmi_comm* comm, const float* send, float* recv, size_t count, int average, segmi_stream_t stream);
-int segmi_comm_allgather_async(segmi_comm* comm, const float* send, float* recv, size_t count_per_rank, segmi_stream_t stream);
+int segmi_comm_allreduce_async(segmi_comm* comm, const float* send, float* recv, size_t count, int average, long* ticket_out,
+                               segmi_stream_t stream);
+int segmi_comm_allgather_async(segmi_comm* comm, const float* send, float* recv, size_t count_per_rank, long* ticket_out,
+                               segmi_stream_t stream);
+int segmi_comm_wait_ticket(segmi_comm* comm, long ticket, segmi_stream_t stream);
 int segmi_comm_wait(segmi_comm* comm, segmi_stream_t stream);
 int segmi_comm_destroy(segmi_comm* comm);
 

@@ -49,14 +49,19 @@ class BaseDataLoader:
             self.indices = np.asarray(_indices)
         elif val_split:
             # the reference's split (base/base_dataloader.py:25-44): a fixed permutation under np.random.seed(0), the first
-            # `val_split` share validates
-            self.shuffle = False if _is_val_split else self.shuffle
+            # `val_split` share validates; the training subset is then drawn through a SubsetRandomSampler, i.e. in a NEW random
+            # order every epoch whatever `shuffle` said (:43-44 sets shuffle = False only because a sampler is given)
+            self.shuffle = True
             split = int(self.nbr_examples * val_split)
             order = np.random.RandomState(0).permutation(self.nbr_examples)
             self.indices, self.val_indices = order[split:], order[:split]
         else:
             self.indices = np.arange(self.nbr_examples)
         self.nbr_examples = len(self.indices)
+        # validation-type loaders (a dataset in val mode, or the held-out split) run no collectives per step: their ranks may see
+        # different batch counts, so every sample is visited exactly once; training loaders need the SAME number of steps on
+        # every rank (gradient all-reduce, SyncBN) and wrap around instead
+        self._validation = bool(_is_val_split or getattr(dataset, "val", False))
         self._init_kwargs = dict(batch_size=batch_size, shuffle=False, num_workers=num_workers, device=device, seed=seed, drop_last=drop_last)
         self._augment = None
 
@@ -71,14 +76,32 @@ class BaseDataLoader:
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + 1000003 * self.epoch)
             idx = idx[torch.randperm(len(idx), generator=g).numpy()]
-        nb = len(idx) // self.batch_size if self.drop_last else -(-len(idx) // self.batch_size)
+        nb = self._num_batches()
         all_b = [idx[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
-        per_rank = len(all_b) // self.world if self.world > 1 else len(all_b)
-        return [all_b[i * self.world + self.rank] for i in range(per_rank)]     # this rank's shard of global step i
+        if self.world == 1:
+            return all_b
+        if nb == 0:
+            return []
+        if self._validation:
+            # every batch exactly once over the ranks (rank r takes batches r, r + world, ...): no sample is dropped or seen twice,
+            # the epoch's metric counters are all-reduced; ranks may differ by one batch
+            return [all_b[j] for j in range(self.rank, nb, self.world)]
+        # training: ceil(nb / world) global steps on EVERY rank; the last global step wraps around to the epoch's first batches
+        # (torch's DistributedSampler pads the same way) instead of silently dropping up to world - 1 batches per epoch
+        steps = -(-nb // self.world)
+        return [all_b[(i * self.world + self.rank) % nb] for i in range(steps)]  # this rank's shard of global step i
+
+    def _num_batches(self):
+        n = len(self.indices)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __len__(self):
-        n = len(self.indices) // self.batch_size if self.drop_last else -(-len(self.indices) // self.batch_size)
-        return n // self.world if self.world > 1 else n
+        nb = self._num_batches()
+        if self.world == 1 or nb == 0:
+            return nb
+        if self._validation:
+            return len(range(self.rank, nb, self.world))
+        return -(-nb // self.world)
 
     def _augmenter(self):
         if self._augment is None:

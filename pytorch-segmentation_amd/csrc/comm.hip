@@ -4,8 +4,9 @@
 //   all-gather of the SyncBN Welford partials      replaces torch.cuda.comm.reduce_add / broadcast_coalesced in
 //                                                  utils/sync_batchnorm/batchnorm.py:117-126 and the master/slave pipes of comm.py:102-133
 // A communicator owns a side HIP stream: *_async makes the side stream wait for the caller's stream (the buffer is complete),
-// enqueues the collective there, and records an event; segmi_comm_wait makes any stream wait for that event — so a bucket's
-// all-reduce overlaps whatever the compute stream does next (the rest of backward) without a host synchronisation.
+// enqueues the collective there, records an event OF ITS OWN (a ring of SEGMI_COMM_EVENTS events) and hands back its ticket;
+// segmi_comm_wait_ticket makes any stream wait for exactly that collective — bucket i's optimizer step starts while buckets
+// i+1... are still on the wire — and segmi_comm_wait for the latest one.  No host synchronisation anywhere.
 // RCCL is bound at run time (dlopen of the librccl the process already carries — torch ships one — else the system's): libsegmi
 // has no link-time dependency on it, and a single-GPU process never touches it.
 #include "segmi_common.h"
@@ -52,11 +53,14 @@ bool rccl() {
 
 }  // namespace
 
+constexpr int SEGMI_COMM_EVENTS = 64;     // a ticket older than the ring waits for the collective that re-used its event: a LATER one
+                                           // on the same in-order side stream, so the wait is still sufficient
 struct segmi_comm {
     ncclComm_t comm;
     hipStream_t side;
-    hipEvent_t ready, done;
-    int world, rank;
+    hipEvent_t ready, done[SEGMI_COMM_EVENTS];
+    long next;                             // ticket of the next collective (tickets start at 1; 0 = nothing enqueued yet)
+    int world, rank, device;
 };
 
 extern "C" {
@@ -82,9 +86,11 @@ int segmi_comm_init(segmi_comm** out, int world, int rank, const void* unique_id
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) { delete c; return SEGMI_ERR_LAUNCH; }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+    c->next = 1;
+    bool ok = hipGetDevice(&c->device) == hipSuccess && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < SEGMI_COMM_EVENTS; ++i) ok = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         g_rccl.CommDestroy(c->comm);
         delete c;
         return SEGMI_ERR_LAUNCH;
@@ -95,30 +101,51 @@ int segmi_comm_init(segmi_comm** out, int world, int rank, const void* unique_id
 
 int segmi_comm_world(const segmi_comm* c) { return c ? c->world : 0; }
 
+// the communicator lives on the device it was created on: a call from a thread whose current device is another one would enqueue
+// on the wrong device's streams
+static bool on_device(const segmi_comm* c) {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess && dev == c->device;
+}
 static int begin(segmi_comm* c, hipStream_t producer) {
+    if (!on_device(c)) return SEGMI_ERR_BADARG;
     if (hipEventRecord(c->ready, producer) != hipSuccess) return SEGMI_ERR_LAUNCH;          // the buffer is complete on the caller's stream
     return hipStreamWaitEvent(c->side, c->ready, 0) == hipSuccess ? SEGMI_OK : SEGMI_ERR_LAUNCH;
 }
+static int finish(segmi_comm* c, long* ticket_out) {
+    const long ticket = c->next++;
+    if (hipEventRecord(c->done[ticket % SEGMI_COMM_EVENTS], c->side) != hipSuccess) return SEGMI_ERR_LAUNCH;
+    if (ticket_out) *ticket_out = ticket;
+    return SEGMI_OK;
+}
 
-int segmi_comm_allreduce_async(segmi_comm* c, const float* send, float* recv, size_t count, int average, segmi_stream_t stream) {
+int segmi_comm_allreduce_async(segmi_comm* c, const float* send, float* recv, size_t count, int average, long* ticket_out,
+                               segmi_stream_t stream) {
     if (!c || !send || !recv || count == 0) return SEGMI_ERR_BADARG;
     int rc = begin(c, (hipStream_t)stream);
     if (rc != SEGMI_OK) return rc;
     if (g_rccl.AllReduce(send, recv, count, ncclFloat, average ? ncclAvg : ncclSum, c->comm, c->side) != ncclSuccess) return SEGMI_ERR_LAUNCH;
-    return hipEventRecord(c->done, c->side) == hipSuccess ? SEGMI_OK : SEGMI_ERR_LAUNCH;
+    return finish(c, ticket_out);
 }
 
-int segmi_comm_allgather_async(segmi_comm* c, const float* send, float* recv, size_t count_per_rank, segmi_stream_t stream) {
+int segmi_comm_allgather_async(segmi_comm* c, const float* send, float* recv, size_t count_per_rank, long* ticket_out,
+                               segmi_stream_t stream) {
     if (!c || !send || !recv || count_per_rank == 0) return SEGMI_ERR_BADARG;
     int rc = begin(c, (hipStream_t)stream);
     if (rc != SEGMI_OK) return rc;
     if (g_rccl.AllGather(send, recv, count_per_rank, ncclFloat, c->comm, c->side) != ncclSuccess) return SEGMI_ERR_LAUNCH;
-    return hipEventRecord(c->done, c->side) == hipSuccess ? SEGMI_OK : SEGMI_ERR_LAUNCH;
+    return finish(c, ticket_out);
+}
+
+int segmi_comm_wait_ticket(segmi_comm* c, long ticket, segmi_stream_t stream) {
+    if (!c || ticket < 1 || ticket >= c->next || !on_device(c)) return SEGMI_ERR_BADARG;
+    return hipStreamWaitEvent((hipStream_t)stream, c->done[ticket % SEGMI_COMM_EVENTS], 0) == hipSuccess ? SEGMI_OK : SEGMI_ERR_LAUNCH;
 }
 
 int segmi_comm_wait(segmi_comm* c, segmi_stream_t stream) {
     if (!c) return SEGMI_ERR_BADARG;
-    return hipStreamWaitEvent((hipStream_t)stream, c->done, 0) == hipSuccess ? SEGMI_OK : SEGMI_ERR_LAUNCH;
+    if (c->next == 1) return SEGMI_OK;                 // nothing was ever enqueued
+    return segmi_comm_wait_ticket(c, c->next - 1, stream);
 }
 
 int segmi_comm_destroy(segmi_comm* c) {
@@ -126,7 +153,7 @@ int segmi_comm_destroy(segmi_comm* c) {
     hipStreamSynchronize(c->side);
     g_rccl.CommDestroy(c->comm);
     hipEventDestroy(c->ready);
-    hipEventDestroy(c->done);
+    for (int i = 0; i < SEGMI_COMM_EVENTS; ++i) hipEventDestroy(c->done[i]);
     hipStreamDestroy(c->side);
     delete c;
     return SEGMI_OK;

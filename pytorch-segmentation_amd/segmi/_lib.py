@@ -109,8 +109,9 @@ SIGNATURES = {
     "segmi_comm_get_unique_id": (i32, [vp, sz]),
     "segmi_comm_init": (i32, [C.POINTER(vp), i32, i32, vp, sz]),
     "segmi_comm_world": (i32, [vp]),
-    "segmi_comm_allreduce_async": (i32, [vp, vp, vp, sz, i32, vp]),
-    "segmi_comm_allgather_async": (i32, [vp, vp, vp, sz, vp]),
+    "segmi_comm_allreduce_async": (i32, [vp, vp, vp, sz, i32, C.POINTER(C.c_long), vp]),
+    "segmi_comm_allgather_async": (i32, [vp, vp, vp, sz, C.POINTER(C.c_long), vp]),
+    "segmi_comm_wait_ticket": (i32, [vp, C.c_long, vp]),
     "segmi_comm_wait": (i32, [vp, vp]),
     "segmi_comm_destroy": (i32, [vp]),
     "segmi_aug_resize": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, i32, vp]),

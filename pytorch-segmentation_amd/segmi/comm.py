@@ -37,31 +37,61 @@ class AbiCommunicator:
         with torch.cuda.device(self.device):
             check(lib.segmi_comm_init(C.byref(handle), self.world, self.rank, buf, n), "comm_init")
         self._h = handle
+        self.last_ticket = 0
+        self._pending = {}          # ticket -> tensors the side stream still uses
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _check(self, *tensors):
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_cuda or t.device != self.device or not t.is_contiguous():
+                raise SegmiError("segmi_comm: contiguous float32 tensors on %s only (got %s %s on %s)" % (self.device, t.dtype, tuple(t.shape), t.device))
+
     def all_reduce_async(self, t, average=False, out=None):
-        """Enqueue all-reduce(t) -> out (in place by default) behind everything on the current stream; returns immediately."""
+        """Enqueue all-reduce(t) -> out (in place by default) behind everything on the current stream; returns `out` immediately.
+        The collective's ticket is `self.last_ticket` (pass it to wait() to wait for exactly this call)."""
         out = t if out is None else out
-        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or not out.is_contiguous():
-            raise SegmiError("segmi_comm.all_reduce: contiguous float32 CUDA tensors only")
-        check(lib.segmi_comm_allreduce_async(self._h, t.data_ptr(), out.data_ptr(), t.numel(), 1 if average else 0, self._stream()), "comm_allreduce_async")
+        self._check(t, out)
+        ticket = C.c_long(0)
+        with torch.cuda.device(self.device):
+            check(lib.segmi_comm_allreduce_async(self._h, t.data_ptr(), out.data_ptr(), t.numel(), 1 if average else 0, C.byref(ticket), self._stream()),
+                  "comm_allreduce_async")
+        self.last_ticket = ticket.value
+        # the side stream reads / writes these buffers: they stay referenced until a wait() has ordered a stream behind the call
+        self._pending[self.last_ticket] = (t, out)
         return out
 
     def all_gather_async(self, t):
-        out = torch.empty(self.world * t.numel(), dtype=torch.float32, device=t.device)
-        check(lib.segmi_comm_allgather_async(self._h, t.contiguous().data_ptr(), out.data_ptr(), t.numel(), self._stream()), "comm_allgather_async")
+        """Enqueue all-gather(t) -> a new [world * numel] tensor behind everything on the current stream; returns it immediately
+        (its contents are valid for streams that have wait()ed on `self.last_ticket`)."""
+        src = t.contiguous()
+        self._check(src)
+        out = torch.empty(self.world * src.numel(), dtype=torch.float32, device=self.device)
+        ticket = C.c_long(0)
+        with torch.cuda.device(self.device):
+            check(lib.segmi_comm_allgather_async(self._h, src.data_ptr(), out.data_ptr(), src.numel(), C.byref(ticket), self._stream()), "comm_allgather_async")
+        self.last_ticket = ticket.value
+        self._pending[self.last_ticket] = (src, out)     # incl. the contiguous copy: freed only after a wait() covers this call
         return out
 
-    def wait(self):
-        """The current stream waits for this communicator's last collective (no host synchronisation)."""
-        check(lib.segmi_comm_wait(self._h, self._stream()), "comm_wait")
+    def wait(self, ticket=None):
+        """The current stream waits for collective `ticket` (default: this communicator's last one) — no host synchronisation.
+        Collectives run in order on the communicator's stream, so every earlier call is complete for this stream as well; their
+        buffers are released here (the caching allocator may then reuse them on this stream, which is ordered behind them)."""
+        ticket = self.last_ticket if ticket is None else int(ticket)
+        if ticket <= 0:
+            return
+        with torch.cuda.device(self.device):
+            check(lib.segmi_comm_wait_ticket(self._h, ticket, self._stream()), "comm_wait_ticket")
+        for k in [k for k in self._pending if k <= ticket]:
+            del self._pending[k]
 
     def close(self):
         if self._h is not None:
-            lib.segmi_comm_destroy(self._h)
+            lib.segmi_comm_destroy(self._h)      # synchronises the side stream
             self._h = None
+            self._pending.clear()
 
     def __del__(self):
         try:

@@ -65,6 +65,18 @@ def bucket_schedule(total_bytes, max_bytes=64 << 20, min_bytes=4 << 20):
     return caps
 
 
+class _AbiWork:
+    """Handle of one collective on an AbiCommunicator: wait() orders the current stream behind that call only (its own event),
+    so finish() steps bucket i while buckets i+1... are still in flight — like torch.distributed's Work objects."""
+    __slots__ = ("comm", "ticket")
+
+    def __init__(self, comm, ticket):
+        self.comm, self.ticket = comm, ticket
+
+    def wait(self):
+        self.comm.wait(self.ticket)
+
+
 class GradAllReducer:
     """Bucketed, overlapped gradient averaging for the parameters of one model replica.
 
@@ -182,7 +194,7 @@ class GradAllReducer:
             if self._ops is not None:
                 self._ops.wgrad_stream_join()
             self._abi.all_reduce_async(b["buf"], average=self.average)     # on the communicator's side stream, behind the compute stream
-            b["work"], b["scale"] = self._abi, False
+            b["work"], b["scale"] = _AbiWork(self._abi, self._abi.last_ticket), False
             return
         if self.side is not None:
             if self._ops is not None:
@@ -231,7 +243,7 @@ class GradAllReducer:
         for i, b in enumerate(self.buckets):
             w = b["work"]
             if w is not None:
-                w.wait()                      # nccl / abi: current stream waits for the collective's stream
+                w.wait()                      # nccl / abi: the current stream waits for THIS bucket's collective only
                 if b.get("scale"):
                     b["buf"].div_(self.world)
                 b["work"] = None

