@@ -1004,8 +1004,16 @@ def _note_bn_consumer(x, batch_stats):
     """Pairing discovery: tell the module that produced `x` whether a batch-statistics BatchNorm consumes its output."""
     ref = getattr(x, "_segmi_producer", None)
     mod = ref() if ref is not None else None
-    if mod is not None:
-        mod._bn_consumer = bool(batch_stats)
+    if mod is None:
+        return
+    if batch_stats:
+        mod._bn_consumer = True
+    elif torch.is_grad_enabled():
+        # a BN on running statistics inside a grad-enabled forward = a FROZEN layer: its producer need not emit partials.  A
+        # validation pass (model.eval() under torch.no_grad(), trainer.py:109-171) leaves the marks alone — clearing them made the
+        # first training step after every validation take the separate statistics pass, i.e. the training trajectory depended
+        # (at fp32 rounding level) on whether validation ran (ADVICE r4)
+        mod._bn_consumer = False
 
 
 class _BatchNormActFn(torch.autograd.Function):
