@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
                                                          "one host call per step instead of ~800 launches")
+    ap.add_argument("--compute-priority", type=int, default=None,
+                    help="A/B: run the steps on a HIP stream of this priority (-1 = high) instead of torch's default stream; together with "
+                         "SEGMI_WGRAD_STREAM_PRIORITY it decides who wins the CUs when a data-gradient and a filter-gradient kernel compete")
     ap.add_argument("--lovasz-boost", type=float, default=0.0,
                     help="cfg5 A/B only: add this to the target logit on 80 %% of the pixels before the loss (trained-like, confident logits "
                          "instead of random-init ones: more elements survive the Lovasz tail pruning); costs one extra elementwise add per step")
@@ -364,6 +367,10 @@ def main():
                                  "effective_tflops": round(r["eff_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
 
     wino_default = segmi_ops.get_conv_winograd()["on"]
+    if args.compute_priority is not None:
+        cstream = torch.cuda.Stream(device=device, priority=args.compute_priority)
+        cstream.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(cstream)
     run = step
     if args.graph:
         from segmi.graph import GraphedStep

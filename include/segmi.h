@@ -181,6 +181,13 @@ int segmi_colsum(const float* dy, int ld, long rows, int C, float* out, void* wo
  * segmi_conv_desc with K == C; the filter is [R,S,C] (tap-major, channels contiguous), R*S <= 9.
  * HBM-bound streaming kernels (0.75 % of Xception's MACs): deliberately not a GEMM. */
 int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, segmi_stream_t stream);
+/* The same launch with the BN-statistics epilogue (the BatchNorm between the depthwise and the pointwise convolution of
+ * SeparableConv2d, models/deeplabv3_plus.py:76-86): segmi_dwconv2d_fwd_stats_parts(d) blocks of {count, mean, M2}[C] floats in the
+ * layout of segmi_conv2d_fwd_stats (possibly > 512 partials: segmi_bn_finalize_from_parts merges in two levels); y is
+ * bit-identical to segmi_dwconv2d_fwd.  stats_partials 16-byte aligned. */
+int segmi_dwconv2d_fwd_stats_parts(const segmi_conv_desc* d);
+int segmi_dwconv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats_partials,
+                             segmi_stream_t stream);
 int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream);
 size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d);
 int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,

@@ -10,6 +10,7 @@
 //
 // All kernels: NHWC fp32, a thread owns one float4 channel group and walks pixels (rowgeom.h).
 #include "rowgeom.h"
+#include "welford.h"
 #include <cstdlib>
 
 namespace {
@@ -18,12 +19,42 @@ struct DwGeom {
     int N, H, W, C, P, Q, R, S, stride, pad, dil;
 };
 
+// BN-statistics epilogue of the forward kernels (STATS): every thread keeps a Welford run over the outputs it writes, the block's
+// thread rows merge through LDS (Chan, fixed tree) and the block writes ONE {count, mean, M2} partial per channel —
+// stats[blockIdx.y][3][C], the layout of the dense convolution's epilogue (conv_igemm.hip) — so the BatchNorm behind a depthwise
+// layer (SeparableConv2d: depthwise -> BN -> pointwise, models/deeplabv3_plus.py:76-86) never reads y for its statistics.
+__device__ __forceinline__ void dw_stats_block(const Wf4& wf, bool cok, int c4, int C, float* __restrict__ stats) {
+    __shared__ Wf4 sm[256];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    sm[t] = wf;
+    __syncthreads();
+    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.y < s) {
+            Wf4 a = sm[t];
+            wf_merge(a, sm[t + s * blockDim.x]);
+            sm[t] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.y == 0 && cok) {
+        const Wf4 a = sm[t];
+        float* o = stats + (long)blockIdx.y * 3 * C + c4 * 4;
+        st4(o, make_float4(a.n, a.n, a.n, a.n));
+        st4(o + C, a.mean);
+        st4(o + 2 * C, a.m2);
+    }
+}
+
 // y[n,p,q,c] = sum_{r,s} x[n, p*stride - pad + r*dil, q*stride - pad + s*dil, c] * w[r,s,c]
-template <int MAXT>
+template <int MAXT, bool STATS>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                         float* __restrict__ y, int ldy, DwGeom g) {
+                                                         float* __restrict__ y, int ldy, DwGeom g, float* __restrict__ stats) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c4 * 4 >= g.C) return;
+    const bool cok = c4 * 4 < g.C;
+    if (!STATS && !cok) return;
+    Wf4 wf;
+    wf_init(wf);
+    if (cok) {
     const int T = g.R * g.S;
     float4 wt[MAXT];
 #pragma unroll
@@ -47,7 +78,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
             }
         }
         st4(y + row * ldy + c4 * 4, acc);
+        if (STATS) wf_push(wf, acc);
     }
+    }
+    if (STATS) dw_stats_block(wf, cok, c4, g.C, stats);
 }
 
 // dx[n,h,w,c] = sum_{r,s} dy[n, (h + pad - r*dil)/stride, (w + pad - s*dil)/stride, c] * w[r,s,c]   (where divisible)
@@ -142,11 +176,16 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 // 4.5 float4 loads per output for D = 1 instead of 9 (the one-output-per-thread kernels above are load-issue bound: 28 us per
 // 728-channel 32x32 layer whose tensors stream in 10 us).
 // FLIP: the filter is read rotated by 180 degrees — the data gradient of the same convolution (dx = dy (*) rot180(w)).
-template <int D, bool FLIP>
+template <int D, bool FLIP, bool STATS>
 __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                          float* __restrict__ y, int ldy, int N, int H, int W, int C) {
+                                                          float* __restrict__ y, int ldy, int N, int H, int W, int C,
+                                                          float* __restrict__ stats) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c4 * 4 >= C) return;
+    const bool cok = c4 * 4 < C;
+    if (!STATS && !cok) return;
+    Wf4 wf;
+    wf_init(wf);
+    if (cok) {
     float4 wt[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t] = ld4(w + (long)(FLIP ? 8 - t : t) * C + c4 * 4);
@@ -183,8 +222,13 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
         float* o = y + ((long)(n * H + p) * W + q0) * ldy + c4 * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (q0 + j < W) st4(o + (long)j * ldy, acc[j]);
+            if (q0 + j < W) {
+                st4(o + (long)j * ldy, acc[j]);
+                if (STATS) wf_push(wf, acc[j]);
+            }
     }
+    }
+    if (STATS) dw_stats_block(wf, cok, c4, C, stats);
 }
 
 // filter gradient of the same convolutions, same strips: part[blockIdx.y][t][C] = sum over this block's strips of dy (x) x-taps
@@ -354,19 +398,42 @@ int dw_strip(const segmi_conv_desc* d) {
 
 extern "C" {
 
-int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, segmi_stream_t stream) {
+static RowGeom dw_fwd_geom(const segmi_conv_desc* d, int strip) {
+    if (strip) return row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
+    return row_geom((long)d->N * d->P * d->Q, d->C, 2, SEGMI_MAX_GRID);
+}
+static int dw_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats, segmi_stream_t stream) {
     if (!dw_ok(d) || !x || !w_rsc || !y) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
-    const long rows = (long)d->N * d->P * d->Q;
-    if (const int D = dw_strip(d)) {
-        RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
-        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, false>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C);
-        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, false>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C);
+    if (stats && ((uintptr_t)stats & 15)) return SEGMI_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = dw_strip(d);
+    const RowGeom g = dw_fwd_geom(d, D);
+    if (D) {
+#define SEGMI_DW_STRIP(DV, SV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, false, SV>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C, stats)
+        if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true); else SEGMI_DW_STRIP(1, false); }
+        else        { if (stats) SEGMI_DW_STRIP(2, true); else SEGMI_DW_STRIP(2, false); }
+#undef SEGMI_DW_STRIP
         return segmi_launch_status();
     }
-    RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
-    hipLaunchKernelGGL((dwconv_fwd_kernel<9>), g.grid, g.block, 0, (hipStream_t)stream, x, d->ldx, w_rsc, y, d->ldy, dw_geom(d));
+    if (stats) hipLaunchKernelGGL((dwconv_fwd_kernel<9, true>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, dw_geom(d), stats);
+    else       hipLaunchKernelGGL((dwconv_fwd_kernel<9, false>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, dw_geom(d), (float*)nullptr);
     return segmi_launch_status();
+}
+
+int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, segmi_stream_t stream) {
+    return dw_fwd_impl(d, x, w_rsc, y, nullptr, stream);
+}
+
+int segmi_dwconv2d_fwd_stats_parts(const segmi_conv_desc* d) {
+    if (!dw_ok(d) || (d->C & 3)) return 0;
+    return (int)dw_fwd_geom(d, dw_strip(d)).grid.y;
+}
+
+int segmi_dwconv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats_partials,
+                             segmi_stream_t stream) {
+    if (!stats_partials) return SEGMI_ERR_BADARG;
+    return dw_fwd_impl(d, x, w_rsc, y, stats_partials, stream);
 }
 
 int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream) {
@@ -375,8 +442,8 @@ int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float*
     const long rows = (long)d->N * d->H * d->W;
     if (const int D = dw_strip(d)) {          // dx = dy (*) rot180(w): the forward strip kernel with the filter read flipped
         RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
-        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C);
-        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C);
+        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr);
+        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr);
         return segmi_launch_status();
     }
     RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "segmi_conv_set_math": (i32, [i32]),
     "segmi_conv_get_math": (i32, []),
     "segmi_dwconv2d_fwd": (i32, [PD, vp, vp, vp, vp]),
+    "segmi_dwconv2d_fwd_stats_parts": (i32, [PD]),
+    "segmi_dwconv2d_fwd_stats": (i32, [PD, vp, vp, vp, vp, vp]),
     "segmi_dwconv2d_dgrad": (i32, [PD, vp, vp, vp, vp]),
     "segmi_dwconv2d_wgrad_workspace": (sz, [PD]),
     "segmi_dwconv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),

@@ -36,9 +36,9 @@ class Conv2d(nn.Conv2d):
         self._bn_consumer = False
 
     def forward(self, x, with_skip=False):
-        if self.depthwise:
-            return ops.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
         fuse = self._bn_consumer and torch.is_grad_enabled()
+        if self.depthwise:
+            return ops.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0], self.dilation[0], bn_stats=fuse, producer=self)
         if with_skip:   # (conv(x), x): residual fork whose backward accumulates dgrad onto the skip gradient (ops.conv2d_skip)
             if self.bias is not None:
                 raise ValueError("with_skip is for the bias-free first convolution of a residual block")
@@ -139,7 +139,7 @@ def link_conv_bn(root):
         last = None
         for child in parent.children():
             if isinstance(child, BatchNorm2d):
-                if isinstance(last, Conv2d) and not last.depthwise:
+                if isinstance(last, Conv2d):
                     if not last._bn_consumer:
                         marked += 1
                     last._bn_consumer = True

@@ -870,7 +870,7 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
     """nn.Conv2d(C, C, k, groups=C, bias=False): filter [C,1,R,S] is re-laid [R,S,C] per call (C*R*S floats)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dil):
+    def forward(ctx, x, weight, stride, pad, dil, bn_stats=False):
         x = to_nhwc(x, "depthwise_conv2d")
         _need_cuda(weight, "depthwise_conv2d")
         N, C, H, W = x.shape
@@ -885,7 +885,14 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, C, P, Q, x.device)
         d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
-        check(lib.segmi_dwconv2d_fwd(d, x.data_ptr(), wrsc.data_ptr(), y.data_ptr(), st), "dwconv2d_fwd")
+        parts = lib.segmi_dwconv2d_fwd_stats_parts(d) if bn_stats else 0
+        if parts > 0:        # the BatchNorm behind this layer takes its statistics from the kernel's epilogue (see _BN_FUSE)
+            part = torch.empty(parts * 3 * C, device=x.device, dtype=torch.float32)
+            check(lib.segmi_dwconv2d_fwd_stats(d, x.data_ptr(), wrsc.data_ptr(), y.data_ptr(), part.data_ptr(), st), "dwconv2d_fwd_stats")
+            _BN_FUSE["last"] = (part, parts)
+            _BN_FUSE["emitted"] += 1
+        else:
+            check(lib.segmi_dwconv2d_fwd(d, x.data_ptr(), wrsc.data_ptr(), y.data_ptr(), st), "dwconv2d_fwd")
         ctx.save_for_backward(x, wrsc)
         ctx.geom = (N, C, H, W, R, S, P, Q, stride, pad, dil)
         return y
@@ -909,11 +916,14 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
             check(lib.segmi_dwconv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, st), "dwconv2d_wgrad")
             dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
             check(lib.segmi_nhwc_to_nchw(dwr.data_ptr(), dw.data_ptr(), 1, C, R * S, 1, C, st), "dw filter rsc->crs")
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def depthwise_conv2d(x, weight, stride=1, padding=0, dilation=1):
-    return _DepthwiseConv2dFn.apply(x, weight, int(stride), int(padding), int(dilation))
+def depthwise_conv2d(x, weight, stride=1, padding=0, dilation=1, bn_stats=False, producer=None):
+    """nn.Conv2d(C, C, k, groups=C).  bn_stats / producer: as for conv2d (BN statistics from the kernel's epilogue, pairing tag)."""
+    _BN_FUSE["last"] = None
+    y = _DepthwiseConv2dFn.apply(x, weight, int(stride), int(padding), int(dilation), bool(bn_stats) and _BN_FUSE["on"])
+    return _tag_bn_stats(y, producer)
 
 
 # --------------------------------------------------------------------------- transposed convolution 2x2 / stride 2

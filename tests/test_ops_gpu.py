@@ -1058,6 +1058,86 @@ def test_winograd_output_transform_emits_the_bn_statistics(cuda, case):
     assert lib.segmi_conv2d_winograd_fwd(d, x.data_ptr(), wf.data_ptr(), bp, y1.data_ptr(), 1, None, part.data_ptr(), wsw.data_ptr(), nwsw, st) != 0
 
 
+@pytest.mark.parametrize("case", [(8, 728, 32, 32, 1, 1), (2, 128, 129, 131, 1, 1), (2, 256, 65, 65, 2, 1), (2, 64, 40, 44, 1, 2),
+                                  (1, 16, 7, 5, 1, 1), (2, 32, 256, 256, 1, 1)])
+def test_depthwise_forward_emits_the_bn_statistics(cuda, case):
+    """Round 5: SeparableConv2d is depthwise -> BatchNorm -> pointwise (models/deeplabv3_plus.py:76-86) — 63 BN layers per
+    DeepLab-Xception step sit behind a depthwise convolution.  segmi_dwconv2d_fwd_stats writes y bit-identically to
+    segmi_dwconv2d_fwd plus {count, mean, M2} partials (strip kernels for stride 1, the general kernel for stride 2; up to 2048
+    partials, merged in two levels) that agree with the streaming statistics pass: counts exactly, mean / M2 against fp64."""
+    from segmi import ops
+    from segmi._lib import ConvDesc, lib
+    N, C, H, W, dil, stride = case
+    g = torch.Generator().manual_seed(13)
+    x = ops.to_nhwc((torch.randn(N, C, H, W, generator=g) + 0.2).to(cuda))
+    w = (torch.randn(9 * C, generator=g) * 0.3).to(cuda)
+    pad = dil
+    P, Q = ops.conv_out_size(H, 3, stride, pad, dil), ops.conv_out_size(W, 3, stride, pad, dil)
+    y0, y1 = ops.empty_nhwc(N, C, P, Q, cuda), ops.empty_nhwc(N, C, P, Q, cuda)
+    d = ConvDesc(N, H, W, C, C, 3, 3, P, Q, stride, pad, dil, ops.ld_of(x), ops.ld_of(y0))
+    st = torch.cuda.current_stream().cuda_stream
+    parts = lib.segmi_dwconv2d_fwd_stats_parts(d)
+    assert parts > 0
+    assert lib.segmi_dwconv2d_fwd(d, x.data_ptr(), w.data_ptr(), y0.data_ptr(), st) == 0
+    part = torch.full((parts * 3 * C,), float("nan"), device=cuda)
+    assert lib.segmi_dwconv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), y1.data_ptr(), part.data_ptr(), st) == 0
+    assert torch.equal(y0, y1) and not torch.isnan(part).any()
+    rows = N * P * Q
+    cnt = part.view(parts, 3, C)[:, 0].sum(0)
+    assert float(cnt.min()) == rows == float(cnt.max())
+    nws = max(lib.segmi_bn_stats_workspace(rows, C), lib.segmi_bn_parts_workspace(parts, C))
+    ws = torch.empty(nws + 16, dtype=torch.uint8, device=cuda)
+    ref, got = torch.empty(3 * C, device=cuda), torch.empty(3 * C, device=cuda)
+    assert lib.segmi_bn_stats(y0.data_ptr(), ops.ld_of(y0), rows, C, ref.data_ptr(), ws.data_ptr(), nws, st) == 0
+    assert lib.segmi_bn_stats_from_parts(part.data_ptr(), parts, C, got.data_ptr(), ws.data_ptr(), nws, st) == 0
+    ref, got = ref.view(3, C).cpu().double(), got.view(3, C).cpu().double()
+    assert torch.equal(ref[0], got[0])
+    y64 = y0.detach().cpu().double().permute(0, 2, 3, 1).reshape(rows, C)
+    mean64, m264 = y64.mean(0), ((y64 - y64.mean(0)) ** 2).sum(0)
+    scale = y64.abs().max().item()
+    for name, t in (("statistics pass", ref), ("depthwise epilogue", got)):
+        assert (t[1] - mean64).abs().max().item() <= 2e-6 * scale, name
+        assert ((t[2] - m264).abs() / m264).max().item() <= 2e-5, name
+
+
+def test_separable_conv_block_takes_its_bn_statistics_from_both_epilogues(cuda):
+    """A SeparableConv2d + BatchNorm as models/deeplabv3_plus.py builds them: after link_conv_bn both the depthwise layer and the
+    pointwise layer emit their BN's statistics — no stand-alone statistics pass; outputs and gradients equal the unfused path."""
+    import copy
+    from models.deeplabv3_plus import SeparableConv2d
+    from segmi import nn as snn, ops
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sep, self.bn = SeparableConv2d(64, 128, 3, dilation=2), snn.BatchNorm2d(128)
+
+        def forward(self, x):
+            return self.bn(self.sep(x), relu=True)
+
+    prev = ops.get_conv_bn_stats()["on"]
+    try:
+        torch.manual_seed(4)
+        net = Net().to(cuda).train()
+        assert snn.link_conv_bn(net) == 2 and net.sep.conv1._bn_consumer and net.sep.pointwise._bn_consumer
+        ref = copy.deepcopy(net)
+        x = torch.randn(4, 64, 40, 36, device=cuda)
+        ops.set_conv_bn_stats(False)
+        yr = ref(x)
+        yr.square().mean().backward()
+        ops.set_conv_bn_stats(True)
+        c0 = ops.get_conv_bn_stats()
+        y = net(x)
+        y.square().mean().backward()
+        c1 = ops.get_conv_bn_stats()
+        assert c1["emitted"] - c0["emitted"] == 2 and c1["consumed"] - c0["consumed"] == 2
+        assert (y.detach() - yr.detach()).abs().max().item() <= 1e-5 * yr.abs().max().item()
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert ((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)).item() <= 2e-5, k
+    finally:
+        ops.set_conv_bn_stats(prev)
+
+
 def test_conv_to_batchnorm_pairing_static_link_and_runtime_discovery(cuda):
     """conv -> BN pairs are linked at model construction (snn.link_conv_bn: registration order), so the BN statistics come from the
     convolution's epilogue from the FIRST training step on; a pair the link did not see is discovered at run time (the BN layer
