@@ -31,6 +31,11 @@ class Conv2d(nn.Conv2d):
                 raise ValueError("segmi.nn.Conv2d needs symmetric %s, got %s" % (name, (v,)))
         if not self.depthwise and (self.kernel_size[0] > 1 or self.kernel_size[1] > 1):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        if self.depthwise:
+            # the depthwise kernels read the filter tap-major [R, S, C]: the parameter keeps its logical shape [C, 1, R, S] (state_dict
+            # keys, shapes and values unchanged) over memory in that order, so no per-step re-layout launch is needed — 63 forward +
+            # 63 gradient transposes per DeepLab-Xception step before (ops._dw_rsc_view)
+            self.weight.data = ops.dw_filter_rsc_layout(self.weight.data)
         # set by the BatchNorm2d that receives this module's output (ops._note_bn_consumer): True while a batch-statistics BN
         # consumes it — the convolution then emits the BN statistics partials from its epilogue (ops._BN_FUSE)
         self._bn_consumer = False

@@ -866,8 +866,24 @@ def conv2d_fan(x, branches):
 
 
 # --------------------------------------------------------------------------- depthwise convolution
+def dw_filter_rsc_layout(w):
+    """The depthwise filter [C, 1, R, S] re-laid over [R, S, C] memory (same logical tensor): what segmi.nn.Conv2d stores."""
+    C, one, R, S = w.shape
+    return w.permute(2, 3, 0, 1).contiguous().permute(2, 3, 0, 1)
+
+
+def _dw_rsc_view(w):
+    """Flat [R*S*C] view of a depthwise filter whose memory already is tap-major (dw_filter_rsc_layout), else None."""
+    C, one, R, S = w.shape
+    s = w.stride()
+    if one == 1 and s[0] == 1 and (S == 1 or s[3] == C) and (R == 1 or s[2] == S * C) and (w.data_ptr() & 15) == 0:
+        return torch.as_strided(w, (R * S * C,), (1,), w.storage_offset())
+    return None
+
+
 class _DepthwiseConv2dFn(torch.autograd.Function):
-    """nn.Conv2d(C, C, k, groups=C, bias=False): filter [C,1,R,S] is re-laid [R,S,C] per call (C*R*S floats)."""
+    """nn.Conv2d(C, C, k, groups=C, bias=False): the kernels read the filter as [R,S,C]; a parameter stored in that memory order
+    (segmi.nn.Conv2d does) is used in place and receives its gradient in the same order, any other filter is re-laid per call."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad, dil, bn_stats=False):
@@ -880,8 +896,11 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
         if C & 3:
             raise SegmiError("depthwise_conv2d: channel count must be a multiple of 4 (got %d)" % C)
         st = _stream()
-        wrsc = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
-        check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), wrsc.data_ptr(), 1, C, R * S, 1, C, st), "dw filter crs->rsc")
+        wrsc = _dw_rsc_view(weight.detach())
+        ctx.rsc_param = wrsc is not None
+        if wrsc is None:
+            wrsc = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
+            check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), wrsc.data_ptr(), 1, C, R * S, 1, C, st), "dw filter crs->rsc")
         P, Q = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         y = empty_nhwc(N, C, P, Q, x.device)
         d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(y))
@@ -914,8 +933,11 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
             ws = workspace(nws, x.device)
             dwr = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
             check(lib.segmi_dwconv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, st), "dwconv2d_wgrad")
-            dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
-            check(lib.segmi_nhwc_to_nchw(dwr.data_ptr(), dw.data_ptr(), 1, C, R * S, 1, C, st), "dw filter rsc->crs")
+            if ctx.rsc_param:     # the parameter's own memory order: the gradient is a view of what the kernel wrote
+                dw = dwr.view(R, S, C).permute(2, 0, 1).unsqueeze(1)
+            else:
+                dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
+                check(lib.segmi_nhwc_to_nchw(dwr.data_ptr(), dw.data_ptr(), 1, C, R * S, 1, C, st), "dw filter rsc->crs")
         return dx, dw, None, None, None, None
 
 

@@ -50,6 +50,7 @@ MEMBOUND_BYTES = {
     "segmi_nchw_to_nhwc": lambda a: _b4(2 * a[2] * a[3] * a[4] * a[5]),
     # depthwise 3x3 (args: desc*, x, w, y, stream): input + output once; the filter gradient reads x and dy
     "segmi_dwconv2d_fwd": lambda a: _dw_bytes(a[0]),
+    "segmi_dwconv2d_fwd_stats": lambda a: _dw_bytes(a[0]),            # + the BN statistics partials (a few KB)
     "segmi_dwconv2d_dgrad": lambda a: _dw_bytes(a[0]),
     "segmi_dwconv2d_wgrad": lambda a: _dw_bytes(a[0]),
     # Lovasz forward, tail-pruned (round 5): the threshold of a class is a reduction over ALL its pixels, so the logits are read at
