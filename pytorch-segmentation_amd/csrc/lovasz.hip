@@ -46,17 +46,38 @@ constexpr unsigned NO_THR = 0xFFFFFFFFu;   // threshold of a class without foreg
 
 // bits of |fg - p_c| with p_c = exp(z - lse): the ONE expression prepare / count / emit / backward all evaluate (no contraction
 // across the subtractions), so that every pass takes the same keep decision for an element
-__device__ __forceinline__ unsigned lov_err_bits(float z, float l, bool fg) {
-    const float p = expf(__fsub_rn(z, l));
-    return __float_as_uint(fabsf(__fsub_rn(fg ? 1.f : 0.f, p)));
-}
+__device__ __forceinline__ float lov_p(float z, float l) { return expf(__fsub_rn(z, l)); }
+__device__ __forceinline__ unsigned lov_p_err_bits(float p, bool fg) { return __float_as_uint(fabsf(__fsub_rn(fg ? 1.f : 0.f, p))); }
+__device__ __forceinline__ unsigned lov_err_bits(float z, float l, bool fg) { return lov_p_err_bits(lov_p(z, l), fg); }
 // effective threshold of class c: absent classes keep nothing; prune == 0 keeps every valid pixel of a present class (the
 // round-4 full sort, kept for A/B and as the bit-identity reference of the tests)
 __device__ __forceinline__ unsigned lov_thr_eff(const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int c, int prune) {
     return counts[c] == 0 ? NO_THR : (prune ? thr[c] : 0u);
 }
 
+// A pixel's logits row held in registers by the 8 lanes that share the pixel: lane g owns the float4 groups g, g + 8, ...  KQ > 0:
+// ceil(C/32) <= KQ <= 8 groups per lane, ALL loaded up front (KQ 16-byte loads in flight per lane instead of one; the second
+// sweep of a kernel re-uses the registers instead of re-reading L1/L2) — the streaming passes went from 2.5-3.3 to 4-5 TB/s at
+// C = 150.  KQ == 0: more than 256 classes, the groups are re-read from memory in every sweep (the round-4 form).
+template <int KQ>
+struct LovRow {
+    float4 v[KQ > 0 ? KQ : 1];
+    __device__ __forceinline__ void load(const float* __restrict__ row, int g, int c4n) {
+        if (KQ > 0) {
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+                const int q = g + 8 * k;
+                v[k] = q < c4n ? ld4(row + q * 4) : zero4();
+            }
+        }
+    }
+    __device__ __forceinline__ float4 get(const float* __restrict__ row, int k, int q) const { return KQ > 0 ? v[k] : ld4(row + q * 4); }
+};
+// trips of lane g over its groups (KQ > 0: compile-time, groups past the row are zeros and every use is guarded by c < C)
+#define LOV_TRIPS(KQ, g, c4n) (KQ > 0 ? KQ : ((c4n) - (g) + 7) / 8)
+
 // 8 lanes share a pixel (float4 channel groups, xor-shuffle reductions): coalesced 128-byte row segments
+template <int KQ>
 __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                              long rows, int C, long ignore, float* __restrict__ lse,
                                                              unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */,
@@ -68,23 +89,28 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
     __syncthreads();
     const int g = threadIdx.x & 7;
     const int c4n = (C + 3) >> 2;
+    const int trips = LOV_TRIPS(KQ, g, c4n);
     for (long r = (long)blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += (long)gridDim.x * 32) {
         const float* row = logits + r * ld;
+        LovRow<KQ> R;
+        R.load(row, g, c4n);
         float m = -INFINITY;
-        for (int q = g; q < c4n; q += 8) {
-            const float4 v = ld4(row + q * 4);
-            const int c = q * 4;
-            m = fmaxf(m, v.x);
+#pragma unroll
+        for (int k = 0; k < trips; ++k) {
+            const int q = g + 8 * k, c = q * 4;
+            const float4 v = R.get(row, k, q);
+            if (c < C) m = fmaxf(m, v.x);
             if (c + 1 < C) m = fmaxf(m, v.y);
             if (c + 2 < C) m = fmaxf(m, v.z);
             if (c + 3 < C) m = fmaxf(m, v.w);
         }
         m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
         float s = 0.f;
-        for (int q = g; q < c4n; q += 8) {
-            const float4 v = ld4(row + q * 4);
-            const int c = q * 4;
-            s += expf(v.x - m);
+#pragma unroll
+        for (int k = 0; k < trips; ++k) {
+            const int q = g + 8 * k, c = q * 4;
+            const float4 v = R.get(row, k, q);
+            if (c < C) s += expf(v.x - m);
             if (c + 1 < C) s += expf(v.y - m);
             if (c + 2 < C) s += expf(v.z - m);
             if (c + 3 < C) s += expf(v.w - m);
@@ -112,6 +138,7 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
 
 // cnt[c][unit] = number of survivors of class c among the unit's UPX pixels.  Same thread layout as prepare (a wave reads 8
 // pixel rows per step as 128-byte segments); a survivor costs one LDS atomic on its wave's counter row.
+template <int KQ>
 __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                                 const float* __restrict__ lse, long rows, int C, long ignore,
                                                                 const unsigned* __restrict__ thr, const unsigned* __restrict__ counts,
@@ -125,6 +152,7 @@ __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __r
     __syncthreads();
     const long unit = (long)blockIdx.x * 4 + w;
     const int c4n = (C + 3) >> 2;
+    const int trips = LOV_TRIPS(KQ, g, c4n);
     if (unit < nunits) {
         const long r0 = unit * UPX;
 #pragma unroll 2
@@ -133,12 +161,15 @@ __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __r
             if (r >= rows) continue;
             const long t = target[r];
             if (t == ignore) continue;
-            const float l = lse[r];
             const float* row = logits + r * ld;
-            for (int q = g; q < c4n; q += 8) {
-                const float4 v = ld4(row + q * 4);
-                const int c = q * 4;
-                if (lov_err_bits(v.x, l, t == c) >= thr_s[c]) atomicAdd(&run[c], 1u);
+            LovRow<KQ> R;
+            R.load(row, g, c4n);
+            const float l = lse[r];
+#pragma unroll
+            for (int k = 0; k < trips; ++k) {
+                const int q = g + 8 * k, c = q * 4;
+                const float4 v = R.get(row, k, q);
+                if (c < C && lov_err_bits(v.x, l, t == c) >= thr_s[c]) atomicAdd(&run[c], 1u);
                 if (c + 1 < C && lov_err_bits(v.y, l, t == c + 1) >= thr_s[c + 1]) atomicAdd(&run[c + 1], 1u);
                 if (c + 2 < C && lov_err_bits(v.z, l, t == c + 2) >= thr_s[c + 2]) atomicAdd(&run[c + 2], 1u);
                 if (c + 3 < C && lov_err_bits(v.w, l, t == c + 3) >= thr_s[c + 3]) atomicAdd(&run[c + 3], 1u);
@@ -182,6 +213,7 @@ __global__ __launch_bounds__(KS_T) void lovasz_keep_scan_kernel(unsigned* __rest
 // at a time; the 8 lanes holding the same class (same lane & 7, same float4 component) rank themselves with one ballot, the
 // wave's running slot of the class lives in LDS (a wave's LDS operations execute in order: every lane reads the slot before
 // the group's first lane advances it).
+template <int KQ>
 __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                           const float* __restrict__ lse, long rows, int C, long ignore, int PB,
                                                           const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int prune,
@@ -208,12 +240,16 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restric
         const bool valid = rok && t != ignore;
         if (__ballot(valid) == 0ull) continue;
         const float l = valid ? lse[r] : 0.f;
-        const float* row = logits + r * ld;
-        for (int q0 = 0; q0 < c4n; q0 += 8) {                          // uniform trip count: the ballots below see the whole wave
-            const int q = q0 + g, c = q * 4;
+        const float* row = logits + (valid ? r : 0) * ld;
+        LovRow<KQ> R;
+        if (valid) R.load(row, g, c4n);
+        const int trips = KQ > 0 ? KQ : (c4n + 7) / 8;                 // uniform trip count: the ballots below see the whole wave
+#pragma unroll
+        for (int k = 0; k < trips; ++k) {
+            const int q = g + 8 * k, c = q * 4;
             const bool qok = valid && q < c4n;
             float4 v = zero4();
-            if (qok) v = ld4(row + c);
+            if (qok) v = R.get(row, k, q);
             const float zs[4] = {v.x, v.y, v.z, v.w};
             unsigned eb[4];
             bool kp[4];
@@ -624,9 +660,10 @@ __device__ __forceinline__ float grp_sum8(float v) {
 // dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j), streaming: 8 lanes share a pixel like the forward's passes.  G_c is
 // fetched only where the forward's keep test holds (the same lov_err_bits against the thresholds the forward saved) — a
 // sparse gather of the survivor entries; every other G_c is exactly 0.
-__device__ __forceinline__ float lov_g(const float* __restrict__ grow, const unsigned* thr_s, float z, float l, long t, int c) {
-    return lov_err_bits(z, l, t == c) >= thr_s[c] ? grow[c] : 0.f;
+__device__ __forceinline__ float lov_g(const float* __restrict__ grow, const unsigned* thr_s, float p, long t, int c) {
+    return lov_p_err_bits(p, t == c) >= thr_s[c] ? grow[c] : 0.f;      // p = lov_p(z, lse): ONE exp per element serves the keep test and the product
 }
+template <int KQ>
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                                                          long ignore, const float* __restrict__ lse,
                                                          const float* __restrict__ G, int ldg, long rows, int C,
@@ -649,28 +686,55 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
         const float l = lse[r];
         const float* row = logits + r * ld;
         const float* grow = G + r * ldg;
+        LovRow<KQ> R;
+        R.load(row, g, c4n);
+        const int trips = LOV_TRIPS(KQ, g, c4n);
+        // sweep 1: p = softmax probabilities (kept in the row's registers when KQ > 0: the second sweep needs no exp), s = sum_j G_j p_j
         float s = 0.f;
-        for (int q = g; q < c4n; q += LPP) {
-            const float4 v = ld4(row + q * 4);
-            const int c = q * 4;
-            s += lov_g(grow, thr_s, v.x, l, t, c) * expf(v.x - l);
-            if (c + 1 < C) s += lov_g(grow, thr_s, v.y, l, t, c + 1) * expf(v.y - l);
-            if (c + 2 < C) s += lov_g(grow, thr_s, v.z, l, t, c + 2) * expf(v.z - l);
-            if (c + 3 < C) s += lov_g(grow, thr_s, v.w, l, t, c + 3) * expf(v.w - l);
+#pragma unroll
+        for (int k = 0; k < trips; ++k) {
+            const int q = g + 8 * k, c = q * 4;
+            const float4 v = R.get(row, k, q);
+            float4 p = zero4();
+            if (c < C) { p.x = lov_p(v.x, l); s += lov_g(grow, thr_s, p.x, t, c) * p.x; }
+            if (c + 1 < C) { p.y = lov_p(v.y, l); s += lov_g(grow, thr_s, p.y, t, c + 1) * p.y; }
+            if (c + 2 < C) { p.z = lov_p(v.z, l); s += lov_g(grow, thr_s, p.z, t, c + 2) * p.z; }
+            if (c + 3 < C) { p.w = lov_p(v.w, l); s += lov_g(grow, thr_s, p.w, t, c + 3) * p.w; }
+            if (KQ > 0) R.v[k] = p;
         }
         s = grp_sum8(s);
-        for (int q = g; q < c4n; q += LPP) {
-            const float4 v = ld4(row + q * 4);
-            const int c = q * 4;
-            float4 d;
-            d.x = gs * expf(v.x - l) * (lov_g(grow, thr_s, v.x, l, t, c) - s);
-            d.y = c + 1 < C ? gs * expf(v.y - l) * (lov_g(grow, thr_s, v.y, l, t, c + 1) - s) : 0.f;
-            d.z = c + 2 < C ? gs * expf(v.z - l) * (lov_g(grow, thr_s, v.z, l, t, c + 2) - s) : 0.f;
-            d.w = c + 3 < C ? gs * expf(v.w - l) * (lov_g(grow, thr_s, v.w, l, t, c + 3) - s) : 0.f;
+        // sweep 2: dz_c = gs * p_c * (G_c - s)
+#pragma unroll
+        for (int k = 0; k < trips; ++k) {
+            const int q = g + 8 * k, c = q * 4;
+            if (q >= c4n) continue;
+            float4 p;
+            if (KQ > 0) p = R.v[k];
+            else {
+                const float4 v = ld4(row + q * 4);
+                p = make_float4(lov_p(v.x, l), lov_p(v.y, l), lov_p(v.z, l), lov_p(v.w, l));
+            }
+            float4 d = zero4();
+            d.x = gs * p.x * (lov_g(grow, thr_s, p.x, t, c) - s);
+            if (c + 1 < C) d.y = gs * p.y * (lov_g(grow, thr_s, p.y, t, c + 1) - s);
+            if (c + 2 < C) d.z = gs * p.z * (lov_g(grow, thr_s, p.z, t, c + 2) - s);
+            if (c + 3 < C) d.w = gs * p.w * (lov_g(grow, thr_s, p.w, t, c + 3) - s);
             st4(drow + q * 4, d);
         }
     }
 }
+
+// KQ of a class count: float4 groups per lane when the row fits 8 per lane (C <= 256), else 0 (groups re-read per sweep)
+int lov_kq(int C) {
+    const int c4n = (C + 3) >> 2;
+    return c4n <= 64 ? (c4n + 7) / 8 : 0;
+}
+#define LOV_DISPATCH(KQV, CALL)                                                                                       \
+    switch (KQV) {                                                                                                    \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;               \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;               \
+        default: CALL(0); break;                                                                                      \
+    }
 
 struct LovaszLayout {
     size_t keys_a, keys_b, chunk_fg, counts, thr, nkept, part, cnt, temp, total;
@@ -753,14 +817,24 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     hipMemsetAsync(thr, 0xFF, (size_t)C * 4, st);
     long pb = (rows + 31) / 32;
     if (pb > SEGMI_MAX_GRID) pb = SEGMI_MAX_GRID;
-    hipLaunchKernelGGL(lovasz_prepare_kernel, dim3((unsigned)pb), dim3(256), (size_t)(2 * C + 1) * 4, st, logits, ld, target, rows, C,
-                       ignore_index, lse, counts, thr);
+    const int kq = lov_kq(C);
     const unsigned ublocks = (unsigned)((L.nunits + 3) / 4);
-    hipLaunchKernelGGL(lovasz_keep_count_kernel, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C,
-                       ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt);
+#define LOV_PREPARE(K) hipLaunchKernelGGL(lovasz_prepare_kernel<K>, dim3((unsigned)pb), dim3(256), (size_t)(2 * C + 1) * 4, st, logits, ld, target, rows, C, \
+                                          ignore_index, lse, counts, thr)
+#define LOV_COUNT(K) hipLaunchKernelGGL(lovasz_keep_count_kernel<K>, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, \
+                                        rows, C, ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt)
+#define LOV_EMIT(K) hipLaunchKernelGGL(lovasz_emit_kernel<K>, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C, \
+                                       ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka)
+    // measured at C = 150 (profiles/r05_lovasz_alone_kernel_stats*.csv): prepare<5> 267 us against 384 us for the re-reading form;
+    // count<5> 255 against 258 (no gain); emit<5> 667 against 410 (the unrolled ballot groups need 212 VGPRs: 2 waves per SIMD) —
+    // the selection passes stay on the re-reading form
+    LOV_DISPATCH(kq, LOV_PREPARE)
+    LOV_COUNT(0);
     hipLaunchKernelGGL(lovasz_keep_scan_kernel, dim3((unsigned)C), dim3(KS_T), 0, st, cnt, L.nunits, nkept);
-    hipLaunchKernelGGL(lovasz_emit_kernel, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C,
-                       ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka);
+    LOV_EMIT(0);
+#undef LOV_PREPARE
+#undef LOV_COUNT
+#undef LOV_EMIT
     const bool fused_fg = L.nchunks <= SEG_FG_LDS;         // chunk fg counts come out of the last scatter pass
     // four stable 8-bit passes over the 31-bit field [invalid | ~error] above the fg bit: ka -> kb -> ka -> kb -> ka
     unsigned* hist = (unsigned*)(ws + L.temp);
@@ -795,8 +869,12 @@ int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ig
     if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     long b = (rows + 31) / 32;
     if (b > 4 * SEGMI_MAX_GRID) b = 4 * SEGMI_MAX_GRID;
-    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3((unsigned)b), dim3(256), (size_t)C * 4, (hipStream_t)stream, logits, ld, target, ignore_index,
-                       lse, G, ldg, rows, C, loss_out, grad_out, dlogits, lddl);
+#define LOV_BWD(K) hipLaunchKernelGGL(lovasz_bwd_kernel<K>, dim3((unsigned)b), dim3(256), (size_t)C * 4, (hipStream_t)stream, logits, ld, target, ignore_index, \
+                                      lse, G, ldg, rows, C, loss_out, grad_out, dlogits, lddl)
+    // the re-reading form: with the row (and its probabilities) held in registers the kernel needs 131 VGPRs at C = 150 and ran
+    // 1018 us against 794 us (profiles/r05_lovasz_alone_kernel_stats_rowregs{1,0}.csv)
+    LOV_BWD(0);
+#undef LOV_BWD
     return segmi_launch_status();
 }
 
