@@ -124,17 +124,19 @@ FIXTURE_BATCH = {"cfg2": 8, "cfg3": 16, "cfg4": 4, "cfg5": 8}
 def audit_line(r, algo):
     from segmi import ops
     note = " [backbone oracle unpinned (torchvision ResNet-v1.5 restated, oracle/tv_resnet.py)]" if r["config"] == "cfg3" else ""
-    return ("[fullsize %s batch %d, conv math %s, %s]" + note + " pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
+    head = "[fullsize %s batch %d, conv math %s, %s]" % (r["config"], r["batch"], ops.get_conv_math(), algo)
+    body = ("pixels %d | argmax mismatches %d | max margin among mismatches %.3e | max|dlogit| %.3e "
             "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
             "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s) | "
             "grad-sample rel-L2 from the reference fp32 median %.2e max %.2e (%s) | from the fp64 oracle: HIP median %.2e max %.2e (%s), "
             "reference fp32 median %.2e max %.2e"
-            % (r["config"], r["batch"], ops.get_conv_math(), algo, r["pixels"], r["mismatches"], r["max_margin_among_mismatches"],
+            % (r["pixels"], r["mismatches"], r["max_margin_among_mismatches"],
                r["max_abs_dlogit"], r["logit_absmax"], r["hip_err_f64"], r["ref_err_f64"], r["mismatches_outside_margin"],
                r["near_ties_in_oracle(margin<2d)"], r["loss"], r["loss_ref"], r["grad_norm_rel_err_median"], r["grad_norm_rel_err_max"],
                r["grad_norm_worst"], r["grad_sample_rel_err_median"], r["grad_sample_rel_err_max"], r["grad_sample_worst"],
                r["grad_f64_rel_err_median"], r["grad_f64_rel_err_max"], r["grad_f64_worst"], r["ref_grad_f64_rel_err_median"],
                r["ref_grad_f64_rel_err_max"]))
+    return head + note + " " + body
 
 
 def record_audit(r, algo):
