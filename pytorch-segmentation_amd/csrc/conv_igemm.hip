@@ -1514,13 +1514,28 @@ unsigned span32(long elems) {
     return (b > 0 && b < 0xFFFFFF00L) ? (unsigned)b : 0u;
 }
 
-// Small problems (fewer 128-row tiles than the 512 workgroups the chip holds) run with 64-row tiles: twice the
-// workgroups, three resident per CU (48 KB LDS each) — e.g. Xception's 728->728 1x1 on 32x32 maps: 384 -> 768 tiles.
-bool dma_half_m(int M, int Cd) {
+// 64-row tiles (twice the workgroups, three resident per CU at 48 KB of LDS each) instead of 128-row tiles:
+//   * small problems — fewer 128-row tiles than the 512 workgroups the chip holds (Xception's 728->728 1x1 on 32x32 maps:
+//     384 -> 768 tiles);
+//   * round 5, wave quantisation: when the LAST per-CU round of the 128-row tiling is less than half full (tiles mod 256 in
+//     (0, 128]).  A CU works its resident tiles off at a roughly constant aggregate rate, so a launch costs ceil-ish(tiles / 256)
+//     tile times; with 1096 tiles (DeepLab-R101's 256->1024 1x1 on 16 x 33x33 maps) the fifth round runs 72 tiles on 256 CUs.
+//     Halving the tile halves the cost of that round.  Measured per layer in one call (profiles/r05_half_m_layers.txt):
+//     33x33 C256->K1024 89.8 -> 95.1 TF/s, C512->K2048 dgrad 91.1 -> 107.6, 65x65 C128->K512 dgrad 77.0 -> 90.9; where the last
+//     round is full or more than half full the 64-row kernel is 1.5-3 % slower (less filter reuse per LDS byte) and 128 rows stay.
+// SEGMI_CONV_HALF_M: 0 never, 1 always (where the kernel exists), 3 the round-4 rule (small problems only); unset = both rules.
+int g_half_m = -2;
+bool dma_half_m(int M, int Cd, int batch = 1) {      // batch: the 16 contractions of a Winograd pass share one launch
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
-    if (bn == 32) return false;
-    const long tiles = (long)segmi_cdiv(M, 128) * segmi_cdiv(Cd, bn);
-    return tiles < 2L * SEGMI_NUM_CU && M > 64;
+    if (bn == 32 || M <= 64) return false;
+    if (g_half_m == -2) { const char* e = getenv("SEGMI_CONV_HALF_M"); g_half_m = (e && *e) ? atoi(e) : -1; }
+    if (g_half_m == 0) return false;
+    if (g_half_m == 1) return true;
+    const long tiles = (long)segmi_cdiv(M, 128) * segmi_cdiv(Cd, bn) * (batch > 1 ? batch : 1);
+    if (g_half_m == 3) return batch > 1 ? false : tiles < 2L * SEGMI_NUM_CU;       // round 4: batched launches always took 128-row tiles
+    if (tiles < 2L * SEGMI_NUM_CU) return true;
+    const long rem = tiles % SEGMI_NUM_CU;
+    return rem > 0 && rem <= SEGMI_NUM_CU / 2;
 }
 
 template <int MODE>
@@ -1529,7 +1544,7 @@ int dispatch_gather(GatherParams& p, hipStream_t st) {
     unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
     if (p.wplanes) wb = 3u * p.plane_bytes;                                    // three bf16 planes (presplit_ok bounded them)
     if (conv_dma() && sb && wb) {
-        const bool half_m = p.batch > 1 ? false : dma_half_m(p.M, p.Cd);   // a batched launch has batch x the tiles: full 128-row tiles
+        const bool half_m = dma_half_m(p.M, p.Cd, p.batch);              // (a batched launch has batch x the tiles)
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
         if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
         return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, st);
@@ -1963,8 +1978,8 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
 
 int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
     if (!buf || len < 64) return SEGMI_ERR_BADARG;
-    const int bm = 128, bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);           // batched launches always take 128-row tiles
-    (void)M;
+    const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+    const int bm = dma_half_m(M, Cd, 16) ? 64 : 128;                         // the 16 batched contractions of a Winograd pass
     snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %d>", bm, bn, bn == 32 ? "4, 1" : "2, 2", conv_math());
     return SEGMI_OK;
 }
