@@ -167,6 +167,9 @@ size_t segmi_filter_presplit_bytes(long n);
 int segmi_filter_presplit(const float* w, long n, void* planes, segmi_stream_t stream);
 int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
                               int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+/* ... with the BN-statistics epilogue of segmi_conv2d_fwd_stats (same partial layout and count: segmi_conv2d_fwd_stats_parts) */
+int segmi_conv2d_fwd_presplit_stats(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
+                                    float* stats_partials, segmi_stream_t stream);
 int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
                                 segmi_stream_t stream);
 int segmi_conv_set_math(int math);

@@ -1837,6 +1837,12 @@ int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const vo
     return conv_fwd_impl(d, x, nullptr, w_planes, bias, y, accumulate, workspace, workspace_bytes, stream);
 }
 
+int segmi_conv2d_fwd_presplit_stats(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
+                                    float* stats_partials, segmi_stream_t stream) {
+    if (!w_planes || !stats_partials || !segmi_conv2d_presplit_ok(d, 0)) return SEGMI_ERR_BADARG;
+    return conv_fwd_impl(d, x, nullptr, w_planes, bias, y, 0, nullptr, 0, stream, stats_partials);
+}
+
 int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
                                 segmi_stream_t stream) {
     if (!w_crsk_planes || !segmi_conv2d_presplit_ok(d, 1)) return SEGMI_ERR_BADARG;

@@ -65,6 +65,7 @@ SIGNATURES = {
     "segmi_filter_presplit_bytes": (sz, [i64]),
     "segmi_filter_presplit": (i32, [vp, i64, vp, vp]),
     "segmi_conv2d_fwd_presplit": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "segmi_conv2d_fwd_presplit_stats": (i32, [PD, vp, vp, vp, vp, vp, vp]),
     "segmi_conv2d_dgrad_presplit": (i32, [PD, vp, vp, vp, i32, vp]),
     "segmi_conv_set_math": (i32, [i32]),
     "segmi_conv_get_math": (i32, []),

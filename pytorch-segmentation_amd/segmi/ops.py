@@ -419,12 +419,15 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
         return v
     bp = bias.data_ptr() if bias is not None else None
     pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
-    if bn_stats and not accumulate and pre is None:
+    if bn_stats and not accumulate:
         parts = lib.segmi_conv2d_fwd_stats_parts(d)
         if parts > 0:
             part = torch.empty(parts * 3 * d.K, device=dev, dtype=torch.float32)
             with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-                check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
+                if pre is not None:     # bf16x3 with pre-split filter planes: the same epilogue
+                    check(lib.segmi_conv2d_fwd_presplit_stats(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
+                else:
+                    check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
             _BN_FUSE["last"] = (part, parts)
             _BN_FUSE["emitted"] += 1
             return None
