@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-cap", type=float, default=240.0, help="seconds of host time the cpu_baseline leg may spend (after its warm-up step)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
     ap.add_argument("--no-alt", action="store_true", help="skip the `alt` leg (same steps with the convolutions on the bf16x3 arithmetic)")
     ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
@@ -452,7 +453,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.config)
+        cpu = cpu_baseline(args.config, seconds_cap=args.cpu_cap)
 
     if rank == 0:
         line = {

@@ -184,6 +184,39 @@ r3final)
   ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -20 ) > gpurun_out/r3f_stray_aten.txt
   for c in cfg1 cfg3 cfg4 cfg5; do ( timeout 400 python bench.py --config $c --no-cpu --no-roofline --no-alt 2>&1 | tail -1 ) > gpurun_out/r3f_bench_$c.log; python -c "import json; d=json.loads(open('gpurun_out/r3f_bench_$c.log').read()); print('$c', d['value'], d['ms_per_step'])" 2>&1 | tail -1; done
   bash tools/gpu_round.sh pk2 ;;
+r5final)
+  # round 5, evidence run of the final tree (the whole suite runs in its own call): full bench line, rocprof stats (default and
+  # in order), PMC traffic, per-layer / per-call tables, every other BASELINE config WITH its cpu_baseline and roofline
+  ( timeout 900 python bench.py 2>&1 | tail -1 ) > gpurun_out/r5f_bench_cfg2.json
+  python -c "import json; d=json.loads(open('gpurun_out/r5f_bench_cfg2.json').read()); r=d['roofline']; print('bench', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['executed_step_frac'], d['cpu_baseline']['value'], [d[k]['value'] for k in ('alt','alt_direct') if d.get(k)])" 2>&1 | tail -1
+  for mode in default inorder; do
+    rm -rf gpurun_out/prof
+    ( cd /tmp; SEGMI_WGRAD_STREAM=$([ $mode = inorder ] && echo 0 || echo 1) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+    find gpurun_out/prof -name "*kernel_trace*" -delete
+    f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r5f_cfg2_kernel_stats_f32_$mode.csv
+  done
+  head -4 gpurun_out/r5f_cfg2_kernel_stats_f32_inorder.csv | cut -c1-200
+  rm -rf gpurun_out/pmc_f32
+  ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_f32/fetch -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/pmc_f32.log
+  ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_f32/write -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) >> gpurun_out/pmc_f32.log
+  for d in fetch write; do f=$(find gpurun_out/pmc_f32/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/pmc_f32/$d/r_counter_collection.csv 2>/dev/null; done
+  python tools/traffic_json.py gpurun_out/pmc_f32 gpurun_out/r5f_cfg2_conv_traffic_f32.json
+  find gpurun_out/pmc_f32 -name "*kernel_trace*" -delete; find gpurun_out/pmc_f32 -name "*.csv" -size +8M -delete
+  ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r5f_cfg2_conv_layers.txt; tail -1 gpurun_out/r5f_cfg2_conv_layers.txt
+  for c in cfg2 cfg5 cfg3 cfg1; do ( timeout 300 python tools/membound_ops.py $c 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r5f_${c}_membound_ops.txt; tail -2 gpurun_out/r5f_${c}_membound_ops.txt; done
+  ( timeout 300 python tools/stray_aten.py 2>&1 | grep -v amdgpu.ids | tail -20 ) > gpurun_out/r5f_cfg2_stray_aten.txt
+  for c in cfg1 cfg3 cfg4 cfg5; do
+    ( timeout 600 python bench.py --config $c --no-alt --cpu-cap 110 2>&1 | tail -1 ) > gpurun_out/r5f_bench_$c.json
+    python -c "import json; d=json.loads(open('gpurun_out/r5f_bench_$c.json').read()); print('$c', d['value'], d['ms_per_step'], d['roofline']['executed_step_frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])" 2>&1 | tail -1
+  done
+  python tools/top_kernels.py gpurun_out/r5f_bench_cfg1.json gpurun_out/r5f_bench_cfg3.json gpurun_out/r5f_bench_cfg4.json gpurun_out/r5f_bench_cfg5.json gpurun_out/r5f_bench_cfg2.json > gpurun_out/r5f_top_kernels.txt
+  for c in cfg5 cfg3; do
+    rm -rf gpurun_out/prof
+    ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+    find gpurun_out/prof -name "*kernel_trace*" -delete
+    f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r5f_${c}_kernel_stats.csv
+  done
+  ( timeout 300 python tools/lovasz_bench.py --iters 5 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r5f_lovasz_alone_bench.txt; cat gpurun_out/r5f_lovasz_alone_bench.txt ;;
 r3g)
   # round 3, call 5: in-order rocprof stats (agreement with bench.py's instrumented step), packed-fp32 cross experiment, new tests,
   # whole suite under bf16x3 at HEAD
