@@ -274,23 +274,22 @@ __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __r
                     }
             }
         }
-    __shared__ float4 sm[256];
+    // block reduction over the thread rows: all nine taps go to LDS at once (36 KB), ONE barrier, then thread (tx, ty) adds the rows
+    // of taps ty, ty + ry, ... in a fixed order (round 4: a barrier tree per tap, 36 barriers per block for 2 strips of work per thread)
+    __shared__ float4 sm[9][256];
     const int tix = threadIdx.y * blockDim.x + threadIdx.x;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        sm[tix] = acc[t];
-        __syncthreads();
-        for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
-            if ((int)threadIdx.y < s) {
-                float4 a = sm[tix], b = sm[tix + s * blockDim.x];
+    for (int t = 0; t < 9; ++t) sm[t][tix] = acc[t];
+    __syncthreads();
+    if (cok)
+        for (int t = threadIdx.y; t < 9; t += blockDim.y) {
+            float4 a = sm[t][threadIdx.x];
+            for (int r = 1; r < (int)blockDim.y; ++r) {
+                const float4 b = sm[t][r * blockDim.x + threadIdx.x];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                sm[tix] = a;
             }
-            __syncthreads();
+            st4(part + ((long)blockIdx.y * 9 + t) * C + c4 * 4, a);
         }
-        if (threadIdx.y == 0 && cok) st4(part + ((long)blockIdx.y * 9 + t) * C + c4 * 4, sm[tix]);
-        __syncthreads();
-    }
 }
 
 // out[i] = sum_p part[p][i]; block = (32 elements, 8 part lanes)

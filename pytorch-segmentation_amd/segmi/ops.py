@@ -869,6 +869,9 @@ def conv2d_fan(x, branches):
 
 
 # --------------------------------------------------------------------------- depthwise convolution
+_DW_WGRAD_SIDE = os.environ.get("SEGMI_DW_WGRAD_STREAM", "1") == "1"      # A/B hook: 0 keeps the depthwise filter gradients in order
+
+
 def dw_filter_rsc_layout(w):
     """The depthwise filter [C, 1, R, S] re-laid over [R, S, C] memory (same logical tensor): what segmi.nn.Conv2d stores."""
     C, one, R, S = w.shape
@@ -915,13 +918,13 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
             _BN_FUSE["emitted"] += 1
         else:
             check(lib.segmi_dwconv2d_fwd(d, x.data_ptr(), wrsc.data_ptr(), y.data_ptr(), st), "dwconv2d_fwd")
-        ctx.save_for_backward(x, wrsc)
+        ctx.save_for_backward(x, wrsc, weight)
         ctx.geom = (N, C, H, W, R, S, P, Q, stride, pad, dil)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wrsc = ctx.saved_tensors
+        x, wrsc, weight = ctx.saved_tensors
         N, C, H, W, R, S, P, Q, stride, pad, dil = ctx.geom
         dy = to_nhwc(dy, "depthwise_conv2d.backward")
         st = _stream()
@@ -932,13 +935,24 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
             check(lib.segmi_dwconv2d_dgrad(d, dy.data_ptr(), wrsc.data_ptr(), dx.data_ptr(), st), "dwconv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
-            nws = lib.segmi_dwconv2d_wgrad_workspace(d)
-            ws = workspace(nws, x.device)
             dwr = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
-            check(lib.segmi_dwconv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, st), "dwconv2d_wgrad")
-            if ctx.rsc_param:     # the parameter's own memory order: the gradient is a view of what the kernel wrote
+
+            def run_wgrad():
+                nws = lib.segmi_dwconv2d_wgrad_workspace(d)
+                ws = workspace(nws, x.device)             # (keyed by the stream the call runs on)
+                check(lib.segmi_dwconv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, _stream()), "dwconv2d_wgrad")
+
+            if ctx.rsc_param:
+                # the parameter's own memory order: the gradient is a view of what the kernel wrote, and — like the dense filter
+                # gradients — nothing in the backward pass reads it: the two launches (partials + their sum) go to the
+                # filter-gradient side stream when that is safe (round 5: 63 x ~43 us per DeepLab-Xception step off the compute stream)
+                if _DW_WGRAD_SIDE:
+                    _on_wgrad_stream(weight, (x, dy, dwr), run_wgrad)
+                else:
+                    run_wgrad()
                 dw = dwr.view(R, S, C).permute(2, 0, 1).unsqueeze(1)
             else:
+                run_wgrad()
                 dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
                 check(lib.segmi_nhwc_to_nchw(dwr.data_ptr(), dw.data_ptr(), 1, C, R * S, 1, C, st), "dw filter rsc->crs")
         return dx, dw, None, None, None, None
