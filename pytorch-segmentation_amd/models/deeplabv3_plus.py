@@ -187,6 +187,8 @@ class SeparableConv2d(nn.Module):
 
 
 class Block(nn.Module):
+    fused_tail = os.environ.get("SEGMI_XCEPTION_FUSED_TAIL", "1") == "1"     # `+ skip` (+ the consumer's ReLU) inside the last BatchNorm's pass
+
     def __init__(self, in_channels, out_channels, stride=1, dilation=1, exit_flow=False, use_1st_relu=True):
         super().__init__()
         if in_channels != out_channels or stride != 1:
@@ -206,14 +208,23 @@ class Block(nn.Module):
             rep = rep[1:]
         self.rep = snn.Sequential(*rep)   # same child indices (-> checkpoint keys) as the reference's nn.Sequential
 
-    def forward(self, x):
+    def forward(self, x, relu_in=True, relu_out=False):
+        """relu_in=False: the producer of x already applied this block's first (in-place, hence idempotent) ReLU; relu_out=True: the
+        consumer is a Block whose first ReLU is in place — the reference then only ever sees relu(rep(x) + skip)
+        (models/deeplabv3_plus.py:121-132, :210-220), so this block's last BatchNorm applies `+ skip` and that ReLU in its own pass
+        (the fused apply(+residual)(+ReLU) kernel of the ResNet blocks): no stand-alone add / ReLU kernels and no stand-alone ReLU
+        backward between the 20 Xception blocks (round 5).  Same arithmetic in the same order: bit-identical."""
         mods = list(self.rep)
         if self.use_1st_relu:
-            x = ops.relu(x)               # the reference's in-place ReLU: the skip branch sees relu(x) too
+            if relu_in:
+                x = ops.relu(x)           # the reference's in-place ReLU: the skip branch sees relu(x) too
             mods = mods[1:]
-        output = snn.run_fused(mods, x)
         skip = x if self.skip is None else self.skipbn(self.skip(x))
-        return ops.add(output, skip)
+        if not Block.fused_tail:              # A/B and tests: the literal form (stand-alone add, then the consumer's ReLU here)
+            out = ops.add(snn.run_fused(mods, x), skip)
+            return ops.relu(out) if relu_out else out
+        output = snn.run_fused(mods[:-1], x)
+        return mods[-1](output, residual=skip, relu=relu_out)      # rep's last module is its BatchNorm2d
 
 
 class Xception(nn.Module):
@@ -250,12 +261,13 @@ class Xception(nn.Module):
         x = self.bn1(self.conv1(x), relu=True)
         x = self.bn2(self.conv2(x))                 # no ReLU here in the reference (:205-207)
         x = self.block1(x)
-        low_level_features = x
+        low_level_features = x                      # (pre-ReLU, :211-213 of the reference)
         x = ops.relu(x)
-        x = self.block3(self.block2(x))
+        # every later block starts with an in-place ReLU on its input: the producing block's last BatchNorm applies it (Block.forward)
+        x = self.block3(self.block2(x, relu_in=False, relu_out=True), relu_in=False, relu_out=True)
         for i in range(4, 20):
-            x = getattr(self, "block%d" % i)(x)
-        x = ops.relu(self.block20(x))
+            x = getattr(self, "block%d" % i)(x, relu_in=False, relu_out=True)
+        x = self.block20(x, relu_in=False, relu_out=True)           # + the F.relu that follows block20 (:223-224)
         x = self.bn3(self.conv3(x), relu=True)
         x = self.bn4(self.conv4(x), relu=True)
         x = self.bn5(self.conv5(x), relu=True)

@@ -140,3 +140,38 @@ def test_deeplab_factored_and_literal_decoder_agree(cuda, monkeypatch):
     for k in g0:
         e = (g0[k] - g1[k]).norm().item() / (g0[k].norm().item() + 1e-30)
         assert e <= 1e-3, (k, e)
+
+
+@pytest.mark.parametrize("freeze", [False, True])
+def test_xception_block_tail_fused_into_the_last_batchnorm_is_bit_identical(cuda, monkeypatch, freeze):
+    """Round 5: the 20 Xception blocks end with `rep(x) + skip`, and every following block starts with an in-place ReLU
+    (models/deeplabv3_plus.py:121-132, :210-224 of the reference).  The drop-in lets the block's last BatchNorm apply `+ skip` and that
+    ReLU in its own pass (the fused apply(+residual)(+ReLU) kernel of the ResNet blocks) instead of stand-alone add / ReLU kernels:
+    same arithmetic in the same order — logits, loss and EVERY parameter gradient equal the literal form bit for bit, with batch
+    statistics and with frozen BatchNorm."""
+    import models
+    from models.deeplabv3_plus import Block
+    from utils.losses import CrossEntropyLoss2d
+    classes = 7
+    tmpl = models.DeepLab(classes, backbone="xception", pretrained=False, output_stride=16, freeze_bn=freeze)
+    sd = synth_state_dict([(k, tuple(v.shape)) for k, v in tmpl.state_dict().items()], seed=9)
+    x, t = synth_batch(2, 3, 96, 128, classes, seed=21)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(Block, "fused_tail", fused)
+        m = models.DeepLab(classes, backbone="xception", pretrained=False, output_stride=16, freeze_bn=freeze)
+        m.load_state_dict(sd)
+        m.to(cuda).train()
+        if freeze:
+            m.freeze_bn()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        out = m(x.to(cuda))
+        loss = CrossEntropyLoss2d(ignore_index=255)(out, t.to(cuda))
+        loss.backward()
+        res[fused] = (out.detach().clone(), loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    (o0, l0, g0), (o1, l1, g1) = res[False], res[True]
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max().item())
