@@ -217,6 +217,30 @@ r5final)
     f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r5f_${c}_kernel_stats.csv
   done
   ( timeout 300 python tools/lovasz_bench.py --iters 5 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r5f_lovasz_alone_bench.txt; cat gpurun_out/r5f_lovasz_alone_bench.txt ;;
+r5last)
+  # round 5, last call on the final tree: whole suite + smoke, cfg5 evidence refreshed (depthwise filter gradients on the side stream,
+  # Xception block tails), HBM traffic of the Lovasz kernels (PMC, separate passes)
+  ( timeout 1150 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider 2>&1 | tail -28 ) > gpurun_out/r5l_gpu_suite.txt; tail -4 gpurun_out/r5l_gpu_suite.txt
+  cp gpurun_out/audit.json gpurun_out/r5l_fullsize_audit.json 2>/dev/null
+  ( timeout 300 python __graft_entry__.py smoke 2>&1 | grep graft | cut -c1-400 ) > gpurun_out/r5l_smoke.txt; cut -c1-160 gpurun_out/r5l_smoke.txt
+  ( timeout 600 python bench.py --config cfg5 --no-alt --cpu-cap 150 2>&1 | tail -1 ) > gpurun_out/r5l_bench_cfg5.json
+  python -c "import json; d=json.loads(open('gpurun_out/r5l_bench_cfg5.json').read()); print('cfg5', d['value'], d['ms_per_step'], d['roofline']['executed_step_frac'], d['roofline']['hbm_bound_calls']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])" 2>&1 | tail -1
+  ( timeout 300 python tools/membound_ops.py cfg5 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r5l_cfg5_membound_ops.txt; tail -2 gpurun_out/r5l_cfg5_membound_ops.txt
+  rm -rf gpurun_out/prof
+  ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --config cfg5 --steps 5 --warmup 2 --no-cpu --no-roofline --no-alt 2>&1 | tail -2 ) > gpurun_out/prof.log
+  find gpurun_out/prof -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r5l_cfg5_kernel_stats.csv
+  ( timeout 300 python bench.py --no-cpu --no-alt --no-roofline 2>&1 | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('cfg2', j['value'], j['ms_per_step'])" )
+  rm -rf gpurun_out/lpmc
+  for pc in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --pmc $pc --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/lpmc/$pc -o r -- python $GRAFT_REPO_ROOT/tools/lovasz_bench.py --iters 2 --modes random --prune 1 2>&1 | tail -1 ) > /dev/null
+    f=$(find gpurun_out/lpmc/$pc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/lpmc/$pc/r_counter_collection.csv
+    f=$(find gpurun_out/lpmc/$pc -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/lpmc/$pc/r_kernel_trace.csv
+    echo "== $pc (KB per launch; FETCH_SIZE under-counts 16 B/lane streaming reads 2x on gfx950: MI355X_MICROARCH.md)" >> gpurun_out/r5l_lovasz_traffic.txt
+    python tools/pmc_summary.py gpurun_out/lpmc/$pc r lovasz segsort >> gpurun_out/r5l_lovasz_traffic.txt 2>&1
+  done
+  find gpurun_out/lpmc -name "*.csv" -size +4M -delete
+  tail -30 gpurun_out/r5l_lovasz_traffic.txt ;;
 r3g)
   # round 3, call 5: in-order rocprof stats (agreement with bench.py's instrumented step), packed-fp32 cross experiment, new tests,
   # whole suite under bf16x3 at HEAD
