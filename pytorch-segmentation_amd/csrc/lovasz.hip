@@ -869,6 +869,9 @@ int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ig
     if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3) || (lddl & 3) || lddl < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     long b = (rows + 31) / 32;
     if (b > 4 * SEGMI_MAX_GRID) b = 4 * SEGMI_MAX_GRID;
+    // (The kernel sweeps a pixel's row twice and the second sweep misses the L2 — PMC: 2.5x the logits fetched,
+    //  profiles/r05_lovasz_traffic.txt — but capping the residency with dummy LDS so that it hits made the kernel SLOWER: 806 us at 8
+    //  workgroups per CU, 852 / 1031 / 1155 / 1864 us with 20 / 30 / 40 / 60 KB of padding: it is latency-bound, not bandwidth-bound.)
 #define LOV_BWD(K) hipLaunchKernelGGL(lovasz_bwd_kernel<K>, dim3((unsigned)b), dim3(256), (size_t)C * 4, (hipStream_t)stream, logits, ld, target, ignore_index, \
                                       lse, G, ldg, rows, C, loss_out, grad_out, dlogits, lddl)
     // the re-reading form: with the row (and its probabilities) held in registers the kernel needs 131 VGPRs at C = 150 and ran
