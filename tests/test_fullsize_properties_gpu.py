@@ -112,6 +112,38 @@ def test_lovasz_properties_at_full_size(cuda):
     assert abs(crit(xp, tp).item() - loss.item()) < 1e-5
 
 
+@pytest.mark.parametrize("boost", [0.0, 5.0])
+def test_lovasz_tail_pruning_equals_the_full_sort_at_full_size(cuda, boost):
+    """2 M pixels x 19 classes: class segments of up to 2 M keys — 512 sort tiles and 1024 scan chunks per class, walked by capped
+    grids (64 workgroups per class and pass; 128 for the Jaccard pass) — pruned and full sort agree BIT FOR BIT in loss and gradient,
+    on random-init-like and on confident logits (more survivors)."""
+    import utils.losses as L
+    from segmi import lib, ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    N, C, H, W = 8, 19, 512, 512
+    x = torch.randn(N, C, H, W, device=cuda, generator=g) * 2
+    t = torch.randint(0, C - 2, (N, H, W), device=cuda, generator=g)
+    t[:, :9, :] = 255
+    if boost:
+        hit = (torch.rand(N, H, W, device=cuda, generator=g) < 0.8) & (t != 255)
+        x.scatter_add_(1, t.clamp(0, C - 1).unsqueeze(1), hit.float().unsqueeze(1) * boost)
+    crit = L.LovaszSoftmax(ignore_index=255)
+    res = []
+    try:
+        for prune in (1, 0):
+            assert lib.segmi_lovasz_set_prune(prune) == 0
+            xd = x.detach().clone().requires_grad_(True)
+            loss = crit(xd, t)
+            (dl,) = torch.autograd.grad(loss, xd)
+            res.append((loss.detach().clone(), dl, ops.lovasz_last_stats()))
+    finally:
+        lib.segmi_lovasz_set_prune(1)
+    (l1, d1, (k1, f1)), (l0, d0, (k0, f0)) = res
+    assert torch.equal(l1, l0) and torch.equal(d1, d0), ((l1 - l0).item(), (d1 - d0).abs().max().item())
+    assert k0 == f0 == f1 and k1 < f1 and torch.isfinite(d1).all()
+    print("survivors %d of %d (%.2f %%)" % (k1, f1, 100.0 * k1 / f1))
+
+
 def test_cfg2_training_step_is_bit_reproducible(cuda):
     import models
     from utils.losses import CrossEntropyLoss2d
