@@ -935,7 +935,10 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
             check(lib.segmi_dwconv2d_dgrad(d, dy.data_ptr(), wrsc.data_ptr(), dx.data_ptr(), st), "dwconv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, C, C, R, S, P, Q, stride, pad, dil, ld_of(x), ld_of(dy))
-            dwr = torch.empty(R * S * C, device=x.device, dtype=torch.float32)
+            # under a data-parallel reducer the kernel writes straight into the parameter's slot of the all-reduce bucket (same
+            # tap-major memory order): the reducer's hook then finds the gradient in place — no copy, no join of the side stream
+            slot = _take_grad_slot(weight) if (_GRAD_SLOTS and ctx.rsc_param) else None
+            dwr = slot if slot is not None else torch.empty(R * S * C, device=x.device, dtype=torch.float32)
 
             def run_wgrad():
                 nws = lib.segmi_dwconv2d_wgrad_workspace(d)
@@ -950,7 +953,7 @@ class _DepthwiseConv2dFn(torch.autograd.Function):
                     _on_wgrad_stream(weight, (x, dy, dwr), run_wgrad)
                 else:
                     run_wgrad()
-                dw = dwr.view(R, S, C).permute(2, 0, 1).unsqueeze(1)
+                dw = slot if slot is not None else dwr.view(R, S, C).permute(2, 0, 1).unsqueeze(1)
             else:
                 run_wgrad()
                 dw = torch.empty((C, 1, R, S), device=x.device, dtype=torch.float32)
