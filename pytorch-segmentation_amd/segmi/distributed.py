@@ -102,14 +102,21 @@ class GradAllReducer:
         order = list(reversed(self.params))
         self.buckets = []          # dict(buf, params, pending, launched, work)
         self._where = {}           # id(param) -> (bucket index, view)
-        caps = bucket_schedule(sum(p.numel() * p.element_size() for p in order)) if bucket_bytes is None else None
+        # bucket_schedule's rule applied to the bytes ACTUALLY still to come when a bucket is opened: a tensor larger than its bucket's
+        # capacity (PSPNet's 72 MB bottleneck filter) closes the bucket before it early and travels alone — indexing a precomputed
+        # schedule by bucket number then ran out of large capacities and cut the last 40 MB into ten 4 MB buckets (17 buckets for
+        # PSPNet-R50: 17 collectives + 17 optimizer launches per step; now 9)
+        left = sum(p.numel() * p.element_size() for p in order)
+        cap = bucket_bytes if bucket_bytes is not None else bucket_schedule(left)[0]
         cur, cur_bytes = [], 0
         for p in order:
             nb = p.numel() * p.element_size()
-            cap = bucket_bytes if caps is None else caps[min(len(self.buckets), len(caps) - 1)]
-            if cur and cur_bytes + nb > cap:
+            if cur and cur_bytes + nb > cap and (bucket_bytes is not None or cur_bytes >= (1 << 20)):
+                # (a bucket still below 1 MiB — a few BN vectors — takes the oversized tensor in instead of travelling alone)
                 self._make_bucket(cur)
+                left -= cur_bytes
                 cur, cur_bytes = [], 0
+                cap = bucket_bytes if bucket_bytes is not None else bucket_schedule(left)[0]
             cur.append(p)
             cur_bytes += nb
         if cur:
