@@ -482,10 +482,10 @@ def main():
                        "lovasz": lovasz_stats},
             "roofline": roof, "cpu_baseline": cpu, "alt": alt, ("alt_direct" if wino_default else "alt_winograd"): alt_algo,
         }
-    if ddp:
-        dist.destroy_process_group()
-    # The JSON line is the LAST thing this process writes to stdout: RCCL prints a version banner through C stdio, which sits in the
-    # libc buffer (stdout is a pipe under the driver) until it is flushed — left alone it comes out at exit, AFTER the line.
+    # The JSON line is the LAST thing this process writes to stdout: RCCL prints a version banner through C stdio at communicator
+    # creation, which sits in the libc buffer (stdout is a pipe under the driver) until it is flushed — left alone it comes out at
+    # exit, AFTER the line.  Flushed here, then the line, then the (silent) teardown — a teardown that stalled on some rank must not
+    # cost the result.
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
@@ -494,6 +494,8 @@ def main():
     sys.stderr.flush()
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if ddp:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
