@@ -288,3 +288,28 @@ def test_bucket_schedule_follows_backward_order():
     uni = GradAllReducer(net.parameters(), bucket_bytes=16 * mb)
     assert [b["buf"].numel() * 4 // mb for b in uni.buckets] == [16] * 6
     uni.remove()
+
+
+def test_bucket_layout_with_an_oversized_tensor_keeps_large_buckets():
+    """Round 5 regression: PSPNet-R50's gradients contain one 72 MiB filter (the PSP bottleneck).  It closes the bucket in front of it
+    early and travels alone; the capacities of the FOLLOWING buckets must come from the bytes actually still to come (half of the
+    rest, clamped to [4, 64] MiB) — indexing a precomputed schedule by bucket number cut the last 40 MiB into ten 4 MiB buckets
+    (17 collectives + 17 optimizer launches per step instead of 8).  Also: a bucket of a few small vectors does not travel alone in
+    front of an oversized tensor."""
+    from segmi.distributed import GradAllReducer
+    mb = 1 << 20
+
+    def lin(n_mb):
+        return torch.nn.Linear(1024, n_mb * 256, bias=False)          # n_mb MiB of fp32
+
+    # registration order = forward order; backward produces the gradients in reverse: 18 MiB head, the 72 MiB filter, then 116 MiB of
+    # 4 MiB tensors (the backbone), a tiny BN-like vector right behind a 9 MiB tensor at the very end
+    tiny = torch.nn.BatchNorm1d(64)
+    net = torch.nn.Sequential(lin(9), tiny, *[lin(4) for _ in range(29)], lin(72), *[lin(6) for _ in range(3)])
+    red = GradAllReducer(net.parameters())
+    sizes = [b["buf"].numel() * 4 / mb for b in red.buckets]
+    assert abs(sum(sizes) - (9 + 116 + 72 + 18)) < 0.01
+    assert sizes[0] == 18 and sizes[1] == 72, sizes                   # the oversized tensor alone, the head before it
+    assert len(sizes) <= 9 and min(sizes) >= 1.0, sizes               # no run of 4 MiB buckets, no sliver bucket
+    assert sizes[2] >= 40 and all(a >= b * 0.99 for a, b in zip(sizes[2:], sizes[3:-1])), sizes   # halves of what remains, in backward order
+    red.remove()
