@@ -377,3 +377,32 @@ def test_bn_stats_epilogue_planning():
     assert lib.segmi_conv2d_fwd_stats_parts(d) == 0
     assert lib.segmi_bn_parts_workspace(256, 2048) == 16
     assert lib.segmi_bn_parts_workspace(1024, 256) == 16 * 3 * 256 * 4 + 16
+
+
+def test_depthwise_filters_are_stored_tap_major_behind_the_reference_shape():
+    """Round 5: segmi.nn.Conv2d keeps a depthwise filter as [C,1,R,S] (the reference's state_dict key, shape and values:
+    models/deeplabv3_plus.py:80) over memory in [R,S,C] order — the order the depthwise kernels read — so no per-step re-layout is
+    needed.  Host-side contract, no GPU: load_state_dict / state_dict / deepcopy preserve values and layout, the flat view the
+    kernels receive is the tap-major sequence, and a gradient produced in that order satisfies autograd's layout contract."""
+    import copy
+    from segmi import nn as snn, ops
+    from segmi.optim import _same_layout
+    torch.manual_seed(0)
+    ref = torch.nn.Conv2d(24, 24, 3, padding=2, dilation=2, groups=24, bias=False)
+    m = snn.Conv2d(24, 24, 3, padding=2, dilation=2, groups=24, bias=False)
+    assert m.depthwise and tuple(m.weight.shape) == (24, 1, 3, 3) and m.weight.stride()[0] == 1 and m.weight.stride()[2:] == (3 * 24, 24)
+    m.load_state_dict(ref.state_dict())
+    assert torch.equal(m.weight, ref.weight) and torch.equal(m.state_dict()["weight"], ref.weight)
+    assert m.weight.stride()[2:] == (72, 24)                                  # the copy went into the tap-major memory
+    flat = ops._dw_rsc_view(m.weight.detach())
+    assert flat is not None and flat.data_ptr() == m.weight.data_ptr()
+    assert torch.equal(flat, ref.weight.detach().permute(2, 3, 0, 1).reshape(-1))   # [r][s][c]
+    assert copy.deepcopy(m).weight.stride() == m.weight.stride()
+    # a contiguous [C,1,R,S] filter (a foreign module) is NOT mistaken for the tap-major layout: it takes the re-layout path
+    assert ops._dw_rsc_view(ref.weight.detach()) is None
+    # the gradient the kernel writes ([R*S*C] flat) viewed back as [C,1,R,S]: same element order as the parameter
+    g = torch.arange(216.0).view(3, 3, 24).permute(2, 0, 1).unsqueeze(1)
+    assert _same_layout(g, m.weight) and tuple(g.shape) == tuple(m.weight.shape)
+    # 1x1 "depthwise" (R = S = 1) degenerates gracefully
+    one = snn.Conv2d(8, 8, 1, groups=8, bias=False)
+    assert ops._dw_rsc_view(one.weight.detach()) is not None
