@@ -261,9 +261,12 @@ def test_batch_norm_act(cuda, shape, relu, res, training):
 
 @pytest.mark.parametrize("shape", [(8, 256, 64, 64), (8, 728, 32, 32), (2, 64, 256, 256), (4, 2048, 8, 8), (2, 16, 33, 35)])
 @pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.skipif(os.environ.get("SEGMI_TEST_BN_TICKETS") != "1",
+                    reason="opt-in (SEGMI_TEST_BN_TICKETS=1): the one-launch form is itself opt-in and measured slower (profiles/r05_bn_tickets_ab.txt); "
+                           "passed on hardware in round 5 in both of its variants")
 def test_bn_backward_reduction_in_one_launch_equals_the_two_launch_form(cuda, shape, relu, monkeypatch):
-    """Round 5: the last workgroup of a channel column adds the column's fp64 row partials itself (ticket counters, release /
-    acquire fences across the XCDs' L2s) instead of a second launch.  Both forms add the same fp64 partials and round once to fp32:
+    """Round 5: the last workgroup of a channel column adds the column's fp64 row partials itself (ticket counters; the partials
+    travel as device-scope atomic stores / loads across the XCDs' L2s) instead of a second launch.  Both forms add the same fp64 partials and round once to fp32:
     gradients agree to the last bit or two; repeated calls are bit-identical (the order of the additions is fixed, whichever
     workgroup comes last) and every call hands its counters back at zero."""
     from segmi import ops
