@@ -28,8 +28,10 @@ ToTensor, Normalize) step by step.  The cv2 calls are restated from OpenCV's PUB
       m1 = 256 - 2 m0;  rows t = m0 * (s[x-1] + s[x+1]) + m1 * s[x] (uint16), columns (m0 * (t[y-1] + t[y+1]) + m1 * t[y] + 2^15) >> 16,
       BORDER_REFLECT_101 on both axes.
 
-PARITY UNPINNED: cv2 (opencv-python, unpinned in the reference's requirements.txt) and its source are absent from this image and
-from /root/reference, so the restatement is from the library's published algorithm, not checked against the library here; a
+PARITY: the PIL piece (validation label resize) is PINNED against the installed Pillow 12.2.0 by
+tests/test_augment.py::test_pil_nearest_resize_is_pinned_to_the_installed_pillow (the pin corrected this file: Pillow accumulates the
+source coordinate).  The cv2 pieces are UNPINNED: cv2 (opencv-python, unpinned in the reference's requirements.txt) and its source are
+absent from this image and from /root/reference, so they are restated from the library's published algorithm, not checked against it; a
 build of OpenCV that routes these calls through IPP / OpenCL / a platform HAL may round differently, and softfloat's exp() in
 getGaussianKernelBitExact could differ from numpy's by one ulp (it matters only if k0 * 256 lands within 1e-13 of a half).
 The random decisions are drawn with Python's `random` in the reference's order, so a seeded run takes the same decisions.
