@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — training images/sec of the MI355X-native segmentation hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--no-alt] [--conv-math f32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--no-cpu] [--no-roofline] [--no-alt]
 
 `python bench.py --gpus N` drives all N GPUs by itself (it re-executes under torch.distributed.run, one rank per GPU over
 RCCL); the driver's own form `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` is what
@@ -23,13 +23,13 @@ Rank 0 prints ONE JSON line.  Beyond the driver contract it carries
   cpu_baseline : the oracle (torch-CPU restatement of the reference, oracle/pspnet_ref.py) timed on this host's cores on a
                  bounded sample: the FULL batch of the same workload, one untimed warm-up step, a one-step sweep over
                  {16, 32, 64, all} threads, then >= 3 timed steps at the best count within a 240 s cap (N = 1 only).
-  alt          : the same K steps with the convolutions on the bf16x3 arithmetic (fp32 products as three-plane bf16 splits on
-                 the bf16 matrix pipe), its own roofline object priced against BOTH ceilings.  Never the headline.  N = 1 only.
   alt_direct   : the same K steps in fp32 with Winograd OFF (every layer on the direct implicit-GEMM kernels).  The headline
                  runs the eligible 3x3 stride-1 layers on the Winograd F(2x2,3x3) kernels — the default since the whole GPU
                  suite runs under both algorithms at the same tolerances (tests/conftest.py).  N = 1 only.
 `roofline.achieved/frac` count EXECUTED FLOPs (a Winograd contraction executes 16/36 of the direct convolution's), `effective`
-the direct-convolution FLOPs the launches stand for; `executed_step_frac` / `effective_step_frac` are the same pair for the step.
+the direct-convolution FLOPs the launches stand for; `executed_step_frac` = executed FLOPs of one step / step time / peak.  The
+reference formulation's FLOPs per step time are reported as a RATE (`reference_formulation.tflops_equivalent`), never
+as a fraction of a peak: the step executes fewer FLOPs than the reference formulation has (Winograd, factored PSP bottleneck).
 """
 import argparse
 import json
@@ -49,9 +49,6 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-# --conv-math bf16x3: every fp32 product costs six v_mfma_f32_32x32x16_bf16 plane products (csrc/conv_igemm.hip), so the
-# matrix-pipe ceiling in ALGORITHMIC (fp32) FLOPs is the dense bf16 peak / 6: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz / 6
-PEAK_BF16X3_EQUIV_TFLOPS = round(2516.6 / 6, 1)
 
 # name -> (arch, kwargs, num_classes, per-GPU batch, H, W, train FLOPs/image (conv only), loss, ignore_index)
 # cfg2 is the bench line (BASELINE.json configs[1]); the others are the remaining BASELINE configs, runnable with --config
@@ -179,7 +176,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-cap", type=float, default=240.0, help="seconds of host time the cpu_baseline leg may spend (after its warm-up step)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented roofline step")
-    ap.add_argument("--no-alt", action="store_true", help="skip the `alt` leg (same steps with the convolutions on the bf16x3 arithmetic)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the `alt_direct` leg (same steps with Winograd off)")
     ap.add_argument("--sync-bn", action="store_true", help="SynchronizedBatchNorm across ranks (cfg4 regime)")
     ap.add_argument("--force-ddp", action="store_true", help="run the N>1 code path (process group, bucketed all-reduce) in a 1-rank group")
     ap.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (segmi.graph.GraphedStep) and time replays: "
@@ -190,9 +187,6 @@ def main():
     ap.add_argument("--lovasz-boost", type=float, default=0.0,
                     help="cfg5 A/B only: add this to the target logit on 80 %% of the pixels before the loss (trained-like, confident logits "
                          "instead of random-init ones: more elements survive the Lovasz tail pruning); costs one extra elementwise add per step")
-    ap.add_argument("--conv-math", default=os.environ.get("SEGMI_CONV_MATH", "f32"), choices=["f32", "bf16x3"],
-                    help="matrix arithmetic of the convolutions: f32 = fp32 MFMA chain (default, the parity path); bf16x3 = three-plane "
-                         "bf16 split of the fp32 operands, six products on the bf16 matrix pipe, fp32 accumulate (fp32-level accuracy)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -228,7 +222,6 @@ def main():
     import utils.losses as losses_mod
 
     from segmi import ops as segmi_ops
-    segmi_ops.set_conv_math(args.conv_math)
 
     arch, kw, classes, nb, h, w, flops_img, loss_name, ign = CONFIGS[args.config]
     model = build_model(args.config, device)
@@ -293,9 +286,9 @@ def main():
             dt = float(tt.item())
         return dt, float(loss.item())
 
-    def roofline_of(math, value):
+    def roofline_of(value):
         """Instrumented extra step (HIP events around every conv launch on the launch stream) -> the `roofline` object."""
-        peak = PEAK_FP32_MFMA_TFLOPS if math == "f32" else PEAK_BF16X3_EQUIV_TFLOPS
+        peak = PEAK_FP32_MFMA_TFLOPS
         side = segmi_ops.get_wgrad_stream()["on"]
         segmi_ops.set_wgrad_stream(False)      # per-kernel durations are taken with every launch in order on ONE stream
         try:
@@ -329,7 +322,7 @@ def main():
         # kernel was renamed / re-tiled yields null and a note, never a stale number.
         traffic = step_traffic = None
         tnote = "no PMC profile for this config/arithmetic under profiles/"
-        tag = math + ("" if wino_default else "_direct")
+        tag = "f32" + ("" if wino_default else "_direct")
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_cfg2_conv_traffic_%s.json" % tag))
         if args.config == "cfg2" and cands:
             tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
@@ -341,11 +334,9 @@ def main():
                 tnote = "HBM+MALL bytes per launch from the rocprofv3 PMC passes (profiles/%s)" % cands[-1]
         step_s = nb * world / value                                   # seconds per step of the timed loop
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic,
                 "effective": round(top["eff_flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
-                "peak_note": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if math == "f32" else
-                              "fp32-equivalent ceiling of the bf16x3 scheme = dense bf16 MFMA peak 2516.6 / 6 plane products; "
-                              "achieved/frac count ALGORITHMIC fp32 FLOPs (the fp32 MFMA peak is %.1f)" % PEAK_FP32_MFMA_TFLOPS),
+                "peak_note": "fp32 MFMA (v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz; MI355X_MICROARCH.md)",
                 "kernel": top_name, "launches": top["launches"], "avg_us": round(top["avg_us"], 1),
                 "flops_per_launch": top["flops"] // top["launches"], "algorithmic_bytes_per_launch": top["bytes"] // top["launches"],
                 "scope": "dominant kernel = the matrix kernel with the largest total time in one step; HIP events per launch on the launch "
@@ -358,13 +349,15 @@ def main():
                              "flops_per_step": tot_fl, "effective_flops_per_step": tot_eff,
                              "algorithmic_bytes_per_step": sum(r["bytes"] for r in summ.values()),
                              "traffic_bytes_per_step": step_traffic},
-                # executed_step_frac: FLOPs the matrix kernels actually executed in one step / step time / peak (a utilisation);
-                # effective_step_frac: the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as
-                # written) / step time / peak — an effective-throughput figure that may exceed what any fp32 kernel can execute
+                # executed_step_frac: FLOPs the matrix kernels actually executed in one step / step time / peak (a utilisation)
                 "hbm_bound_calls": hbm,
                 "executed_step_frac": round(tot_fl / step_s / 1e12 / peak, 4),
-                "effective_step_frac": round(value / world * flops_img / 1e12 / peak, 4),
-                "reference_formulation_flops_per_step": flops_img * nb,
+                # the REFERENCE formulation's conv FLOPs (3 x forward MACs x 2 of models/*.py as written) per step time:
+                # an equivalent-throughput RATE, not a roofline fraction — this step executes fewer FLOPs
+                "reference_formulation": {"flops_per_step": flops_img * nb, "tflops_equivalent": round(value / world * flops_img / 1e12, 1),
+                                          "executed_over_reference_flops": round(tot_fl / (flops_img * nb), 4),
+                                          "note": "not a fraction of any peak: Winograd F(2x2,3x3) and the factored PSP bottleneck execute "
+                                                  "fewer FLOPs than the reference formulation has; utilisation = executed_step_frac / frac"},
                 "variants": {k: {"launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                  "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1),
                                  "effective_tflops": round(r["eff_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for k, r in sorted(summ.items())}}
@@ -381,7 +374,7 @@ def main():
     dt, final_loss = timed(run)
     ms = 1e3 * dt / args.steps
     value = world * nb * args.steps / dt
-    roof = None if args.no_roofline else roofline_of(args.conv_math, value)
+    roof = None if args.no_roofline else roofline_of(value)
 
     # SyncBN: small latency-bound collectives per step (one all-gather forward + one all-reduce backward per BN layer; exact
     # SyncBN needs both before the layer can proceed, so only parallel branches could share one)
@@ -392,29 +385,10 @@ def main():
         step()
         syncbn_per_step = sum(c.collectives for c in ctxs) - before
 
-    # `alt`: the same K steps of the same job (it simply keeps training) with the convolutions on the OTHER arithmetic — fp32
-    # products evaluated as three-plane bf16 splits on the bf16 matrix pipe (csrc/conv_igemm.hip).  Reported
-    # beside the headline, never as it: the headline line is the fp32-MFMA parity path.
-    alt = None
-    run_alt = args.conv_math == "f32" and not args.no_alt and not args.graph and world == 1   # N > 1: the headline only (no 3x collectives)
-    if run_alt:
-        segmi_ops.set_conv_math("bf16x3")
-        try:
-            adt, aloss = timed(step)
-            aval = world * nb * args.steps / adt
-            alt = {"conv_math": "bf16x3", "value": round(aval, 2), "unit": "img/s", "ms_per_step": round(1e3 * adt / args.steps, 2),
-                   "steps": args.steps, "warmup": args.warmup, "final_loss": round(aloss, 5),
-                   "dtype": "f32 storage / LDS / accumulate; every conv product a*b evaluated as six bf16 plane products of the exact "
-                            "three-way split a = h+m+l (per-product error <= 2^-24, i.e. one fp32 rounding)",
-                   "parity": "not the headline arithmetic: the whole GPU suite passes under SEGMI_CONV_MATH=bf16x3 at HEAD (274 passed, 0 failed, "
-                             "profiles/r03_gpu_suite_bf16x3.txt; distances from the fp64 oracle over 5 seeds x 4 model families equal to the "
-                             "fp32-MFMA path's, tests/test_conv_bf16x3_gpu.py), but the UNet frozen-BN gradient check lands at 1.7-2.0e-3 against "
-                             "the 1e-3 bar of the default arithmetic and passes only under the noise-floor criterion (DESIGN.md 4.3)",
-                   "roofline": None if args.no_roofline else roofline_of("bf16x3", aval)}
-        finally:
-            segmi_ops.set_conv_math("f32")
-    # `alt_direct`: the same K steps, fp32 arithmetic, with Winograd OFF — every layer on the direct implicit-GEMM kernels (the
-    # round-2 headline path; csrc/conv_winograd.hip is an ALGORITHM change in the same arithmetic).  When the
+    run_alt = not args.no_alt and not args.graph and world == 1   # N > 1: the headline only
+    # `alt_direct`: the same K steps of the same job (it simply keeps training), fp32 arithmetic, with Winograd OFF — every layer on
+    # the direct implicit-GEMM kernels (the round-2 headline path; csrc/conv_winograd.hip is an ALGORITHM change in the same
+    # arithmetic).  When the
     # process runs with SEGMI_CONV_WINOGRAD=0 the roles swap (`alt_winograd`).
     alt_algo = None
     if run_alt:
@@ -462,8 +436,7 @@ def main():
             "metric": "training images/sec @512x512 (PSPNet-R50)" if args.config == "cfg2" else "training images/sec (%s)" % args.config,
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if args.conv_math == "f32" else
-                      "f32 (HBM/LDS/accumulate fp32; conv products as bf16x3 split on the bf16 matrix pipe)"),
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s: %s%s %dx3x%dx%d per GPU, %d classes, %s%s, SGD(momentum 0.9, wd 1e-4), "
                                    "BN batch stats%s, dropout on" % (args.config, arch, "-" + kw["backbone"] if "backbone" in kw else "", nb, h, w,
@@ -472,7 +445,7 @@ def main():
                        "global_batch": nb * world, "parallelism": "dp%d" % world,
                        "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if ddp else None),
                        "rccl_ranks": rccl_ranks, "final_loss": round(final_loss, 5),
-                       "conv_math": args.conv_math, "conv_winograd": bool(wino_default),
+                       "conv_math": "f32 (v_mfma_f32_32x32x2_f32)", "conv_winograd": bool(wino_default),
                        "conv_algorithm": ("winograd_f2x2_3x3 (fwd, dgrad, wgrad) for the 3x3 stride-1 layers with >= %d channels, direct implicit "
                                           "GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"]) if wino_default else "direct implicit GEMM",
                        "hip_graph": bool(args.graph), "wgrad_side_stream": bool(segmi_ops.get_wgrad_stream()["on"]),
@@ -480,7 +453,7 @@ def main():
                        "grad_buckets_mb": ([round(b["buf"].numel() * 4 / 2 ** 20, 1) for b in dm.reducer.buckets] if dm is not None else None),
                        "syncbn_collectives_per_step": syncbn_per_step,
                        "lovasz": lovasz_stats},
-            "roofline": roof, "cpu_baseline": cpu, "alt": alt, ("alt_direct" if wino_default else "alt_winograd"): alt_algo,
+            "roofline": roof, "cpu_baseline": cpu, ("alt_direct" if wino_default else "alt_winograd"): alt_algo,
         }
     # The JSON line is the LAST thing this process writes to stdout: RCCL prints a version banner through C stdio at communicator
     # creation, which sits in the libc buffer (stdout is a pipe under the driver) until it is flushed — left alone it comes out at

@@ -142,38 +142,10 @@ int segmi_conv2d_winograd_wgrad_variant(const segmi_conv_desc* d, char* buf, siz
  * launch (one-shot; NULL, NULL cancels), so the MFMA-bound kernel is timed apart from the HBM-bound transforms around it. */
 long segmi_conv2d_winograd_tiles(const segmi_conv_desc* d);
 int segmi_conv2d_winograd_trace(void* ev_begin, void* ev_end);
-/* Matrix arithmetic of the three convolution passes above (process-wide; takes effect on the next launch):
- *   SEGMI_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain — the default and the parity path;
- *   SEGMI_CONV_MATH_BF16X3 every fp32 operand is split in registers into three bf16 planes (x == h + m + l exactly) and
- *                          the six plane products of weight >= 2^-16 run on v_mfma_f32_32x32x16_bf16 with fp32
- *                          accumulation: per-product error <= 2^-24 (one fp32 rounding), data in HBM stays fp32.
- * Also selectable at first use with the environment variable SEGMI_CONV_MATH=bf16x3.  aten has no counterpart (the
- * reference computes in fp32, trainer.py:56); this is the drop-in's throughput knob. */
-enum segmi_conv_math {
-    SEGMI_CONV_MATH_F32 = 0,
-    SEGMI_CONV_MATH_BF16X3 = 1
-};
-/* bf16x3 with the FILTER operand pre-split: segmi_filter_presplit writes the three bf16 planes {h, m, l} (plane stride n
- * elements, n % 8 == 0, 6 bytes per filter element: segmi_filter_presplit_bytes) of an fp32 filter ONCE per step; the
- * _presplit entry points take those planes instead of the fp32 filter (KRSC for fwd, CRSK for dgrad, i.e. the array that
- * segmi_conv2d_fwd / _dgrad would have been given) and split only the activation operand in registers — half of the loop's VALU
- * work.  Results are bit-identical to segmi_conv2d_fwd / _dgrad under SEGMI_CONV_MATH_BF16X3 (same split, same products,
- * same order).  segmi_conv2d_presplit_ok(d, op) (op 0 fwd, 1 dgrad) says whether the variant applies to a problem (bf16x3
- * selected, channel counts multiples of 8, >= 64-wide output tiles, unit-stride dgrad); segmi_conv_set_presplit(0) /
- * SEGMI_CONV_PRESPLIT=0 switches it off process-wide (A/B). */
-int segmi_conv_set_presplit(int on);
-int segmi_conv2d_presplit_ok(const segmi_conv_desc* d, int op);
-size_t segmi_filter_presplit_bytes(long n);
-int segmi_filter_presplit(const float* w, long n, void* planes, segmi_stream_t stream);
-int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
-                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
-/* ... with the BN-statistics epilogue of segmi_conv2d_fwd_stats (same partial layout and count: segmi_conv2d_fwd_stats_parts) */
-int segmi_conv2d_fwd_presplit_stats(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
-                                    float* stats_partials, segmi_stream_t stream);
-int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
-                                segmi_stream_t stream);
-int segmi_conv_set_math(int math);
-int segmi_conv_get_math(void);
+/* The three convolution passes above compute on v_mfma_f32_32x32x2_f32 — fp32 products, fp32 accumulation, the reference's
+ * arithmetic (trainer.py:56).  (ABI v9 removed the second arithmetic of v3-v8, fp32 products as three-plane bf16 splits on the bf16
+ * matrix pipe — segmi_conv_set_math / segmi_conv_get_math / segmi_*_presplit: DESIGN.md section 4.3 has the measurements and why
+ * it was retired.) */
 /* db[k] = sum over rows of dy[row,k]  (classifier biases: models/pspnet.py:61,69; models/unet.py:37,77) */
 size_t segmi_colsum_workspace(long rows, int C);
 int segmi_colsum(const float* dy, int ld, long rows, int C, float* out, void* workspace, size_t workspace_bytes,

@@ -19,6 +19,18 @@ inputs from oracle.weights.synth_batch) with exactly the loss expression of the 
            to ~1e-3 of the logit scale, so "1e-3 * max|logit| from the fp32 reference" is not attainable by ANY second fp32
            implementation there; the test then requires the HIP path to be as close to fp64 as the reference is.
 
+  metrics  the reference's own `eval_metrics` (utils/metrics.py:59-67: correct, labeled, inter[C], union[C]) on its fp32 logits -> the
+           checkable form of "argmax masks bit-identical => mIoU parity"
+  wide     for the 6 largest filter gradients: per-output-channel L2 norms, per-input-channel L2 norms and per-tap sums — EXACT
+           reductions of the whole tensor (fp64 accumulation), so that a defect confined to one tile of a 72 MB gradient, which the 64
+           strided samples can miss, moves a stored number; `wide_f64` = the same from the fp64 oracle backward.
+
+cfg4_sync8 = BASELINE cfg4's defining regime, SyncBN, at a global batch the build container can hold: the reference PSPNet-R50 after
+its own `convert_model` (utils/sync_batchnorm/batchnorm.py:353-394) on ONE CPU process with the concatenated global batch of 8 x 769^2
+— `_SynchronizedBatchNorm.forward` then IS `F.batch_norm` over the global batch (batchnorm.py:65-68), the semantics the data-parallel
+path has to reproduce from 2 ranks x 4 images (tests/test_distributed_gpu.py).  Its fp64 backward recomputes every bottleneck
+(oracle/pspnet_ref.py `checkpoint=True`; 70 GB otherwise).
+
 cfg2 = PSPNet-R50 8x3x512x512 21 classes (the bench line); cfg3 = DeepLabV3+ R101 OS16 513x513 19 classes at batch 2 (of 16);
 cfg4 = one SyncBN shard's shape, PSPNet-R50 4x3x769x769 19 classes (97x97 maps), local BN; cfg5 = DeepLabV3+ Xception 512x512
 150 classes + LovaszSoftmax at batch 2 (of 8), ignore_index -1.
@@ -48,7 +60,30 @@ FULL = {
              ("initial.0.1.running_mean", "layer4.2.bn3.running_var", "master_branch.0.bottleneck.1.running_mean")),
     "cfg5": ("DeepLab", dict(backbone="xception", output_stride=16), 150, 8, 512, 512, "LovaszSoftmax", -1, 16, 2, 777,
              ("ASSP.aspp4.1.running_var", "decoder.bn1.running_mean")),
+    "cfg4_sync8": ("PSPNet", dict(backbone="resnet50"), 19, 8, 769, 769, "CrossEntropyLoss2d", 255, 12, 0, 4321,
+                   ("initial.0.1.running_mean", "initial.1.running_var", "layer4.2.bn3.running_mean", "layer4.2.bn3.running_var",
+                    "master_branch.0.stages.3.2.running_var", "master_branch.0.bottleneck.1.running_mean", "auxiliary_branch.1.running_var")),
 }
+SYNCBN = {"cfg4_sync8"}        # the reference's convert_model() is applied: SynchronizedBatchNorm2d modules on one CPU process
+CHECKPOINT_F64 = {"cfg4_sync8"}
+WIDE_TOP = 6
+
+
+def wide_keys(manifest):
+    """The 6 largest 4-D parameters (filters) of a model, by element count, ties in manifest order."""
+    filt = [(-int(torch.Size(shape).numel()), i, k) for i, (k, shape) in enumerate(manifest) if len(shape) == 4]
+    return [k for _, _, k in sorted(filt)[:WIDE_TOP]]
+
+
+def wide_stats(g):
+    """Exact whole-tensor reductions of a filter gradient [K,C,R,S] in fp64: O(K + C + R*S) numbers."""
+    g = g.detach().double()
+    return {"knorm": g.flatten(1).norm(dim=1), "cnorm": g.transpose(0, 1).flatten(1).norm(dim=1), "tapsum": g.sum(dim=(0, 1)).reshape(-1)}
+
+
+def wide_rel_err(a, b):
+    """Per statistic: relative L2 distance of a's vector from b's."""
+    return {k: ((a[k].double() - b[k].double()).norm() / (b[k].double().norm() + 1e-300)).item() for k in ("knorm", "cnorm", "tapsum")}
 
 
 def gen(name, models, losses):
@@ -59,6 +94,10 @@ def gen(name, models, losses):
         model.backbone.block2.relu.inplace = False          # numerically neutral autograd workaround
     man = manifest_of(model.state_dict())
     model.load_state_dict(synth_state_dict(man, seed=wseed))
+    if name in SYNCBN:
+        from utils.sync_batchnorm import SynchronizedBatchNorm2d, convert_model     # the REFERENCE's (sys.path: /root/reference first)
+        model = convert_model(model)
+        assert sum(isinstance(m, SynchronizedBatchNorm2d) for m in model.modules()) == 61 and manifest_of(model.state_dict()) == man
     model.train()
     for m in model.modules():
         if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
@@ -79,7 +118,13 @@ def gen(name, models, losses):
     o = out.detach()
     top2 = o.topk(2, dim=1).values
     sd_after = model.state_dict()
-    rec = {"name": name, "arch": arch, "kwargs": kw, "num_classes": C, "input_shape": (N, 3, H, W), "loss_name": loss_name,
+    from utils import metrics as ref_metrics                # the REFERENCE's utils/metrics.py
+    correct, labeled, inter, union = ref_metrics.eval_metrics(o, t, C)
+    named = dict(model.named_parameters())
+    rec = {"name": name, "syncbn": name in SYNCBN,
+           "metrics": {"correct": int(correct), "labeled": int(labeled), "inter": torch.from_numpy(inter.astype("int64")),
+                       "union": torch.from_numpy(union.astype("int64"))},
+           "wide": {k: wide_stats(named[k].grad) for k in wide_keys(man)}, "arch": arch, "kwargs": kw, "num_classes": C, "input_shape": (N, 3, H, W), "loss_name": loss_name,
            "ignore_index": ign, "weight_seed": wseed, "batch_seed": bseed, "stride": stride, "manifest": man,
            "mask": o.argmax(1).to(torch.uint8), "margin": (top2[:, 0] - top2[:, 1]).to(torch.float16),
            "logits": o[:, :, ::stride, ::stride].clone(), "logit_absmax": o.abs().max().item(),
@@ -89,6 +134,14 @@ def gen(name, models, losses):
     if aux is not None:
         rec["aux"] = aux.detach()[:, :, ::2 * stride, ::2 * stride].clone()
     path = os.path.join(GOLD, "full_%s.pt" % name)
+    if os.path.exists(path):                    # re-generation: the fp32 record must come out bit for bit; the fp64 passes are kept
+        old = torch.load(path, weights_only=False)
+        assert torch.equal(old["logits"], rec["logits"]) and torch.equal(old["mask"], rec["mask"]) and torch.equal(old["loss"], rec["loss"]), name
+        assert all(torch.equal(old["grads"][k]["sample"], v["sample"]) for k, v in rec["grads"].items()), name
+        for k in ("logits_f64", "ref_err_f64", "grads_f64", "ref_grad_err_f64", "loss_f64", "wide_f64", "wide_ref_err_f64"):
+            if k in old:
+                rec[k] = old[k]
+        print("%s: identical to the committed fixture in logits, masks, loss and gradient samples" % name, flush=True)
     torch.save(rec, path)
     print("%s: loss %.6f |logit| max %.3f, margin<1e-4 on %d px, fwd %.1fs bwd %.1fs -> %s (%.1f MB)"
           % (name, loss.item(), rec["logit_absmax"], int((rec["margin"].float() < 1e-4).sum()), t1 - t0, t2 - t1, path,
@@ -165,7 +218,7 @@ def add_f64_grads(name):
     st = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}, requires_grad=True)
     t0 = time.time()
     if rec["arch"] == "PSPNet":
-        out, aux = pspnet_ref.pspnet_forward(st, x.to(dt), training=True, backbone=rec["kwargs"]["backbone"])
+        out, aux = pspnet_ref.pspnet_forward(st, x.to(dt), training=True, backbone=rec["kwargs"]["backbone"], checkpoint=name in CHECKPOINT_F64)
         loss = losses_ref.cross_entropy(out, t, ign) + 0.4 * losses_ref.cross_entropy(aux, t, ign)
         del aux
     else:
@@ -188,6 +241,13 @@ def add_f64_grads(name):
         errs[k] = ((a - b).norm() / (b.norm() + 1e-300)).item()
     top = max(v["norm"] for v in g64.values())
     live = [e for k, e in errs.items() if g64[k]["norm"] > 1e-5 * top]     # analytically-zero gradients are pure rounding noise
+    if "grads_f64" in rec:                      # a re-run reproduces the committed digests bit for bit
+        assert all(torch.equal(rec["grads_f64"][k]["sample"], v["sample"]) for k, v in g64.items()), name
+    if "wide" in rec:
+        rec["wide_f64"] = {k: wide_stats(st[k].grad) for k in rec["wide"]}
+        rec["wide_ref_err_f64"] = {k: wide_rel_err(rec["wide"][k], rec["wide_f64"][k]) for k in rec["wide"]}
+        for k, e in rec["wide_ref_err_f64"].items():
+            print("  wide %-45s reference fp32 vs fp64: knorm %.2e cnorm %.2e tapsum %.2e" % (k, e["knorm"], e["cnorm"], e["tapsum"]), flush=True)
     rec["grads_f64"] = g64
     rec["ref_grad_err_f64"] = {"per_tensor": errs, "median": statistics.median(live), "max": max(live),
                                "worst": max((e, k) for k, e in errs.items() if g64[k]["norm"] > 1e-5 * top)[1]}

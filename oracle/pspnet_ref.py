@@ -35,17 +35,28 @@ def _bottleneck(sd, pre, x, stride, dil, training):
     return F.relu(out + x)
 
 
-def _stage(sd, name, x, blocks, stride, dilation, training):
+def _stage(sd, name, x, blocks, stride, dilation, training, checkpoint=False):
     first = 1 if dilation in (1, 2) else 2
-    x = _bottleneck(sd, "%s.0" % name, x, stride, first, training)
+
+    def block(pre, x, stride, dil):
+        if not checkpoint:
+            return _bottleneck(sd, pre, x, stride, dil, training)
+        # recompute the block's interior in backward (same kernels on the same operands => the same bits); only the block inputs
+        # stay alive.  The recomputation applies the block's running-statistics update a second time: callers that read the
+        # running statistics must not ask for checkpointing (the fp64 gradient pass of gen_golden_fullsize.py does not).
+        from torch.utils.checkpoint import checkpoint as ckpt
+        return ckpt(lambda t: _bottleneck(sd, pre, t, stride, dil, training), x, use_reentrant=False)
+
+    x = block("%s.0" % name, x, stride, first)
     for i in range(1, blocks):
-        x = _bottleneck(sd, "%s.%d" % (name, i), x, 1, dilation, training)
+        x = block("%s.%d" % (name, i), x, 1, dilation)
     return x
 
 
-def pspnet_forward(sd, x, training=True, backbone="resnet50", use_aux=True, bins=(1, 2, 3, 6), bn_training=None):
+def pspnet_forward(sd, x, training=True, backbone="resnet50", use_aux=True, bins=(1, 2, 3, 6), bn_training=None, checkpoint=False):
     """Returns (output, aux) when `training and use_aux`, else output — as models/pspnet.py:89-94.
-    `bn_training` overrides the BN mode (freeze_bn() => False while the rest trains)."""
+    `bn_training` overrides the BN mode (freeze_bn() => False while the rest trains).  `checkpoint` recomputes every bottleneck
+    in backward (memory of the fp64 pass at 8 x 769^2; gradients are bit-identical to the plain pass)."""
     bnt = training if bn_training is None else bn_training
     blocks = STAGES[backbone]
     H, W = x.shape[2], x.shape[3]
@@ -54,10 +65,10 @@ def pspnet_forward(sd, x, training=True, backbone="resnet50", use_aux=True, bins
     y = F.relu(_bn(sd, "initial.0.4", _conv(sd, "initial.0.3", y, 1, 1), bnt))
     y = F.relu(_bn(sd, "initial.1", _conv(sd, "initial.0.6", y, 1, 1), bnt))
     y = F.max_pool2d(y, 3, 2, 1)
-    y = _stage(sd, "layer1", y, blocks[0], 1, 1, bnt)
-    y = _stage(sd, "layer2", y, blocks[1], 2, 1, bnt)
-    y_aux = _stage(sd, "layer3", y, blocks[2], 1, 2, bnt)
-    y = _stage(sd, "layer4", y_aux, blocks[3], 1, 4, bnt)
+    y = _stage(sd, "layer1", y, blocks[0], 1, 1, bnt, checkpoint)
+    y = _stage(sd, "layer2", y, blocks[1], 2, 1, bnt, checkpoint)
+    y_aux = _stage(sd, "layer3", y, blocks[2], 1, 2, bnt, checkpoint)
+    y = _stage(sd, "layer4", y_aux, blocks[3], 1, 4, bnt, checkpoint)
 
     h, w = y.shape[2], y.shape[3]
     pyramid = [y]

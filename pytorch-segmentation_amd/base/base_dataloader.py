@@ -58,11 +58,13 @@ class BaseDataLoader:
         else:
             self.indices = np.arange(self.nbr_examples)
         self.nbr_examples = len(self.indices)
-        # validation-type loaders (a dataset in val mode, or the held-out split) run no collectives per step: their ranks may see
-        # different batch counts, so every sample is visited exactly once; training loaders need the SAME number of steps on
-        # every rank (gradient all-reduce, SyncBN) and wrap around instead
+        # validation-type loaders (a dataset in val mode, or the held-out split) visit every sample exactly once, so their ranks
+        # may see batch counts that differ by one: the consumer must run NO collective per step (Trainer._valid_epoch evaluates
+        # the loss per rank and all-reduces once per epoch; BN is in eval mode); training loaders need the SAME number of steps
+        # on every rank (gradient all-reduce, SyncBN, global-batch loss) and wrap around instead
         self._validation = bool(_is_val_split or getattr(dataset, "val", False))
-        self._init_kwargs = dict(batch_size=batch_size, shuffle=False, num_workers=num_workers, device=device, seed=seed, drop_last=drop_last)
+        self._init_kwargs = dict(batch_size=batch_size, shuffle=False, num_workers=num_workers, device=device, seed=seed, drop_last=drop_last,
+                                 rank=self.rank, world=self.world)      # the held-out split shards like its parent
         self._augment = None
 
     def get_val_loader(self):

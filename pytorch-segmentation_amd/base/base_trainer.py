@@ -87,11 +87,6 @@ class BaseTrainer:
         otype = config["optimizer"]["type"]
         oargs = config["optimizer"]["args"]
         fused = hasattr(segmi_optim, otype) and not oargs.get("nesterov") and not oargs.get("dampening")
-        # segmi extension of the `trainer` section (absent = the process-wide setting, SEGMI_CONV_MATH or the library default):
-        #   "conv_math": "f32" | "bf16x3"   matrix arithmetic of the convolutions (include/segmi.h segmi_conv_set_math)
-        from segmi import ops as segmi_ops
-        if "conv_math" in cfg_trainer:
-            segmi_ops.set_conv_math(cfg_trainer["conv_math"])
         self.optimizer = get_instance(segmi_optim if fused else torch.optim, "optimizer", config, trainable_params)
         # data parallel + fused SGD: the update of a gradient bucket is launched right after ITS all-reduce (segmi.distributed)
         self.bucket_step = bool(self.model.reducer.collective and fused and self.model.attach_optimizer(self.optimizer))

@@ -51,10 +51,6 @@ struct GatherParams {
     // tap ids from the tables below.  R = 1, S = ntaps for the loop logic; wRS = the filter's real tap count.
     int sub, Hc, Wc, ph, pw, os, wRS;
     int tab_r[16], tab_s[16], tab_w[16];
-    // MATH_BF16X3_PRE: the filter arrives already split into three bf16 planes (segmi_filter_presplit): [3][Cd][R*S*Cs] bf16,
-    // plane stride `plane_bytes`; `wgt` is unused
-    const void* wplanes;
-    unsigned plane_bytes;
     // batch > 1 (LDS-DMA kernel, ksplit == 1): blockIdx.y selects one of `batch` independent problems of identical shape whose
     // operands lie bs_src / bs_wgt / bs_dst floats apart (the 16 transform-domain GEMMs of a Winograd convolution)
     int batch;
@@ -270,87 +266,10 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voffset, unsig
                  :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
-// ------------------------------------------------------------------------------------------------
-// MATH_BF16X3: fp32-accurate products on the bf16 matrix pipe (16x the fp32 MFMA rate per instruction).
-// Each fp32 operand x is split IN REGISTERS, after the fragment read, into three bf16 planes
-//     h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)          (round-to-nearest-even, v_cvt_pk_bf16_f32)
-// Both subtractions are exact in fp32 and the last residual has <= 7 significant bits, so x == h + m + l EXACTLY
-// (8+8+8 = 24 significand bits; exponent range of fp32 kept, unlike an fp16 split).  Of the nine plane products the six
-// of relative weight >= 2^-16 are issued as v_mfma_f32_32x32x16_bf16 into the SAME fp32 accumulator:
-//     x*y ~= l*h' + h*l' + m*m' + m*h' + h*m' + h*h'       dropped: m*l' + l*m' + l*l'  <= 2^-24 |x*y|, signs random
-// i.e. the dropped part is at the level of ONE fp32 rounding of the product, and the accumulator sees 6K/16 roundings
-// instead of the K of the fp32 MFMA chain.  Data in HBM and LDS stay fp32: same DMA, same swizzle, same epilogue;
-// only the fragment reads (8 consecutive k per lane instead of 4) and the matrix instructions differ.
-// Cost model per wave and 32-wide K chunk (64x64 wave tile): 48 MFMAs x 32 cycles = 1536 cycles of matrix pipe against
-// 4096 for fp32 MFMA, plus 64 operand floats per lane x 5.5 VALU to split (the issue-slot budget beside an MFMA is ~5-7
-// VALU: this kernel is VALU-issue/MFMA co-limited, not LDS- or HBM-limited).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// The loop is software-pipelined over 16-wide k steps across chunk boundaries; two other loop structures (compiler-scheduled
-// per-chunk loop, packed residual subtractions) and a two-plane reduced-precision variant were measured on hardware in round 2
-// (profiles/r02_bf16x3_*) and removed: this one was the fastest (197 vs 182/186 TF/s on the PSP bottleneck).
-enum { MATH_F32 = SEGMI_CONV_MATH_F32, MATH_BF16X3 = SEGMI_CONV_MATH_BF16X3,
-       // internal variant of bf16x3 (fprop / dgrad only, never selected by the caller directly): the FILTER operand is read as
-       // pre-split bf16 planes, so only the activation operand is split in registers — half of the loop's VALU work
-       MATH_BF16X3_PRE = 2 };
-
-struct Planes { u32x4_t h, m, l; };     // 8 k-values of one tile row: element 2i in the low half of dword i
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
-}
-// The two residuals of a pair are kept as two plain v_sub_f32: left to itself the SLP vectoriser fuses them into one
-// v_pk_add_f32, which on gfx950 is no faster than two fp32 VALU ops (the fp32 vector pipe is already 32 lanes wide) and is the
-// costliest filler beside matrix instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  The empty asm is
-// an optimisation fence on ONE value of the pair (emits nothing; the subtractions stay ordinary, schedulable VALU).
-__device__ __forceinline__ void slp_fence(float& v) { asm("" : "+v"(v)); }
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, h << 16);
-    float r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
-    slp_fence(r1);
-    m = cvt_pk_bf16(r0, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, m << 16);
-    float s1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
-    slp_fence(s1);
-    l = cvt_pk_bf16(s0, s1);
-}
-__device__ __forceinline__ Planes split8(const float (&x)[8]) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
-    Planes p;
-    p.h = u32x4_t{h[0], h[1], h[2], h[3]};
-    p.m = u32x4_t{m[0], m[1], m[2], m[3]};
-    p.l = u32x4_t{l[0], l[1], l[2], l[3]};
-    return p;
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-// acc[i][j] += A_i (x) B_j over 16 k-values, six plane products, smallest terms first; the (i, j) loop is innermost so
-// that consecutive matrix instructions target different accumulators
-template <int TM, int TN>
-__device__ __forceinline__ void mma_bf16x3(f32x16 (&acc)[TM][TN], const Planes (&a)[TM], const Planes (&b)[TN]) {
-#define SEGMI_PLANE_PRODUCT(PA, PB)                                                       \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].PA, b[j].PB, acc[i][j]);
-    SEGMI_PLANE_PRODUCT(l, h)
-    SEGMI_PLANE_PRODUCT(h, l)
-    SEGMI_PLANE_PRODUCT(m, m)
-    SEGMI_PLANE_PRODUCT(m, h)
-    SEGMI_PLANE_PRODUCT(h, m)
-    SEGMI_PLANE_PRODUCT(h, h)
-#undef SEGMI_PLANE_PRODUCT
-}
-
 // FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
 // keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
 // an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int MATH>
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -359,15 +278,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile shape");
 
     extern __shared__ __attribute__((aligned(1024))) float smem[];
-    constexpr bool BPRE = MATH == MATH_BF16X3_PRE;
     const int bidy = p.batch > 1 ? 0 : (int)blockIdx.y;  // split-K slice, unless blockIdx.y is the batch index
     const long bat = p.batch > 1 ? (long)blockIdx.y : 0;
     const float* const src_base = p.src + bat * p.bs_src;     // (locals: writing to the by-value parameter block would move it to scratch)
     const float* const wgt_base = p.wgt + bat * p.bs_wgt;
     float* const dst_base = p.dst + bat * p.bs_dst;
-    // floats per pipeline stage: A = BM rows x 32 fp32; B = BN rows x 32 fp32, or (BPRE) three planes of BN rows x 32 bf16
-    constexpr int STAGE = BM * BK + (BPRE ? BN * 48 : BN * BK);
-    static_assert(!BPRE || (BN % 64 == 0), "pre-split B planes move 16 rows x 64 B per wave-instruction, 4 waves");
+    constexpr int STAGE = (BM + BN) * BK;             // floats per pipeline stage: A = BM rows x 32 fp32, B = BN rows x 32 fp32
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,12 +303,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     const int m0 = tm * BM, n0 = tn * BN;
 
     const i32x4 src_rsrc = make_rsrc(src_base, src_bytes);
-    const i32x4 wgt_rsrc = make_rsrc(BPRE ? (const float*)p.wplanes : wgt_base, wgt_bytes);
+    const i32x4 wgt_rsrc = make_rsrc(wgt_base, wgt_bytes);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)wave * (8 * BK * 4);
-    // BPRE: a wave-instruction deposits 16 plane rows of 64 B (32 bf16); lane -> (row lane/4, 16-byte slot lane%4); the slot a
-    // lane FETCHES is XOR-swizzled with (row/4)%4 so that the ds_read_b128 of 16 consecutive rows hit 16 distinct bank quads
-    const unsigned ldsB0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + BM * BK * 4 + (unsigned)wave * (16 * 64);
-    const int kgB = (lane & 3) ^ ((lane >> 4) & 3);
 
     // DMA role of this lane: row (wave*8 + lane/8) of every 32-row group, 16-byte slot lane%8
     const int rl = wave * 8 + (lane >> 3);
@@ -442,21 +354,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)((subm ? p.wRS : RS) * p.Cs) : OOB;
     }
 
-    auto issue_b_planes = [&](int r, int s, int c0, int buf) {
-        const unsigned Bp = ldsB0 + (unsigned)buf * (STAGE * 4);
-        const int cB = c0 + kgB * 8;                             // this lane's 8-channel group of the chunk
-        const bool cokB = cB < p.Cs;
-        const unsigned tapc = (unsigned)((r * p.S + s) * p.Cs + cB);
-        const unsigned rowlen = (unsigned)(p.R * p.S * p.Cs);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < BN / 64; ++i) {
-                const int k = n0 + i * 64 + wave * 16 + (lane >> 2);
-                const bool ok = cokB && k < p.Cd;
-                dma16(wgt_rsrc, ok ? (unsigned)pl * p.plane_bytes + ((unsigned)k * rowlen + tapc) * 2u : OOB, Bp + pl * (BN * 64) + i * (64 * 64));
-            }
-    };
     auto issue = [&](int r, int s, int c0, int buf) {
         const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BM * BK * 4;   // LDS byte addresses (wave's 8-row slice)
         const int c = c0 + kg * 4;
@@ -510,7 +407,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
             const unsigned off = ((unsigned)(a_pix[i] + hs * p.Ws + ws) * (unsigned)p.lds + (unsigned)c) * 4u;
             dma16(src_rsrc, ok ? off : OOB, As + i * (32 * BK * 4));
         }
-        if constexpr (BPRE) { issue_b_planes(r, s, c0, buf); return; }   // (never combined with pack4 / parity-class launches: host side)
         const unsigned tapc = (unsigned)((r * p.S + s) * p.Cs + c);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -546,113 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
-    if (MATH != MATH_F32) {
-        // A lane feeds 8 consecutive k of its row per matrix instruction: k-groups (ks*4 + lhalf*2, +1), i.e. two swizzled
-        // 16-byte slots that are neighbours (the XOR only permutes slots, a row's pair stays a pair).
-        // Software pipeline over 16-wide k steps, ACROSS chunk boundaries (matrix instructions only need registers, so the
-        // second step of chunk t may issue after the barrier that releases its LDS stage):
-        //     phase A(t): MFMAs of step (t-1, 1)  ||  split of step (t, 0)
-        //     phase B(t): MFMAs of step (t, 0)    ||  split of step (t, 1)
-        // Each phase pairs 6*TM*TN matrix instructions (32 cycles each) with the ~44 VALU per tile row-block of one split
-        // (sched_group_barrier: 1 MFMA + its share of VALU per group), so neither pipe waits for the other inside a wave;
-        // only the very first split of a tile is exposed, and the last step drains after the loop.
-        constexpr int NMMA = TM * TN * 6;
-        // VALU per group: one split8 = 12 cvt + 16 unpack + 16 sub = 44; with pre-split filter planes only the A row-blocks are split
-        constexpr int VPG = ((TM + (BPRE ? 0 : TN)) * 44 + NMMA - 1) / NMMA;
-        float ra[2][TM][8], rb[2][TN][8];                    // (rb is dead under BPRE)
-        Planes pa[2][TM], pb[2][TN];
-        const int swzB = (lrow32 >> 2) & 3;
-        auto fetch = [&](const float* Ab, const float* Bb, int ks) {
-            const int g0 = ks * 4 + lhalf * 2;
-            const int s0 = (g0 ^ swz) * 4, s1 = ((g0 + 1) ^ swz) * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float* rowp = Ab + (wm0 + i * 32 + lrow32) * BK;
-                const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                ra[ks][i][0] = u.x; ra[ks][i][1] = u.y; ra[ks][i][2] = u.z; ra[ks][i][3] = u.w;
-                ra[ks][i][4] = v.x; ra[ks][i][5] = v.y; ra[ks][i][6] = v.z; ra[ks][i][7] = v.w;
-            }
-            if constexpr (!BPRE) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float* rowp = Bb + (wn0 + j * 32 + lrow32) * BK;
-                    const float4 u = ld4(rowp + s0), v = ld4(rowp + s1);
-                    rb[ks][j][0] = u.x; rb[ks][j][1] = u.y; rb[ks][j][2] = u.z; rb[ks][j][3] = u.w;
-                    rb[ks][j][4] = v.x; rb[ks][j][5] = v.y; rb[ks][j][6] = v.z; rb[ks][j][7] = v.w;
-                }
-            }
-        };
-        // BPRE: the filter planes of step ks straight from LDS into the matrix-instruction operands (one ds_read_b128 per plane:
-        // 8 consecutive bf16 of the lane's row), slot un-swizzled as the DMA swizzled it
-        auto load_b_planes = [&](const float* Bb, int ks) {
-            const u32x4_t* base = reinterpret_cast<const u32x4_t*>(Bb);
-            const int slot = (ks * 2 + lhalf) ^ swzB;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 32 + lrow32;
-                pb[ks][j].h = base[(0 * BN + row) * 4 + slot];
-                pb[ks][j].m = base[(1 * BN + row) * 4 + slot];
-                pb[ks][j].l = base[(2 * BN + row) * 4 + slot];
-            }
-        };
-        auto split_b = [&](int ks) {
-            if constexpr (!BPRE) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) pb[ks][j] = split8(rb[ks][j]);
-            }
-        };
-        auto phase_b = [&](const float* Bb) {                  // MFMAs of step 0 || split of step 1, then hand over the stage
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (BPRE) load_b_planes(Bb, 1);            // pb[1] is free: the pending step's MFMAs precede this point
-#pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
-            split_b(1);
-            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
-#pragma unroll
-            for (int q = 0; q < NMMA; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (BPRE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pb[1]'s reads of this stage are consumed only next iteration
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
-            __syncthreads();                                     // ... for every wave, and this stage is free again
-            buf ^= 1;
-        };
-        if (it0 < T) {                                         // first chunk of the tile: nothing pending, its first split is exposed
-            if (it0 + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
-            const float* Ab = smem + buf * STAGE;
-            const float* Bb = Ab + BM * BK;
-            fetch(Ab, Bb, 0);
-            fetch(Ab, Bb, 1);
-            if constexpr (BPRE) load_b_planes(Bb, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
-            split_b(0);
-            phase_b(Bb);
-        }
-        for (int it = it0 + 1; it < T; ++it) {
-            if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
-            const float* Ab = smem + buf * STAGE;
-            const float* Bb = Ab + BM * BK;
-            fetch(Ab, Bb, 0);
-            fetch(Ab, Bb, 1);                                  // both steps up front: step 1's LDS latency hides behind phase A
-            if constexpr (BPRE) load_b_planes(Bb, 0);            // pb[0] was consumed by the previous phase B
-            // phase A: MFMAs of the pending step || split of step 0
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
-            split_b(0);
-            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
-#pragma unroll
-            for (int q = 0; q < NMMA; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
-            }
-            phase_b(Bb);
-        }
-        if (it0 < T) mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);    // drain: second step of the last chunk
-    } else {
+    {
     // fp32 MFMA: the matrix instruction adds its 2 products onto the accumulator in k order, i.e. an fp32 chain as long as the
     // reduction (up to 9 x 2048 terms) with a rounding error that grows like sqrt(length) — measured 2-5x the error of the
     // reference's CPU kernels on the same operands (tools/probes/conv_error_vs_fp64.py, profiles/r04_conv_error_vs_fp64*.txt).
@@ -1015,7 +805,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // ROWQ (Q % 32 == 0): a 32-pixel chunk never straddles an output row, so (n, p, q0) of the chunk are wave-uniform scalars
 // advanced with SALU, and a lane only adds its fixed in-chunk column: ~20 VALU per chunk instead of ~130 (the m -> (n,p,q)
 // bookkeeping per lane and per load is what kept the generic path's waves off the matrix pipe: 125 vs 136 TF/s of fprop).
-template <int BM, int BN, bool ROWQ, int MATH>
+template <int BM, int BN, bool ROWQ>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int BKP = 32, WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -1147,77 +937,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (MATH != MATH_F32) {
-        // Same software pipeline as conv_dma_kernel (phase A: pending step's MFMAs || split of step 0; phase B: step 0's
-        // MFMAs || split of step 1; the second step of a chunk issues after the barrier).  The reduction axis (pixels) is the
-        // LDS row index here: a lane gathers its channel's 8 pixels (ks*16 + lhalf*8 + e) with ds_read_b32 (lanes of a
-        // half-wave read consecutive channels of one pixel: conflict-free as in the fp32 path).
-        constexpr int NMMA = TM * TN * 6;
-        constexpr int VPG = ((TM + TN) * 44 + NMMA - 1) / NMMA;
-        float ra[2][TM][8], rb[2][TN][8];
-        Planes pa[2][TM], pb[2][TN];
-        int buf = 0;
-        auto fetch = [&](const float* Ab, const float* Bb, int ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ra[ks][i][e] = Ab[(ks * 16 + lhalf * 8 + e) * BM + wm0 + i * 32 + lrow32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rb[ks][j][e] = Bb[(ks * 16 + lhalf * 8 + e) * BN + wn0 + j * 32 + lrow32];
-        };
-        auto phase_b = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) pa[1][i] = split8(ra[1][i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) pb[1][j] = split8(rb[1][j]);
-            mma_bf16x3<TM, TN>(acc, pa[0], pb[0]);
-#pragma unroll
-            for (int q = 0; q < NMMA; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            buf ^= 1;
-        };
-        if (mbeg < mend) {
-            issue(mbeg, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (mbeg + BKP < mend) issue(mbeg + BKP, 1);
-            fetch(smem, smem + BKP * BM, 0);
-            fetch(smem, smem + BKP * BM, 1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);        // first chunk: exposed split
-#pragma unroll
-            for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
-            phase_b();
-            for (int mb = mbeg + BKP; mb < mend; mb += BKP) {
-                if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
-                const float* Ab = smem + buf * STAGE;
-                const float* Bb = Ab + BKP * BM;
-                fetch(Ab, Bb, 0);
-                fetch(Ab, Bb, 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) pa[0][i] = split8(ra[0][i]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) pb[0][j] = split8(rb[0][j]);
-                mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);
-#pragma unroll
-                for (int q = 0; q < NMMA; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
-                }
-                phase_b();
-            }
-            mma_bf16x3<TM, TN>(acc, pa[1], pb[1]);                            // drain
-        }
-    } else
     if (mbeg < mend) {
         issue(mbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1393,20 +1112,6 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
-// planes[p][i] (bf16, p = 0 h, 1 m, 2 l; plane stride n elements) of the fp32 array w[n]: the same split as split_pair, done once
-// per filter and step instead of once per workgroup and chunk
-__global__ __launch_bounds__(256) void filter_presplit_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ planes) {
-    const long n8 = n >> 3, pstride = n >> 1;                        // plane stride in dwords (2 bf16 per dword)
-    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long)gridDim.x * 256) {
-        const float4 a = ld4(w + g * 8), b = ld4(w + g * 8 + 4);
-        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const Planes q = split8(x);
-        *reinterpret_cast<u32x4_t*>(planes + g * 4) = q.h;
-        *reinterpret_cast<u32x4_t*>(planes + pstride + g * 4) = q.m;
-        *reinterpret_cast<u32x4_t*>(planes + 2 * pstride + g * 4) = q.l;
-    }
-}
-
 // ---------------------------------------------------------------------------------- host side
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
 int launch_gather(GatherParams& p, hipStream_t st) {
@@ -1432,19 +1137,6 @@ int conv_bk() {
     return g_bk;
 }
 
-// Matrix arithmetic of the LDS-DMA convolution kernels: MATH_F32 (v_mfma_f32_32x32x2_f32, the default and the parity
-// path) or MATH_BF16X3 (three-plane bf16 split, six products; see the comment above split_pair).  Process-wide, set by
-// segmi_conv_set_math() or, at first use, by SEGMI_CONV_MATH=bf16x3.  The register-staged fallback kernels are fp32 only.
-int g_math = -1;
-int conv_math() {
-    if (g_math < 0) {
-        const char* e = getenv("SEGMI_CONV_MATH");
-        g_math = MATH_F32;
-        if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_math = MATH_BF16X3;
-    }
-    return g_math;
-}
-
 template <int BM, int BN, int WM, int WN, int MODE>
 int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
     p.tiles_m = segmi_cdiv(p.M, BM);
@@ -1455,33 +1147,8 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)(p.batch > 1 ? p.batch : p.ksplit));
-#define SEGMI_LAUNCH_DMA(FASTV, MATHV) \
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, FASTV, MATHV>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes)
-    if (p.wplanes) {
-        // pre-split filter planes (bf16x3 only; the caller checked presplit_ok): three bf16 planes of BN rows x 64 B per stage
-        if constexpr (BN % 64 == 0) {
-            const size_t ldsp = (size_t)2 * (BM * 128 + BN * 192);
-            static bool attr_set[2] = {false, false};      // benign race: idempotent
-            if (!attr_set[fast ? 1 : 0] && ldsp > 64 * 1024) {
-                if (fast) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3_PRE>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-                else      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3_PRE>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-                attr_set[fast ? 1 : 0] = true;
-            }
-            if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, MATH_BF16X3_PRE>), grid, dim3(256), ldsp, st, p, src_bytes, wgt_bytes);
-            else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false, MATH_BF16X3_PRE>), grid, dim3(256), ldsp, st, p, src_bytes, wgt_bytes);
-        } else {
-            return SEGMI_ERR_BADARG;
-        }
-    } else
-    switch (conv_math() * 2 + (fast ? 1 : 0)) {
-        case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_DMA(true, MATH_F32); break;
-        case MATH_F32 * 2:               SEGMI_LAUNCH_DMA(false, MATH_F32); break;
-        case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_DMA(true, MATH_BF16X3); break;
-        default:                         SEGMI_LAUNCH_DMA(false, MATH_BF16X3); break;
-    }
-#undef SEGMI_LAUNCH_DMA
+    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
     if (p.ksplit > 1) {
         const long n4 = (long)p.M * p.ldd / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -1489,15 +1156,6 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, (const float*)p.ws, p.dst, n4, p.ksplit, n4);
     }
     return segmi_launch_status();
-}
-
-int g_presplit = -1;  // SEGMI_CONV_PRESPLIT=0: bf16x3 splits the filter operand in registers too (A/B of the pre-split planes)
-bool conv_presplit() {
-    if (g_presplit < 0) {
-        const char* e = getenv("SEGMI_CONV_PRESPLIT");
-        g_presplit = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return g_presplit == 1;
 }
 
 int g_dma = -1;  // SEGMI_CONV_DMA=0 forces the register-staged kernels (A/B testing)
@@ -1541,8 +1199,7 @@ bool dma_half_m(int M, int Cd, int batch = 1) {      // batch: the 16 contractio
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
-    unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
-    if (p.wplanes) wb = 3u * p.plane_bytes;                                    // three bf16 planes (presplit_ok bounded them)
+    const unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
     if (conv_dma() && sb && wb) {
         const bool half_m = dma_half_m(p.M, p.Cd, p.batch);              // (a batched launch has batch x the tiles)
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
@@ -1672,15 +1329,8 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     if (p.batch > 1 && !wgrad_dma(p, &xb, &dyb)) return SEGMI_ERR_BADARG;     // batch exists in the LDS-DMA kernel only
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
-#define SEGMI_LAUNCH_WGRAD(ROWQV, MATHV) \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, ROWQV, MATHV>), grid, dim3(256), lds, st, p, xb, dyb)
-        switch (conv_math() * 2 + (p.Q % WG_BKP == 0 ? 1 : 0)) {
-            case MATH_F32 * 2 + 1:           SEGMI_LAUNCH_WGRAD(true, MATH_F32); break;
-            case MATH_F32 * 2:               SEGMI_LAUNCH_WGRAD(false, MATH_F32); break;
-            case MATH_BF16X3 * 2 + 1:        SEGMI_LAUNCH_WGRAD(true, MATH_BF16X3); break;
-            default:                         SEGMI_LAUNCH_WGRAD(false, MATH_BF16X3); break;
-        }
-#undef SEGMI_LAUNCH_WGRAD
+        if (p.Q % WG_BKP == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
+        else                   hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
     }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();
@@ -1706,15 +1356,14 @@ static int fwd_stats_parts(const segmi_conv_desc* d) {
     return segmi_cdiv(M, bm);
 }
 
-static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w, const void* planes, const float* bias, float* y,
+static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                          int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream, float* stats = nullptr) {
-    if (!desc_ok(d) || !x || (!w && !planes) || !y) return SEGMI_ERR_BADARG;
+    if (!desc_ok(d) || !x || !w || !y) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || d->ldx < d->C || (d->ldy & 3) || d->ldy < ((d->K + 3) & ~3) || !aligned16(x) ||
-        !aligned16(planes ? planes : (const void*)w) || !aligned16(y))
+        !aligned16(w) || !aligned16(y))
         return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = x; p.wgt = w; p.bias = bias; p.dst = y;
-    p.wplanes = planes; p.plane_bytes = planes ? (unsigned)((long)d->K * d->R * d->S * d->C * 2) : 0u;
     p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.Cs = d->C; p.lds = d->ldx;
     p.Hd = d->P; p.Wd = d->Q; p.Cd = d->K; p.ldd = d->ldy;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -1736,30 +1385,27 @@ static int conv_fwd_impl(const segmi_conv_desc* d, const float* x, const float* 
 
 int segmi_conv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                      int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
-    if (!w) return SEGMI_ERR_BADARG;
-    return conv_fwd_impl(d, x, w, nullptr, bias, y, accumulate, workspace, workspace_bytes, stream);
+    return conv_fwd_impl(d, x, w, bias, y, accumulate, workspace, workspace_bytes, stream);
 }
 
 int segmi_conv2d_fwd_stats_parts(const segmi_conv_desc* d) { return fwd_stats_parts(d); }
 
 int segmi_conv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* stats_partials,
                            segmi_stream_t stream) {
-    if (!w || !stats_partials) return SEGMI_ERR_BADARG;
-    return conv_fwd_impl(d, x, w, nullptr, bias, y, 0, nullptr, 0, stream, stats_partials);
+    if (!stats_partials) return SEGMI_ERR_BADARG;
+    return conv_fwd_impl(d, x, w, bias, y, 0, nullptr, 0, stream, stats_partials);
 }
 
-static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const float* w_crsk, const void* planes, float* dx, int accumulate,
-                           segmi_stream_t stream) {
-    if (!desc_ok(d) || !dy || (!w_crsk && !planes) || !dx) return SEGMI_ERR_BADARG;
+int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                       segmi_stream_t stream) {
+    if (!desc_ok(d) || !dy || !w_crsk || !dx) return SEGMI_ERR_BADARG;
     // the reduction axis is K here: the caller pads it to a multiple of 4 (Kpad = round_up(K,4) <= ldy)
     const int Kpad = (d->K + 3) & ~3;
     if ((d->ldy & 3) || d->ldy < Kpad || (d->ldx & 3) || d->ldx < ((d->C + 3) & ~3) || !aligned16(dy) ||
-        !aligned16(planes ? planes : (const void*)w_crsk) || !aligned16(dx))
+        !aligned16(w_crsk) || !aligned16(dx))
         return SEGMI_ERR_ALIGN;
     GatherParams p;
     p.src = dy; p.wgt = w_crsk; p.bias = nullptr; p.dst = dx;
-    p.wplanes = planes; p.plane_bytes = planes ? (unsigned)((long)d->C * d->R * d->S * Kpad * 2) : 0u;
-    if (planes && d->stride != 1) return SEGMI_ERR_BADARG;
     p.N = d->N; p.Hs = d->P; p.Ws = d->Q; p.Cs = Kpad; p.lds = d->ldy;
     p.Hd = d->H; p.Wd = d->W; p.Cd = d->C; p.ldd = d->ldx;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -1797,56 +1443,6 @@ static int conv_dgrad_impl(const segmi_conv_desc* d, const float* dy, const floa
             if (rc != SEGMI_OK) return rc;
         }
     return SEGMI_OK;
-}
-
-int segmi_conv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
-                       segmi_stream_t stream) {
-    if (!w_crsk) return SEGMI_ERR_BADARG;
-    return conv_dgrad_impl(d, dy, w_crsk, nullptr, dx, accumulate, stream);
-}
-
-// ---- bf16x3 with the FILTER pre-split into bf16 planes (half of the loop's split work moves to one small kernel per step)
-int segmi_conv_set_presplit(int on) { g_presplit = on ? 1 : 0; return SEGMI_OK; }
-
-int segmi_conv2d_presplit_ok(const segmi_conv_desc* d, int op) {
-    if (!desc_ok(d) || conv_math() != MATH_BF16X3 || !conv_dma() || !conv_presplit()) return 0;
-    const int Kpad = (d->K + 3) & ~3;
-    const int Cs = op == 0 ? d->C : Kpad, Cd = op == 0 ? d->K : d->C;
-    if (op != 0 && (op != 1 || d->stride != 1)) return 0;
-    if ((Cs & 7) || Cd <= 32) return 0;                               // 16-byte plane pieces = 8 channels; 64/128-wide output tiles only
-    const long n = (long)Cd * d->R * d->S * Cs;
-    if (!span32(n * 6 / 4)) return 0;                                 // three bf16 planes behind one 32-bit buffer descriptor
-    if (op == 0) return dma_eligible_fwd(d) ? 1 : 0;
-    return (span32((long)d->N * d->P * d->Q * d->ldy) && span32((long)d->C * d->R * d->S * Kpad)) ? 1 : 0;
-}
-
-size_t segmi_filter_presplit_bytes(long n) { return n > 0 ? (size_t)n * 6 : 0; }
-
-int segmi_filter_presplit(const float* w, long n, void* planes, segmi_stream_t stream) {
-    if (!w || !planes || n <= 0 || (n & 7)) return SEGMI_ERR_BADARG;
-    if (!aligned16(w) || !aligned16(planes)) return SEGMI_ERR_ALIGN;
-    long nb = (n / 8 + 255) / 256;
-    if (nb > SEGMI_MAX_GRID * 4) nb = SEGMI_MAX_GRID * 4;
-    hipLaunchKernelGGL(filter_presplit_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, n, (unsigned*)planes);
-    return segmi_launch_status();
-}
-
-int segmi_conv2d_fwd_presplit(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
-                              int accumulate, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
-    if (!w_planes || !segmi_conv2d_presplit_ok(d, 0)) return SEGMI_ERR_BADARG;
-    return conv_fwd_impl(d, x, nullptr, w_planes, bias, y, accumulate, workspace, workspace_bytes, stream);
-}
-
-int segmi_conv2d_fwd_presplit_stats(const segmi_conv_desc* d, const float* x, const void* w_planes, const float* bias, float* y,
-                                    float* stats_partials, segmi_stream_t stream) {
-    if (!w_planes || !stats_partials || !segmi_conv2d_presplit_ok(d, 0)) return SEGMI_ERR_BADARG;
-    return conv_fwd_impl(d, x, nullptr, w_planes, bias, y, 0, nullptr, 0, stream, stats_partials);
-}
-
-int segmi_conv2d_dgrad_presplit(const segmi_conv_desc* d, const float* dy, const void* w_crsk_planes, float* dx, int accumulate,
-                                segmi_stream_t stream) {
-    if (!w_crsk_planes || !segmi_conv2d_presplit_ok(d, 1)) return SEGMI_ERR_BADARG;
-    return conv_dgrad_impl(d, dy, nullptr, w_crsk_planes, dx, accumulate, stream);
 }
 
 size_t segmi_conv2d_wgrad_workspace(const segmi_conv_desc* d) {
@@ -1896,7 +1492,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
         const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
-        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s, %d> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", conv_math(), pl.nsplit);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", pl.nsplit);
         else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
@@ -1906,21 +1502,13 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %d>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op,
-                 fast ? "true" : "false", segmi_conv2d_presplit_ok(d, op) ? (int)MATH_BF16X3_PRE : conv_math());
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false");
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
     snprintf(buf, len, "conv_gather_kernel<128, %d, %d, %s, %d>", bn, bk, bn == 32 ? "4, 1" : "2, 2", op);
     return SEGMI_OK;
 }
-
-int segmi_conv_set_math(int math) {
-    if (math != SEGMI_CONV_MATH_F32 && math != SEGMI_CONV_MATH_BF16X3) return SEGMI_ERR_BADARG;
-    g_math = math;
-    return SEGMI_OK;
-}
-int segmi_conv_get_math(void) { return conv_math(); }
 
 int segmi_filter_krsc_to_crsk(const float* w, float* wt, int K, int R, int S, int C, int Kpad, segmi_stream_t stream) {
     if (!w || !wt || K <= 0 || R <= 0 || S <= 0 || C <= 0 || Kpad < K) return SEGMI_ERR_BADARG;
@@ -1971,7 +1559,6 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
     if (!conv_dma() || !span32((long)M * lda) || !span32((long)Cd * Cs)) return SEGMI_ERR_BADARG;   // batch exists in the LDS-DMA kernel only
     GatherParams p;
     p.src = a; p.wgt = w; p.bias = nullptr; p.dst = d;
-    p.wplanes = nullptr; p.plane_bytes = 0u;
     p.N = 1; p.Hs = 1; p.Ws = M; p.Cs = Cs; p.lds = lda;
     p.Hd = 1; p.Wd = M; p.Cd = Cd; p.ldd = ldd;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.dil = 1;
@@ -1986,7 +1573,7 @@ int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
     if (!buf || len < 64) return SEGMI_ERR_BADARG;
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
     const int bm = dma_half_m(M, Cd, 16) ? 64 : 128;                         // the 16 batched contractions of a Winograd pass
-    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %d>", bm, bn, bn == 32 ? "4, 1" : "2, 2", conv_math());
+    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true>", bm, bn, bn == 32 ? "4, 1" : "2, 2");
     return SEGMI_OK;
 }
 
@@ -2028,7 +1615,7 @@ int segmi_internal_wgrad_batched(const float* x, const float* dy, float* ws, int
 int segmi_internal_wgrad_batched_variant(int M, int C, int K, int batch, char* buf, size_t len) {
     const int nsplit = segmi_internal_wgrad_batched_splits(M, C, K, batch);
     if (!buf || len < 64 || nsplit < 1) return SEGMI_ERR_BADARG;
-    snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, true, %d> splitk=%d", K > 64 ? 128 : 64, C > 64 ? 128 : 64, conv_math(), nsplit);
+    snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, true> splitk=%d", K > 64 ? 128 : 64, C > 64 ? 128 : 64, nsplit);
     return SEGMI_OK;
 }
 

@@ -60,15 +60,6 @@ SIGNATURES = {
     "segmi_conv2d_winograd_trace": (i32, [vp, vp]),
     "segmi_filter_tx_tiles": (i64, [i32, i32, i32, i32, i32]),
     "segmi_filter_krsc_to_crsk_multi": (i32, [vp, i32, i64, vp]),
-    "segmi_conv_set_presplit": (i32, [i32]),
-    "segmi_conv2d_presplit_ok": (i32, [PD, i32]),
-    "segmi_filter_presplit_bytes": (sz, [i64]),
-    "segmi_filter_presplit": (i32, [vp, i64, vp, vp]),
-    "segmi_conv2d_fwd_presplit": (i32, [PD, vp, vp, vp, vp, i32, vp, sz, vp]),
-    "segmi_conv2d_fwd_presplit_stats": (i32, [PD, vp, vp, vp, vp, vp, vp]),
-    "segmi_conv2d_dgrad_presplit": (i32, [PD, vp, vp, vp, i32, vp]),
-    "segmi_conv_set_math": (i32, [i32]),
-    "segmi_conv_get_math": (i32, []),
     "segmi_dwconv2d_fwd": (i32, [PD, vp, vp, vp, vp]),
     "segmi_dwconv2d_fwd_stats_parts": (i32, [PD]),
     "segmi_dwconv2d_fwd_stats": (i32, [PD, vp, vp, vp, vp, vp]),

@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "conv2d_fan", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_math", "get_conv_math", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -267,23 +267,6 @@ def conv_out_size(H, k, stride, pad, dil):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-CONV_MATH = {"f32": 0, "bf16x3": 1}
-
-
-def set_conv_math(name):
-    """Matrix arithmetic of the dense convolution kernels (process-wide; include/segmi.h `segmi_conv_set_math`):
-    "f32" = fp32 MFMA chain (default, the parity path); "bf16x3" = three-plane bf16 split of every fp32 operand, six products
-    on the bf16 matrix pipe, fp32 accumulation (fp32-level accuracy, ~2x the matrix throughput)."""
-    if name not in CONV_MATH:
-        raise SegmiError("segmi.set_conv_math: unknown math %r (choose from %s)" % (name, sorted(CONV_MATH)))
-    check(lib.segmi_conv_set_math(CONV_MATH[name]), "conv_set_math")
-
-
-def get_conv_math():
-    v = lib.segmi_conv_get_math()
-    return next(k for k, x in CONV_MATH.items() if x == v)
-
-
 def conv_variant(d, op):
     """Kernel variant name for (desc, op in {0 fwd, 1 dgrad, 2 wgrad}) as a rocprofv3 trace shows it."""
     buf = ctypes.create_string_buffer(128)
@@ -303,14 +286,6 @@ def _conv_flops(d, C):
 def _conv_bytes(d, C):
     """Algorithmic bytes of one conv pass: each of the three tensors (input, filter, output) crosses HBM once, fp32."""
     return 4 * (d.N * d.H * d.W * C + d.K * d.R * d.S * C + d.N * d.P * d.Q * d.K)
-
-
-def _presplit(w, n, dev):
-    """bf16x3 only: the three bf16 planes of an fp32 filter array (n elements), produced once per use by one small kernel so
-    that the convolution loop splits only its activation operand (include/segmi.h segmi_filter_presplit)."""
-    planes = torch.empty(lib.segmi_filter_presplit_bytes(n), dtype=torch.uint8, device=dev)
-    check(lib.segmi_filter_presplit(w.data_ptr(), n, planes.data_ptr(), _stream()), "filter_presplit")
-    return planes
 
 
 # Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/conv_winograd.hip): the DEFAULT algorithm of the eligible layers for
@@ -418,16 +393,12 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
             _BN_FUSE["emitted"] += 1
         return v
     bp = bias.data_ptr() if bias is not None else None
-    pre = _presplit(w, d.K * d.R * d.S * d.C, dev) if lib.segmi_conv2d_presplit_ok(d, 0) else None
     if bn_stats and not accumulate:
         parts = lib.segmi_conv2d_fwd_stats_parts(d)
         if parts > 0:
             part = torch.empty(parts * 3 * d.K, device=dev, dtype=torch.float32)
             with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-                if pre is not None:     # bf16x3 with pre-split filter planes: the same epilogue
-                    check(lib.segmi_conv2d_fwd_presplit_stats(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
-                else:
-                    check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
+                check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
             _BN_FUSE["last"] = (part, parts)
             _BN_FUSE["emitted"] += 1
             return None
@@ -435,10 +406,7 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
     ws = workspace(nws, dev) if nws else None
     wsp = ws.data_ptr() if ws is not None else None
     with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-        if pre is not None:
-            check(lib.segmi_conv2d_fwd_presplit(d, x.data_ptr(), pre.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
-        else:
-            check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
+        check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
 
 
 def _conv_wgrad(d, C, x, dy, dwb, v=None):
@@ -558,7 +526,7 @@ def _conv_wgrad_param(weight, d, C, x, dy, dwb, v=None):
 
 
 def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
-    """segmi_conv2d_dgrad (or its pre-split-filter form).  wt: flat CRSK filter of d.C * d.R * d.S * pad4(d.K) floats."""
+    """segmi_conv2d_dgrad (or its Winograd form).  wt: flat CRSK filter of d.C * d.R * d.S * pad4(d.K) floats."""
     dev, st = dy.device, _stream()
     if _winograd(d, 1):
         _WINOGRAD["calls"] += 1
@@ -568,12 +536,8 @@ def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
             check(lib.segmi_conv2d_winograd_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, ws.data_ptr(), nws, st),
                   "conv2d_winograd_dgrad")
         return
-    pre = _presplit(wt, d.C * d.R * d.S * pad4(d.K), dev) if lib.segmi_conv2d_presplit_ok(d, 1) else None
     with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
-        if pre is not None:
-            check(lib.segmi_conv2d_dgrad_presplit(d, dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
-        else:
-            check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
+        check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
 
 
 class _FilterTransposes:

@@ -6,6 +6,7 @@ What changed: the reference synchronises with the host twice per iteration (`los
 here the loss sum and the accuracy / IoU counters stay on the device (segmi_seg_metrics) and are read every `log_step`
 iterations and at the end of the epoch.  `iteration_losses` keeps the per-iteration loss tensors of the last epoch for tests.
 """
+import contextlib
 import time
 
 import numpy as np
@@ -105,7 +106,12 @@ class Trainer(BaseTrainer):
         self._reset_metrics()
         loss_sum = torch.zeros((), device=self.device)
         n_iter = 0
-        with torch.no_grad():
+        # validation batches are sharded over the ranks WITHOUT padding (every sample exactly once, base/base_dataloader.py), so
+        # ranks may run different numbers of iterations: nothing inside the loop may be a collective.  The losses' global-batch
+        # weighting IS one (an all-reduce of the valid-pixel count in forward), so it is switched off here — every rank takes
+        # the reference's per-batch mean of ITS batches and `_epoch_mean` all-reduces (sum, count) once, after the loop: the
+        # mean over all batches of the epoch, what the single-process reference computes (trainer.py:134-141)
+        with torch.no_grad(), self._per_rank_loss():
             for data, target in self.val_loader:
                 data, target = data.to(self.device, non_blocking=True), target.to(self.device, non_blocking=True)
                 output = self.model(data)
@@ -119,6 +125,18 @@ class Trainer(BaseTrainer):
         for k, v in list(seg_metrics.items())[:-1]:
             self.writer.add_scalar("%s/%s" % (self.wrt_mode, k), v, self.wrt_step)
         return {"val_loss": self.total_loss.average, **seg_metrics}
+
+    @contextlib.contextmanager
+    def _per_rank_loss(self):
+        """Inside: every loss module evaluates strictly per rank (process_group=None) — no collective in its forward."""
+        saved = [(m, m.process_group) for m in self.loss.modules() if hasattr(m, "process_group")]
+        for m, _ in saved:
+            m.process_group = None
+        try:
+            yield
+        finally:
+            for m, pg in saved:
+                m.process_group = pg
 
     def _epoch_mean(self, loss_sum, n_iter):
         """Mean per-iteration loss of the epoch over ALL ranks (every rank must take the same monitor / early-stop decision

@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 8
+    assert lib.segmi_abi_version() == 9
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
@@ -69,46 +69,21 @@ def test_status_strings_and_queries():
     assert lib.segmi_ce_workspace(1 << 21) > 0
 
 
-def test_conv_math_switch_and_variant_names():
-    """segmi_conv_set_math / get_math (include/segmi.h): two arithmetics, f32 (fp32 MFMA chain) and bf16x3; the variant name
-    reported for profiling carries the arithmetic as its last template argument, exactly as a rocprofv3 kernel trace prints
-    the instantiation.  The process default comes from SEGMI_CONV_MATH (library default otherwise) and is restored."""
+def test_variant_names_and_the_retired_second_arithmetic():
+    """The variant name reported for profiling is the kernel instantiation exactly as a rocprofv3 kernel trace prints it.  ABI v9:
+    the second convolution arithmetic of v3-v8 (bf16x3) is gone — no entry point, no environment switch, no
+    trailing MATH template argument."""
     from segmi import lib, ops
     from segmi._lib import ConvDesc
-    prev = ops.get_conv_math()
-    assert prev in ("f32", "bf16x3")
     d = ConvDesc(8, 64, 64, 512, 512, 3, 3, 64, 64, 1, 2, 2, 512, 512)
-    try:
-        ops.set_conv_math("f32")
-        assert lib.segmi_conv_get_math() == 0
-        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 0>"
-        for bad in (7, -1, 2, 3, 4):                      # 2-4 were round-1 A/B variants, removed after their hardware run
-            assert lib.segmi_conv_set_math(bad) == -1 and ops.get_conv_math() == "f32"
-        for name in ("tf32", "bf16x2", "bf16x3_simple"):
-            with pytest.raises(Exception):
-                ops.set_conv_math(name)
-        ops.set_conv_math("bf16x3")
-        assert lib.segmi_conv_get_math() == 1
-        # fprop / dgrad read the filter as pre-split bf16 planes where that applies (template argument 2) ...
-        assert lib.segmi_conv2d_presplit_ok(d, 0) == 1 and lib.segmi_conv2d_presplit_ok(d, 1) == 1
-        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 2>"
-        assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true, 2>"
-        assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true, 1>")
-        # ... and fall back to the in-register split otherwise: switched off, channels not a multiple of 8, strided dgrad
-        lib.segmi_conv_set_presplit(0)
-        assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>" and lib.segmi_conv2d_presplit_ok(d, 1) == 0
-        lib.segmi_conv_set_presplit(1)
-        assert lib.segmi_conv2d_presplit_ok(ConvDesc(8, 64, 64, 36, 512, 3, 3, 64, 64, 1, 1, 1, 36, 512), 0) == 0
-        assert lib.segmi_conv2d_presplit_ok(ConvDesc(8, 64, 64, 512, 512, 3, 3, 32, 32, 2, 1, 1, 512, 512), 1) == 0
-        assert lib.segmi_filter_presplit_bytes(1024) == 6 * 1024
-        # workspace planning does not depend on the arithmetic
-        assert lib.segmi_conv2d_wgrad_workspace(d) % (512 * 9 * 512 * 4) == 0
-    finally:
-        lib.segmi_conv_set_presplit(1)
-        ops.set_conv_math(prev)
-    ops.set_conv_math("f32")
-    assert lib.segmi_conv2d_presplit_ok(d, 0) == 0          # the fp32 MFMA path never takes planes
-    ops.set_conv_math(prev)
+    assert lib.segmi_abi_version() >= 9
+    assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true>"
+    assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true>"
+    assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true>")
+    for gone in ("segmi_conv_set_math", "segmi_conv_get_math", "segmi_filter_presplit", "segmi_conv2d_fwd_presplit"):
+        assert not hasattr(lib, gone), gone
+    assert not hasattr(ops, "set_conv_math")
+    assert lib.segmi_conv2d_wgrad_workspace(d) % (512 * 9 * 512 * 4) == 0
 
 
 def test_winograd_planning_and_dispatch_rules():
@@ -198,9 +173,7 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
         kern[name]["agpr_count"] = int(blk.split()[0])
     dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
-    # last template argument = MATH: 0 f32, 1 bf16x3, 2 bf16x3 with pre-split filter planes (fprop / dgrad, 64- and 128-wide tiles)
-    per_math = [sum(1 for n in dma if re.search(r"Li%dEEEv" % m, n)) for m in range(5)]
-    assert per_math == [28, 28, 16, 0, 0], per_math
+    assert len(dma) == 28, sorted(dma)          # 5 tile shapes x {fprop, dgrad} x {fast, generic} fprop/dgrad + 4 tiles x {ROWQ, generic} wgrad
     for n, v in dma.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
         # .vgpr_count is the unified total (arch VGPRs up to the accumulator offset + AGPRs); 2 x 256 = one SIMD's file

@@ -152,6 +152,10 @@ def test_loader_surface_batching_and_sharding():
     vl = sp.get_val_loader()
     assert len(sp.indices) == 15 and len(vl.indices) == 5 and not set(sp.indices.tolist()) & set(vl.indices.tolist())
     assert dataloaders.SynthImages(num_classes=2, batch_size=2, device="cpu").get_val_loader() is None
+    # the held-out split shards like its parent (an explicit rank= / world= used to be lost on the way)
+    sp2 = dataloaders.SynthImages(num_classes=5, batch_size=2, num_samples=20, crop_size=64, augment=True, val_split=0.5, device="cpu", rank=1, world=2)
+    vl2 = sp2.get_val_loader()
+    assert (vl2.rank, vl2.world) == (1, 2) and len(vl2) == 2 and [b.tolist() for b in vl2._batches()] == [vl2.indices[2:4].tolist(), vl2.indices[6:8].tolist()]
     # the training subset of a val_split loader is drawn in a new random order every epoch (the reference's
     # SubsetRandomSampler), whatever `shuffle` says
     e0 = sum((b.tolist() for b in sp._batches()), [])

@@ -3,9 +3,8 @@
 Every segmi kernel is deterministic (fixed-order split-K, no float atomics), so identical weights and batch must give identical
 bits on every repetition — also while another process perturbs the schedule on the same compute units, which is how the
 two-rank tests (and the driver's GPU suite) run on a one-GPU box.  Round 2 saw `bilinear_fwd_kernel` outputs differ under
-exactly these conditions with both processes on the bf16x3 convolution arithmetic (profiles/r02_two_process_repeatability.txt);
-since every HBM-bound file is built without the SLP vectoriser it has not recurred.  Both arithmetics are held
-to it here."""
+exactly these conditions with both processes on the since-retired bf16x3 convolution arithmetic
+(profiles/r02_two_process_repeatability.txt); every HBM-bound file has been built without the SLP vectoriser since."""
 import os
 import subprocess
 import sys
@@ -16,9 +15,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
-def test_two_processes_sharing_the_gpu_are_bitwise_repeatable(cuda, math):
-    env = dict(os.environ, SEGMI_CONV_MATH=math)
+def test_two_processes_sharing_the_gpu_are_bitwise_repeatable(cuda):
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_determinism.py"), "--procs", "2", "--iters", "25"],
                        env=env, capture_output=True, text=True, timeout=600)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])

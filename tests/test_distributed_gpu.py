@@ -199,21 +199,135 @@ def test_two_rank_syncbn_step_equals_global_batch_step(cuda):
     # running statistics: every rank holds the global-batch update
     for r in range(world):
         assert torch.allclose(ret[r]["rm"], ref["rm"], rtol=1e-4, atol=1e-6) and torch.allclose(ret[r]["rv"], ref["rv"], rtol=1e-4, atol=1e-6)
-    # gradients: identical on both ranks after the all-reduce.  Against the global-batch run only a coarse bound holds for
-    # this 50-layer net on 9x11 maps (batch-statistics gradients are ill conditioned, DESIGN.md §5: the two runs merge their
-    # BN moments in a different order); the tight equality is asserted on the shallow net above.
-    errs = []
+    # gradients: identical on both ranks after the all-reduce, and held against the ORACLE (the former bound was
+    # 10 % median / 30 % max against the HIP path's own single-process run).  Batch-statistics gradients of this 50-layer net on
+    # 9x11 maps are ill conditioned, so the bar is the measured rounding-noise floor of THIS problem: the CPU oracle
+    # (oracle/pspnet_ref.py on the concatenated global batch = the reference's convert_model-on-CPU semantics, batchnorm.py:65-68)
+    # evaluated in fp64 and in fp32; the 2-rank HIP gradients may be at most 1.5x (median over tensors) / 2x (max) as far from the
+    # fp64 gradients as the oracle's own fp32 run is — the full-size criterion, on whole tensors instead of digests.
     assert torch.equal(ret[0]["grads"], ret[1]["grads"])
+    import models
+    from oracle import losses_ref, pspnet_ref
+    torch.manual_seed(3)                               # = _build(classes, 3, dev) of rank 0, whose weights the wrapper broadcast
+    sd = models.PSPNet(5, backbone="resnet50", pretrained=False).state_dict()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(per * world, 3, 72, 88, generator=g)
+    T = torch.randint(0, 5, (per * world, 72, 88), generator=g)
+
+    def oracle_grads(dt):
+        st = pspnet_ref.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()})
+        o, a = pspnet_ref.pspnet_forward(st, X.to(dt), training=True)
+        (losses_ref.cross_entropy(o, T, 255) + 0.4 * losses_ref.cross_entropy(a, T, 255)).backward()
+        return o.detach(), {k: st[k].grad.detach().double().reshape(-1) for k in ret[0]["names"]}
+
+    o32, g32 = oracle_grads(torch.float32)
+    o64, g64 = oracle_grads(torch.float64)
+    hip_out = torch.cat([ret[r]["out"] for r in range(world)])
+    ref_d, hip_d = (o32.double() - o64).abs().max().item(), (hip_out.double() - o64).abs().max().item()
+    top = max(v.norm().item() for v in g64.values())
+    ref_e, hip_e = [], []
     off = 0
     for k, n in zip(ret[0]["names"], ret[0]["sizes"]):
-        g0, gref = ret[0]["grads"][off:off + n], ref["grads"][off:off + n]
+        g0 = ret[0]["grads"][off:off + n].double()
         off += n
-        errs.append((g0.double() - gref.double()).norm().item() / (gref.double().norm().item() + 1e-30))
-    errs.sort()
-    assert errs[len(errs) // 2] <= 0.1 and errs[-1] <= 0.3, (errs[len(errs) // 2], errs[-1])
+        if g64[k].norm().item() <= 1e-5 * top:          # analytically-zero gradients (conv bias in front of a batch-stat BN): pure noise
+            continue
+        ref_e.append(((g32[k] - g64[k]).norm() / g64[k].norm()).item())
+        hip_e.append(((g0 - g64[k]).norm() / g64[k].norm()).item())
+    import statistics
+    print("\n[2-rank SyncBN PSPNet-R50 4x3x72x88 vs the CPU oracle] logits: |HIP - fp64| %.2e, |oracle fp32 - fp64| %.2e; gradient rel-L2 from "
+          "fp64 over %d tensors: HIP median %.2e max %.2e, oracle fp32 median %.2e max %.2e"
+          % (hip_d, ref_d, len(hip_e), statistics.median(hip_e), max(hip_e), statistics.median(ref_e), max(ref_e)))
+    assert hip_d <= max(2.0 * ref_d, 1e-4 * o64.abs().max().item()), (hip_d, ref_d)
+    assert statistics.median(hip_e) <= 1.5 * statistics.median(ref_e) and max(hip_e) <= 2.0 * max(ref_e), (hip_e, ref_e)
     # per-bucket fused SGD after each bucket's all-reduce: SGD on the averaged gradient, replicas bit-identical afterwards
     assert ret[0]["sgd_rel_err"] <= 1e-5 and ret[1]["sgd_rel_err"] <= 1e-5, (ret[0]["sgd_rel_err"], ret[1]["sgd_rel_err"])
     assert torch.equal(ret[0]["w_after"], ret[1]["w_after"])
+
+
+def _cfg4_sync_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "pytorch-segmentation_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import models
+        from oracle.weights import synth_batch, synth_state_dict
+        from test_fullsize_golden_gpu import GOLD, collect_metrics, collect_step
+        from utils.losses import CrossEntropyLoss2d
+        from utils.sync_batchnorm import DataParallelWithCallback, convert_model
+        dev = torch.device("cuda:0")
+        rec = torch.load(os.path.join(GOLD, "full_cfg4_sync8.pt"), weights_only=False)
+        assert rec["syncbn"] and rec["arch"] == "PSPNet"
+        C, ign = rec["num_classes"], rec["ignore_index"]
+        N, _, H, W = rec["input_shape"]
+        per = N // world
+        net = models.PSPNet(C, pretrained=False, **rec["kwargs"])
+        net.load_state_dict(synth_state_dict(rec["manifest"], seed=rec["weight_seed"]))
+        net.to(dev).train()
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.eval()
+        m = DataParallelWithCallback(convert_model(net))          # the reference's call sequence, base/base_trainer.py:33-38
+        x, t = synth_batch(N, 3, H, W, C, ignore_index=ign, seed=rec["batch_seed"])
+        xd, td = x[rank * per:(rank + 1) * per].to(dev), t[rank * per:(rank + 1) * per].to(dev)
+        crit = CrossEntropyLoss2d(ignore_index=ign)                 # process_group="auto": the global batch's valid-pixel mean
+        m.zero_grad()
+        out, aux = m(xd)
+        loss = crit(out, td) + 0.4 * crit(aux, td)
+        loss.backward()
+        m.finish_gradients()
+        torch.cuda.synchronize()
+        got = collect_step(rec, m.module, out, aux, loss)
+        got["metrics"] = collect_metrics(rec, out, td)
+        got["collectives"] = sum(mod.sync.collectives for mod in m.module.modules() if getattr(mod, "sync", None) is not None)
+        got["grad_samples"] = torch.stack(got["grad_samples"])      # one tensor instead of 187 (file descriptors of the manager dict)
+        for k in list(got["wide"]):
+            got["wide"][k] = {st: v.clone() for st, v in got["wide"][k].items()}
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_syncbn_two_ranks_match_the_reference_global_batch_fixture(cuda):
+    """BASELINE cfg4's defining regime held against the oracle.  tests/golden/full_cfg4_sync8.pt = the REAL reference
+    PSPNet-R50 (19 classes) after its own `convert_model`, one CPU process, the concatenated GLOBAL batch 8 x 3 x 769 x 769 — where
+    `_SynchronizedBatchNorm.forward` is `F.batch_norm` over the global batch (utils/sync_batchnorm/batchnorm.py:65-68), the semantics the
+    GPU branch (:70-145) distributes.  Here: 2 ranks x 4 images on one MI355X through `convert_model` + `DataParallelWithCallback`
+    (Welford partial all-gather + Chan merge, backward-sum all-reduce, bucketed gradient averaging, global-batch loss weighting).
+    Each rank's logits / masks against ITS rows of the fixture, the summed loss, the all-reduced gradients against the fp64 oracle's
+    digests and whole-tensor statistics, the summed segmentation counters, the running statistics of both replicas — under the
+    UNCHANGED single-rank full-size criteria (`assert_audit`)."""
+    from test_fullsize_golden_gpu import GOLD, assert_audit, evaluate_audit, record_audit
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cfg4_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    got = [ret[r] for r in range(world)]
+    rec = torch.load(os.path.join(GOLD, "full_cfg4_sync8.pt"), weights_only=False)
+    # the replicas agree bit for bit on everything that is global: averaged gradients, running statistics
+    assert torch.equal(got[0]["grad_samples"], got[1]["grad_samples"]) and got[0]["grad_norms"] == got[1]["grad_norms"]
+    for k in got[0]["running"]:
+        assert torch.equal(got[0]["running"][k], got[1]["running"][k]), k
+    for k in got[0]["wide"]:
+        for st in got[0]["wide"][k]:
+            assert torch.equal(got[0]["wide"][k][st], got[1]["wide"][k][st]), (k, st)
+    N = rec["input_shape"][0]
+    whole = dict(got[0])
+    whole["mask"] = torch.cat([g["mask"] for g in got])
+    whole["osub"] = torch.cat([g["osub"] for g in got])
+    whole["aux"] = torch.cat([g["aux"] for g in got])
+    whole["shape"] = (N,) + tuple(got[0]["shape"][1:])
+    # every rank back-propagates W * local_sum / global_count (DESIGN §7.2): the mean over ranks is the global-batch loss
+    whole["loss"] = sum(g["loss"] for g in got) / world
+    whole["metrics"] = sum(g["metrics"] for g in got)
+    whole["grad_samples"] = list(got[0]["grad_samples"])
+    r = evaluate_audit(rec, whole, "cfg4_sync8")
+    r["ranks"], r["collectives_per_rank"] = world, got[0]["collectives"]
+    print("\n" + record_audit(r, "2 ranks x 4, SyncBN"))
+    assert_audit(r)
+    assert got[0]["collectives"] == got[1]["collectives"] > 0
 
 
 def _nccl_worker(rank, world, port, ret):
@@ -353,6 +467,69 @@ def test_two_rank_trainer_shards_data_and_agrees_on_epoch_results(cuda, tmp_path
     assert a["first"] != b["first"] and a["losses"] != b["losses"]            # different shards
     assert a["best"] == b["best"] and a["total_loss"] == b["total_loss"] and a["summary"] == b["summary"]
     assert torch.equal(a["w"], b["w"])
+
+
+def _valid_worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "pytorch-segmentation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        import dataloaders
+        import train
+        config = json.load(open(os.path.join(ROOT, "pytorch-segmentation_amd", "config.json")))
+        config["loss"] = ret["loss_name"]
+        config["train_loader"]["args"].update(height=64, width=64, iters=2)
+        val_args = dict(num_classes=2, batch_size=2, num_samples=6, min_size=70, max_size=90, crop_size=64, val=True, seed=5)   # 3 batches over 2 ranks
+        config["val_loader"] = {"type": "SynthImages", "args": val_args}
+        config["trainer"].update(save_dir=os.path.join(tmp, "ck"), log_dir=os.path.join(tmp, "log"), epochs=1, save_period=5)
+        tr = train.main(config, None)                   # one epoch incl. its validation pass: must not hang
+        log = tr._valid_epoch(1)                        # and again, directly
+        groups = [m.process_group for m in tr.loss.modules() if hasattr(m, "process_group")]
+        res = {"len": len(tr.val_loader), "val_loss": float(log["val_loss"]), "miou": float(log["Mean_IoU"]), "acc": float(log["Pixel_Accuracy"]),
+               "restored": bool(groups) and all(g == "auto" for g in groups)}
+        if rank == 0:
+            # the single-process value over ALL batches with the same replica: per-batch mean loss averaged over the batches
+            # (reference trainer.py:134-141), metrics from the summed counters
+            from utils.metrics import SegMetrics
+            full = dataloaders.SynthImages(rank=0, world=1, device=tr.device, **val_args)
+            crit = type(tr.loss)(ignore_index=255, process_group=None)
+            met = SegMetrics(2, tr.device)
+            tr.model.eval()
+            tot, n = 0.0, 0
+            with torch.no_grad():
+                for x, t in full:
+                    o = tr.model(x)
+                    tot += float(crit(o, t))
+                    met.update(o, t)
+                    n += 1
+            s = met.summary()
+            res["ref"] = {"n": n, "val_loss": tot / n, "miou": float(s["Mean_IoU"]), "acc": float(s["Pixel_Accuracy"])}
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss_name", ["CrossEntropyLoss2d", "DiceLoss"])
+def test_two_rank_validation_with_uneven_batch_counts(cuda, tmp_path, loss_name):
+    """validation loaders shard their batches without padding, so with 3 batches on 2 ranks the ranks run 2 and 1
+    iterations.  The losses' global-batch weighting is a collective in forward (CE: one all-reduce, Dice: three) — inside the
+    validation loop that would pair rank 0's second loss all-reduce with rank 1's epoch-end all-reduce (hang or garbage).
+    `Trainer._valid_epoch` evaluates the loss strictly per rank and all-reduces (sum, count) once: both ranks finish, agree, and
+    report the single-process mean over all 3 batches; the loss modules get their process group back afterwards."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ret["loss_name"] = loss_name
+    mp.spawn(_valid_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert (a["len"], b["len"]) == (2, 1)
+    assert a["val_loss"] == b["val_loss"] and a["miou"] == b["miou"] and a["acc"] == b["acc"]
+    assert a["restored"] and b["restored"]
+    ref = a["ref"]
+    assert ref["n"] == 3 and abs(a["val_loss"] - ref["val_loss"]) <= 1e-5 * max(1.0, abs(ref["val_loss"])) + 1e-5, (a["val_loss"], ref["val_loss"])
+    assert a["miou"] == ref["miou"] and a["acc"] == ref["acc"]
 
 
 def test_filter_gradients_are_written_straight_into_the_bucket(cuda):

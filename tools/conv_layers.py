@@ -44,7 +44,7 @@ with KernelTimer() as kt:
     step()
 rows = kt.by_detail()
 tot = sum(r[3] for r in rows)
-PEAK_TF = {"f32": 157.3}.get(ops.get_conv_math(), 2516.6 / 6)      # matrix-pipe ceiling of the arithmetic in algorithmic fp32 TFLOP/s
+PEAK_TF = 157.3      # fp32 MFMA ceiling, TFLOP/s
 PEAK_TB = 8.0                                                      # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 # roofline time of a launch = max(FLOPs / matrix peak, algorithmic bytes / HBM peak); "bound" names the larger term
 print("%-52s %-34s %3s %9s %7s %6s %6s %5s %6s" % ("variant", "geometry", "n", "ms", "TF/s", "TB/s", "%roof", "bound", "%step"))
@@ -53,4 +53,4 @@ for name, det, n, ms, fl, nb in rows:
     roof = max(t_m, t_h)
     print("%-52s %-34s %3d %9.3f %7.1f %6.2f %6.1f %5s %6.2f" % (name, det, n, ms, fl / ms / 1e9, nb / ms / 1e9, 100 * roof / (ms * 1e-3),
                                                               "mfma" if t_m >= t_h else "hbm", 100 * ms / tot))
-print("total conv ms %.2f, %.1f TF/s (%s arithmetic: matrix ceiling %.1f TF/s, HBM %.1f TB/s)" % (tot, sum(r[4] for r in rows) / tot / 1e9, ops.get_conv_math(), PEAK_TF, PEAK_TB))
+print("total conv ms %.2f, %.1f TF/s (fp32 MFMA: matrix ceiling %.1f TF/s, HBM %.1f TB/s)" % (tot, sum(r[4] for r in rows) / tot / 1e9, PEAK_TF, PEAK_TB))

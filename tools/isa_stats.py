@@ -2,10 +2,10 @@
 """Static look at the compiled conv kernels (no GPU): registers / scratch per instantiation and, for the K loops, the
 instruction mix and how VALU work is interleaved with the matrix instructions.
 
-    python tools/isa_stats.py ["kernel name prefix" ...]     # default: the 128x128 fprop / wgrad kernels, both arithmetics
+    python tools/isa_stats.py ["kernel name prefix" ...]     # default: the 128x128 fprop / dgrad / wgrad kernels
 
 Compiles csrc/conv_igemm.hip to gfx950 assembly (hipcc -S --cuda-device-only) under /tmp and parses it.  Used to check the
-software pipeline of the bf16x3 loops: every `M[v8 ...]` group = one MFMA with 8 VALU in its shadow.
+K loops: every `M[v8 ...]` group = one MFMA with 8 VALU in its shadow.
 """
 import collections
 import os
@@ -16,8 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "pytorch-segmentation_amd", "csrc", "conv_igemm.hip")
 ASM = "/tmp/segmi_conv_igemm.s"
-DEFAULT = ["conv_dma_kernel<128, 128, 2, 2, 0, true, 0>", "conv_dma_kernel<128, 128, 2, 2, 0, true, 1>",
-           "conv_wgrad_dma_kernel<128, 128, true, 0>", "conv_wgrad_dma_kernel<128, 128, true, 1>"]
+DEFAULT = ["conv_dma_kernel<128, 128, 2, 2, 0, true>", "conv_dma_kernel<128, 128, 2, 2, 1, true>", "conv_wgrad_dma_kernel<128, 128, true>"]
 
 
 def demangle(n):
