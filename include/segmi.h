@@ -163,6 +163,17 @@ int segmi_dwconv2d_fwd(const segmi_conv_desc* d, const float* x, const float* w_
 int segmi_dwconv2d_fwd_stats_parts(const segmi_conv_desc* d);
 int segmi_dwconv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats_partials,
                              segmi_stream_t stream);
+/* The same convolution reading the PRE-NORMALISATION tensor z of the BatchNorm(+ReLU) in front of it (3x3, stride 1, pad == dil in
+ * {1, 2}: segmi_dwconv2d_pre_ok): every tap is max(fmaf(z, pre_scale[c], pre_shift[c]), 0) (ReLU when pre_relu) evaluated on the loaded
+ * value — segmi_bn_apply's own expression, zero padding applied AFTER it — so the result equals segmi_bn_apply followed by
+ * segmi_dwconv2d_fwd(_stats) bit for bit, and the normalised tensor between a pointwise convolution's BatchNorm and the next depthwise
+ * layer (models/deeplabv3_plus.py:99-119: ReLU -> SeparableConv2d inside Block.rep) is never written or read.  stats_partials may be
+ * NULL.  segmi_dwconv2d_wgrad_pre is the filter gradient with the same fused load of its x operand. */
+int segmi_dwconv2d_pre_ok(const segmi_conv_desc* d);
+int segmi_dwconv2d_fwd_pre(const segmi_conv_desc* d, const float* z, const float* pre_scale, const float* pre_shift, int pre_relu,
+                           const float* w_rsc, float* y, float* stats_partials, segmi_stream_t stream);
+int segmi_dwconv2d_wgrad_pre(const segmi_conv_desc* d, const float* z, const float* pre_scale, const float* pre_shift, int pre_relu,
+                             const float* dy, float* dw_rsc, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream);
 size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d);
 int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
@@ -225,14 +236,10 @@ int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, floa
 size_t segmi_bn_bwd_reduce_workspace(long rows, int C);
 /* ReLU mask source: y (the saved output) when given; y == NULL (allowed when no residual was added) recomputes
  * fmaf(x, scale, shift) > 0 exactly as bn_apply evaluated it, saving one full read of y per pass.
- * tickets (optional): SEGMI_BN_TICKETS uint32 the caller keeps per stream, ZERO before their first use; every call leaves
- * them zero.  With tickets the row partials are added by the last workgroup of each channel column (fixed order: the result
- * does not depend on which one that is) and the call is ONE launch; NULL keeps the separate summation launch.  sums must be
- * 16-byte aligned for the one-launch form. */
-#define SEGMI_BN_TICKETS 256
+ * Two launches: row partials in fp64, then their sum (a one-launch form with ticket counters was measured slower and removed in ABI v9). */
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                         const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
-                        float* sums, void* workspace, size_t workspace_bytes, unsigned* tickets, segmi_stream_t stream);
+                        float* sums, void* workspace, size_t workspace_bytes, segmi_stream_t stream);
 /* dgamma = sums[C:2C], dbeta = sums[0:C];
  * training: dx = scale*(dy' - sums0/count - xhat*sums1/count); eval (frozen): dx = scale*dy'.
  * d_residual (optional) = dy'.  `count` is the (global) element count per channel; when count_dev != NULL it is read

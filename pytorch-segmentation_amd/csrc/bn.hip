@@ -204,8 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            double* __restrict__ part, unsigned* __restrict__ tickets,
-                                                            float* __restrict__ sums) {
+                                                            double* __restrict__ part) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 < c4n;
     D4 s0 = dzero4(), s1 = dzero4();
@@ -264,84 +263,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const D4 a = sm0[t], b = sm1[t];
         const float4 is = ld4(invstd + c4 * 4);
         const double v[8] = {a.x, a.y, a.z, a.w, b.x * (double)is.x, b.y * (double)is.y, b.z * (double)is.z, b.w * (double)is.w};
-        if (tickets) {
-            // device-scope stores (write through the XCD's L2): the workgroup that sums them may run on another XCD
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __hip_atomic_store(o + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o + Cp + i, v[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-            o[Cp] = v[4]; o[Cp + 1] = v[5]; o[Cp + 2] = v[6]; o[Cp + 3] = v[7];
-        }
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        o[Cp] = v[4]; o[Cp + 1] = v[5]; o[Cp + 2] = v[6]; o[Cp + 3] = v[7];
     }
-    if (!tickets) return;                                // two-launch form: sum_parts_kernel adds the row partials
-    // Last workgroup of this channel column adds the column's row partials itself — one launch instead of two (the ~5 us
-    // sum_parts launch was a third of a call on 24 MB tensors: 141 BN layers per DeepLab-Xception step).  The XCDs' L2s are not
-    // coherent with each other for ordinary accesses, and agent-scope fences (__threadfence: L2 write-back + invalidate in
-    // every workgroup) cost 160 us per call — measured, cfg2 56.7 -> 66.5 ms.  So the partials themselves travel as DEVICE-SCOPE
-    // relaxed atomic stores / loads (sc1: through the L2 to the coherence point, no cache maintenance): a workgroup waits for
-    // its stores to be acknowledged (vmcnt), then takes its ticket; the last one reads the partials with device-scope loads.
-    // They are added in a FIXED order (row partial p by thread row p % ry, then a tree over the thread rows), so the result does
-    // not depend on which workgroup happens to be last: deterministic.  The counter is handed back at 0 for the next call.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ unsigned last;
-    __syncthreads();
-    if (t == 0) last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    D4 a0 = dzero4(), a1 = dzero4();
-    if (cok) {
-        const int Cp = c4n * 4;
-        auto ldc = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        for (int p = threadIdx.y; p < (int)gridDim.y; p += blockDim.y) {
-            const double* q = part + (long)p * 2 * Cp + c4 * 4;
-            a0.x += ldc(q); a0.y += ldc(q + 1); a0.z += ldc(q + 2); a0.w += ldc(q + 3);
-            a1.x += ldc(q + Cp); a1.y += ldc(q + Cp + 1); a1.z += ldc(q + Cp + 2); a1.w += ldc(q + Cp + 3);
-        }
-    }
-    sm0[t] = a0; sm1[t] = a1;
-    __syncthreads();
-    for (int s = blockDim.y >> 1; s > 0; s >>= 1) {
-        if ((int)threadIdx.y < s) {
-            D4 a = sm0[t], b = sm0[t + s * blockDim.x];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm0[t] = a;
-            a = sm1[t]; b = sm1[t + s * blockDim.x];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; sm1[t] = a;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.y == 0 && cok) {
-        const int C = c4n * 4;
-        const D4 a = sm0[t], b = sm1[t];
-        st4(sums + c4 * 4, make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w));
-        st4(sums + C + c4 * 4, make_float4((float)b.x, (float)b.y, (float)b.z, (float)b.w));
-    }
-    if (t == 0) tickets[blockIdx.x] = 0u;
+    // (sum_parts_kernel adds the row partials.  Folding that second launch into this kernel — the last workgroup of a channel column
+    //  sums the column's partials, found by a ticket counter — was built and measured slower twice in round 5, with agent-scope
+    //  fences and with device-scope atomics, profiles/r05_bn_tickets_ab.txt; removed in round 6.)
 }
-
-// out[i] = (float) sum_p part[p][i] in double; block = (32 elements, 8 part lanes), LDS tree over the lanes
-__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+// out[i] = (float) sum_p part[p][i] in double; block = (32 elements, 32 part lanes): every lane issues ALL its (<= 16 at the 512-part
+// cap) loads before the first add — the 8-lane form of rounds 4-5 walked 64 partials per lane in 16 dependent round trips: 6.5 us
+// per call, 61-141 calls per step — then a fixed-order sum over the 32 lanes through LDS (deterministic).
+__global__ __launch_bounds__(1024) void sum_parts_kernel(const double* __restrict__ part, int nparts, int n, float* __restrict__ out) {
     const int i = blockIdx.x * 32 + threadIdx.x;
     double a = 0.0;
     if (i < n) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // four independent loads per step
-        int p = threadIdx.y;
-        for (; p + 24 < nparts; p += 32) {
-            a0 += part[(long)p * n + i]; a1 += part[(long)(p + 8) * n + i];
-            a2 += part[(long)(p + 16) * n + i]; a3 += part[(long)(p + 24) * n + i];
+        for (int p0 = threadIdx.y; p0 < nparts; p0 += 32 * 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + 32 * u;
+                v[u] = p < nparts ? part[(long)p * n + i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
         }
-        for (; p < nparts; p += 8) a0 += part[(long)p * n + i];
-        a = (a0 + a1) + (a2 + a3);
     }
-    __shared__ double sm[8][33];
+    __shared__ double sm[32][33];
     sm[threadIdx.y][threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.y == 0 && i < n) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) t += sm[k][threadIdx.x];
         out[i] = (float)t;
     }
 }
@@ -663,7 +616,7 @@ size_t segmi_bn_bwd_reduce_workspace(long rows, int C) {
 
 int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, long rows, int C,
                         const float* mean, const float* invstd, const float* scale, const float* shift, int relu, float* sums,
-                        void* workspace, size_t workspace_bytes, unsigned* tickets, segmi_stream_t stream) {
+                        void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
     if (!dy || !x || !mean || !invstd || !sums || rows <= 0 || C <= 0 || (relu && !y && (!scale || !shift))) return SEGMI_ERR_BADARG;
     if ((C & 3) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || (relu && y && !ld_ok(ldy, C))) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_bn_bwd_reduce_workspace(rows, C)) return SEGMI_ERR_WORKSPACE;
@@ -672,13 +625,9 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     if ((uintptr_t)workspace & 7) return SEGMI_ERR_ALIGN;
-    // one launch when the caller lends a ticket array (SEGMI_BN_TICKETS uint32, zero before its first use, left zero by every call,
-    // never shared by calls that may run concurrently: one per stream); two launches otherwise
-    if (tickets && ((int)g.grid.x > SEGMI_BN_TICKETS || ((uintptr_t)sums & 15) || parts < 2)) tickets = nullptr;
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, tickets, sums);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, tickets, sums);
-    if (!tickets)
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 8), 0, st, (const double*)workspace, parts, 2 * C, sums);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 32), 0, st, (const double*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
 

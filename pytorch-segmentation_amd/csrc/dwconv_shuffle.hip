@@ -176,10 +176,21 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 // 4.5 float4 loads per output for D = 1 instead of 9 (the one-output-per-thread kernels above are load-issue bound: 28 us per
 // 728-channel 32x32 layer whose tensors stream in 10 us).
 // FLIP: the filter is read rotated by 180 degrees — the data gradient of the same convolution (dx = dy (*) rot180(w)).
-template <int D, bool FLIP, bool STATS>
+// PRE (round 6): the input is the PRE-NORMALISATION tensor z of the BatchNorm(+ReLU) in front of this layer; every tap is
+// max(fmaf(z, scale[c], shift[c]), 0) evaluated on the loaded value — bn_apply_kernel's own expression, so the result equals
+// bn_apply followed by the plain kernel bit for bit — and the normalised tensor between a pointwise convolution's BatchNorm and the
+// next depthwise layer (Xception: models/deeplabv3_plus.py:99-119) is never written or read.  Taps outside the image are zeros of
+// the NORMALISED tensor (zero padding applies after the BatchNorm), not transforms of a zero.
+__device__ __forceinline__ float4 dw_pre(float4 v, const float4& sc, const float4& sh, bool relu) {
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+template <int D, bool FLIP, bool STATS, bool PRE>
 __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, int ldy, int N, int H, int W, int C,
-                                                          float* __restrict__ stats) {
+                                                          float* __restrict__ stats, const float* __restrict__ pre_scale,
+                                                          const float* __restrict__ pre_shift, int pre_relu) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 * 4 < C;
     if (!STATS && !cok) return;
@@ -189,6 +200,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
     float4 wt[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t] = ld4(w + (long)(FLIP ? 8 - t : t) * C + c4 * 4);
+    const float4 psc = PRE ? ld4(pre_scale + c4 * 4) : zero4(), psh = PRE ? ld4(pre_shift + c4 * 4) : zero4();
     const int QS = (W + 3) >> 2;
     const long strips = (long)N * H * QS;
     for (long sidx = (long)blockIdx.y * blockDim.y + threadIdx.y; sidx < strips; sidx += (long)gridDim.y * blockDim.y) {
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4 + 2 * D; ++j) {
                 const int ww = q0 - D + j;
-                v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
+                v[j] = (unsigned)ww < (unsigned)W ? (PRE ? dw_pre(ld4(rowp + (long)ww * ldx), psc, psh, pre_relu != 0) : ld4(rowp + (long)ww * ldx)) : zero4();
             }
 #pragma unroll
             for (int s2 = 0; s2 < 3; ++s2) {
@@ -232,14 +244,17 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
 }
 
 // filter gradient of the same convolutions, same strips: part[blockIdx.y][t][C] = sum over this block's strips of dy (x) x-taps
-template <int D>
+template <int D, bool PRE>
 __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
-                                                                float* __restrict__ part, int N, int H, int W, int C) {
+                                                                float* __restrict__ part, int N, int H, int W, int C,
+                                                                const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
+                                                                int pre_relu) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 * 4 < C;
     float4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = zero4();
+    const float4 psc = (PRE && cok) ? ld4(pre_scale + c4 * 4) : zero4(), psh = (PRE && cok) ? ld4(pre_shift + c4 * 4) : zero4();
     const int QS = (W + 3) >> 2;
     const long strips = (long)N * H * QS;
     if (cok)
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 4 + 2 * D; ++j) {
                     const int ww = q0 - D + j;
-                    v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
+                    v[j] = (unsigned)ww < (unsigned)W ? (PRE ? dw_pre(ld4(rowp + (long)ww * ldx), psc, psh, pre_relu != 0) : ld4(rowp + (long)ww * ldx)) : zero4();
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 3; ++s2)
@@ -401,17 +416,25 @@ static RowGeom dw_fwd_geom(const segmi_conv_desc* d, int strip) {
     if (strip) return row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
     return row_geom((long)d->N * d->P * d->Q, d->C, 2, SEGMI_MAX_GRID);
 }
-static int dw_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats, segmi_stream_t stream) {
+static int dw_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats, segmi_stream_t stream,
+                       const float* pre_scale = nullptr, const float* pre_shift = nullptr, int pre_relu = 0) {
     if (!dw_ok(d) || !x || !w_rsc || !y) return SEGMI_ERR_BADARG;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return SEGMI_ERR_BADARG;
+    if (pre_scale && !dw_strip(d)) return SEGMI_ERR_BADARG;               // the fused-BatchNorm load exists in the strip kernels only
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     if (stats && ((uintptr_t)stats & 15)) return SEGMI_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int D = dw_strip(d);
     const RowGeom g = dw_fwd_geom(d, D);
     if (D) {
-#define SEGMI_DW_STRIP(DV, SV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, false, SV>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C, stats)
-        if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true); else SEGMI_DW_STRIP(1, false); }
-        else        { if (stats) SEGMI_DW_STRIP(2, true); else SEGMI_DW_STRIP(2, false); }
+#define SEGMI_DW_STRIP(DV, SV, PV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, false, SV, PV>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C, stats, pre_scale, pre_shift, pre_relu)
+        if (pre_scale) {
+            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, true); else SEGMI_DW_STRIP(1, false, true); }
+            else        { if (stats) SEGMI_DW_STRIP(2, true, true); else SEGMI_DW_STRIP(2, false, true); }
+        } else {
+            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, false); else SEGMI_DW_STRIP(1, false, false); }
+            else        { if (stats) SEGMI_DW_STRIP(2, true, false); else SEGMI_DW_STRIP(2, false, false); }
+        }
 #undef SEGMI_DW_STRIP
         return segmi_launch_status();
     }
@@ -435,14 +458,22 @@ int segmi_dwconv2d_fwd_stats(const segmi_conv_desc* d, const float* x, const flo
     return dw_fwd_impl(d, x, w_rsc, y, stats_partials, stream);
 }
 
+int segmi_dwconv2d_pre_ok(const segmi_conv_desc* d) { return (dw_ok(d) && !(d->C & 3) && dw_strip(d)) ? 1 : 0; }
+
+int segmi_dwconv2d_fwd_pre(const segmi_conv_desc* d, const float* z, const float* pre_scale, const float* pre_shift, int pre_relu,
+                           const float* w_rsc, float* y, float* stats_partials, segmi_stream_t stream) {
+    if (!pre_scale || !pre_shift) return SEGMI_ERR_BADARG;
+    return dw_fwd_impl(d, z, w_rsc, y, stats_partials, stream, pre_scale, pre_shift, pre_relu);
+}
+
 int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float* w_rsc, float* dx, segmi_stream_t stream) {
     if (!dw_ok(d) || !dy || !w_rsc || !dx) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     const long rows = (long)d->N * d->H * d->W;
     if (const int D = dw_strip(d)) {          // dx = dy (*) rot180(w): the forward strip kernel with the filter read flipped
         RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
-        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr);
-        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr);
+        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true, false, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
+        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true, false, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
         return segmi_launch_status();
     }
     RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
@@ -455,9 +486,10 @@ size_t segmi_dwconv2d_wgrad_workspace(const segmi_conv_desc* d) {
     return (size_t)dw_parts((long)d->N * d->P * d->Q, d->C) * d->R * d->S * d->C * sizeof(float);
 }
 
-int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
-                         size_t workspace_bytes, segmi_stream_t stream) {
+static int dw_wgrad_impl(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
+                         size_t workspace_bytes, segmi_stream_t stream, const float* pre_scale, const float* pre_shift, int pre_relu) {
     if (!dw_ok(d) || !x || !dy || !dw_rsc) return SEGMI_ERR_BADARG;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr) || (pre_scale && !dw_strip(d))) return SEGMI_ERR_BADARG;
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < segmi_dwconv2d_wgrad_workspace(d)) return SEGMI_ERR_WORKSPACE;
     const long rows = (long)d->N * d->P * d->Q;
@@ -466,13 +498,26 @@ int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* 
     g.grid.y = parts;
     hipStream_t st = (hipStream_t)stream;
     if (const int D = dw_strip(d)) {
-        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<1>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C);
-        else        hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<2>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C);
+#define SEGMI_DW_WG(DV, PV) hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<DV, PV>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C, pre_scale, pre_shift, pre_relu)
+        if (pre_scale) { if (D == 1) SEGMI_DW_WG(1, true); else SEGMI_DW_WG(2, true); }
+        else           { if (D == 1) SEGMI_DW_WG(1, false); else SEGMI_DW_WG(2, false); }
+#undef SEGMI_DW_WG
     } else
     hipLaunchKernelGGL((dwconv_wgrad_kernel<9>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, dw_geom(d));
     const int n = d->R * d->S * d->C;
     hipLaunchKernelGGL(dw_sum_parts_kernel, dim3(segmi_cdiv(n, 32)), dim3(32, 8), 0, st, (const float*)workspace, parts, n, dw_rsc);
     return segmi_launch_status();
+}
+
+int segmi_dwconv2d_wgrad(const segmi_conv_desc* d, const float* x, const float* dy, float* dw_rsc, void* workspace,
+                         size_t workspace_bytes, segmi_stream_t stream) {
+    return dw_wgrad_impl(d, x, dy, dw_rsc, workspace, workspace_bytes, stream, nullptr, nullptr, 0);
+}
+
+int segmi_dwconv2d_wgrad_pre(const segmi_conv_desc* d, const float* z, const float* pre_scale, const float* pre_shift, int pre_relu,
+                             const float* dy, float* dw_rsc, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!pre_scale || !pre_shift) return SEGMI_ERR_BADARG;
+    return dw_wgrad_impl(d, z, dy, dw_rsc, workspace, workspace_bytes, stream, pre_scale, pre_shift, pre_relu);
 }
 
 int segmi_depth_to_space2(const float* src, int ld_src, float* dst, int ld_dst, const float* bias, int N, int H, int W, int K,

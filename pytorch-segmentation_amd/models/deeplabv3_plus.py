@@ -185,6 +185,17 @@ class SeparableConv2d(nn.Module):
     def forward(self, x):
         return self.pointwise(self.bn(self.conv1(x)))
 
+    def bn_fusable(self, bn):
+        """Can this layer take the PRE-normalisation input of `bn` (+ReLU) — segmi.ops.batch_norm_depthwise?"""
+        return ops.batch_norm_depthwise_ok(bn, self.conv1)
+
+    def forward_bn(self, z, bn, relu=True):
+        """self(relu(bn(z))) with the BatchNorm + ReLU applied inside the depthwise kernels' loads (the reference's
+        `BatchNorm2d -> ReLU -> SeparableConv2d` runs of Block.rep and of the exit flow, models/deeplabv3_plus.py:99-119, 225-232):
+        the normalised tensor is never written or read — bit-identical to the separate passes."""
+        fuse = self.conv1._bn_consumer and torch.is_grad_enabled()
+        return self.pointwise(self.bn(ops.batch_norm_depthwise(z, bn, self.conv1, relu=relu, bn_stats=fuse)))
+
 
 class Block(nn.Module):
     fused_tail = os.environ.get("SEGMI_XCEPTION_FUSED_TAIL", "1") == "1"     # `+ skip` (+ the consumer's ReLU) inside the last BatchNorm's pass
@@ -268,9 +279,11 @@ class Xception(nn.Module):
         for i in range(4, 20):
             x = getattr(self, "block%d" % i)(x, relu_in=False, relu_out=True)
         x = self.block20(x, relu_in=False, relu_out=True)           # + the F.relu that follows block20 (:223-224)
-        x = self.bn3(self.conv3(x), relu=True)
-        x = self.bn4(self.conv4(x), relu=True)
-        x = self.bn5(self.conv5(x), relu=True)
+        # exit flow: bn3 / bn4 (+ReLU) feed the next SeparableConv2d only — applied inside its depthwise kernel (SeparableConv2d.forward_bn)
+        x = self.conv3(x)
+        for bn, conv in ((self.bn3, self.conv4), (self.bn4, self.conv5)):
+            x = conv.forward_bn(x, bn, relu=True) if conv.bn_fusable(bn) else conv(bn(x, relu=True))
+        x = self.bn5(x, relu=True)
         return x, low_level_features
 
 

@@ -64,6 +64,9 @@ SIGNATURES = {
     "segmi_dwconv2d_fwd_stats_parts": (i32, [PD]),
     "segmi_dwconv2d_fwd_stats": (i32, [PD, vp, vp, vp, vp, vp]),
     "segmi_dwconv2d_dgrad": (i32, [PD, vp, vp, vp, vp]),
+    "segmi_dwconv2d_pre_ok": (i32, [PD]),
+    "segmi_dwconv2d_fwd_pre": (i32, [PD, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "segmi_dwconv2d_wgrad_pre": (i32, [PD, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
     "segmi_dwconv2d_wgrad_workspace": (sz, [PD]),
     "segmi_dwconv2d_wgrad": (i32, [PD, vp, vp, vp, vp, sz, vp]),
     "segmi_depth_to_space2": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
@@ -80,7 +83,7 @@ SIGNATURES = {
     "segmi_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     "segmi_bn_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
     "segmi_bn_bwd_reduce_workspace": (sz, [i64, i32]),
-    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp, vp]),
+    "segmi_bn_bwd_reduce": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
     "segmi_bn_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "segmi_relu_fwd": (i32, [vp, i32, vp, i32, i64, i32, vp]),
     "segmi_relu_bwd": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),

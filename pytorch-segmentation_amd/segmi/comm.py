@@ -43,6 +43,17 @@ class AbiCommunicator:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    MAX_PENDING = 48      # below the library's ring of 64 per-call events: an unwaited ticket must still be orderable when it is retired
+
+    def _hold(self, ticket, tensors):
+        """Keep the buffers of collective `ticket` referenced until a wait covers it.  A caller that never waits (a backward
+        without finish(), an exception between enqueue and wait) must not grow this table without bound: beyond
+        MAX_PENDING entries the current stream is ordered behind the OLDEST half — collectives run in order on the
+        communicator's stream, so by then they are long complete and the wait is free — and their buffers are released."""
+        if len(self._pending) >= self.MAX_PENDING:
+            self.wait(sorted(self._pending)[len(self._pending) // 2 - 1])
+        self._pending[ticket] = tensors
+
     def _check(self, *tensors):
         for t in tensors:
             if t.dtype != torch.float32 or not t.is_cuda or t.device != self.device or not t.is_contiguous():
@@ -59,7 +70,7 @@ class AbiCommunicator:
                   "comm_allreduce_async")
         self.last_ticket = ticket.value
         # the side stream reads / writes these buffers: they stay referenced until a wait() has ordered a stream behind the call
-        self._pending[self.last_ticket] = (t, out)
+        self._hold(self.last_ticket, (t, out))
         return out
 
     def all_gather_async(self, t):
@@ -72,7 +83,7 @@ class AbiCommunicator:
         with torch.cuda.device(self.device):
             check(lib.segmi_comm_allgather_async(self._h, src.data_ptr(), out.data_ptr(), src.numel(), C.byref(ticket), self._stream()), "comm_allgather_async")
         self.last_ticket = ticket.value
-        self._pending[self.last_ticket] = (src, out)     # incl. the contiguous copy: freed only after a wait() covers this call
+        self._hold(self.last_ticket, (src, out))         # incl. the contiguous copy: freed only after a wait() covers this call
         return out
 
     def wait(self, ticket=None):

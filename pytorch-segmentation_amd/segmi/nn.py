@@ -177,12 +177,19 @@ def residual_out(x_last, bn, downsample, x, identity, proj=None):
 
 
 def run_fused(modules, x):
-    """Run a module chain, fusing BatchNorm2d -> ReLU pairs into one apply pass."""
+    """Run a module chain, fusing BatchNorm2d -> ReLU pairs into one apply pass — or, when the consumer can take the
+    PRE-normalisation tensor (a module with `forward_bn`, e.g. SeparableConv2d: its depthwise kernel applies the BatchNorm + ReLU
+    on the loaded taps, ops.batch_norm_depthwise), into the consumer itself: the normalised tensor is then never materialised."""
     mods = list(modules)
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            nxt = mods[i + 2] if i + 2 < len(mods) else None
+            if nxt is not None and hasattr(nxt, "forward_bn") and nxt.bn_fusable(m):
+                x = nxt.forward_bn(x, m, relu=True)
+                i += 3
+                continue
             x = m(x, relu=True)
             i += 2
             continue

@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "conv2d_fan", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "sync_groupable", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "batch_norm_depthwise", "batch_norm_depthwise_ok", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -52,28 +52,6 @@ def workspace(nbytes, device):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
-
-
-_BN_TICKETS = {}
-# SEGMI_BN_TICKETS=1: bn_bwd_reduce sums its row partials in the last workgroup of each channel column (one launch) instead of a
-# second launch.  OFF by default — measured negative in one call each (profiles/r05_bn_tickets_ab.txt): with agent-scope fences
-# cfg2 56.7 -> 66.5 ms (every workgroup's __threadfence writes back / invalidates its XCD's L2: +160 us per call); with
-# device-scope (sc1) atomic stores / loads and no cache maintenance cfg2 56.6 -> 58.8, cfg5 54.3 -> 55.1, cfg3 82.8 -> 85.2 ms:
-# the last workgroup's serial walk over up to 512 partials (one CU, ~2 us per dependent round trip) is longer than the ~5 us
-# launch it replaces, and nothing else runs beside it.  Kept as a tested opt-in.
-_BN_TICKETS_ON = os.environ.get("SEGMI_BN_TICKETS", "0") == "1"
-
-
-def _bn_tickets(device):
-    """Per-(device, stream) ticket counters of segmi_bn_bwd_reduce's one-launch form: zero at creation, every call leaves them zero;
-    calls on one stream run in order, so they never share a counter concurrently.  None switches to the two-launch form."""
-    if not _BN_TICKETS_ON:
-        return None
-    key = (device.index, _stream())
-    t = _BN_TICKETS.get(key)
-    if t is None:
-        t = _BN_TICKETS[key] = torch.zeros(256, dtype=torch.int32, device=device)
-    return t.data_ptr()
 
 
 # --------------------------------------------------------------------------- layout helpers
@@ -1032,6 +1010,65 @@ def _note_bn_consumer(x, batch_stats):
         mod._bn_consumer = False
 
 
+def _bn_coefficients(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, sync, pstats):
+    """The statistics half of a BatchNorm layer on the NHWC tensor x: coef = mean | invstd | scale | shift | global count (4*C + 4
+    floats) from the producer's partials, a pass over x, the gathered partials of all ranks (SyncBN) or the running statistics;
+    running statistics updated like nn.BatchNorm2d.  Returns (coef, count) — count None when it lives on the device (SyncBN)."""
+    N, C, H, W = x.shape
+    rows = N * H * W
+    dev, st = x.device, _stream()
+    coef = torch.empty(4 * C + 4, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift | global count (SyncBN)
+    mean, invstd, scale, shift = (coef[i * C:(i + 1) * C] for i in range(4))
+    gp = gamma.data_ptr() if gamma is not None else None
+    bp = beta.data_ptr() if beta is not None else None
+    count = float(rows)
+    rm = running_mean.data_ptr() if running_mean is not None else None
+    rv = running_var.data_ptr() if running_var is not None else None
+    nbt = num_batches_tracked.data_ptr() if num_batches_tracked is not None else None
+    if training and pstats is not None and (sync is not None or rows > 1):
+        part, nparts = pstats
+        nws = lib.segmi_bn_parts_workspace(nparts, C)
+        ws = workspace(nws, dev)
+        _BN_FUSE["consumed"] += 1
+        if sync is None:
+            check(lib.segmi_bn_finalize_from_parts(part.data_ptr(), nparts, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
+                                                   mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   ws.data_ptr(), nws, st), "bn_finalize_from_parts")
+        else:
+            one = torch.empty(3 * C, device=dev, dtype=torch.float32)
+            check(lib.segmi_bn_stats_from_parts(part.data_ptr(), nparts, C, one.data_ptr(), ws.data_ptr(), nws, st), "bn_stats_from_parts")
+            allp, nall = sync.gather_stats(one)
+            count = None
+            check(lib.segmi_bn_finalize(allp.data_ptr(), nall, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
+                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                        coef.data_ptr() + 16 * C, st), "bn_finalize")
+    elif training and sync is None:
+        if rows <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        nws = lib.segmi_bn_stats_workspace(rows, C)
+        ws = workspace(nws, dev)
+        check(lib.segmi_bn_stats_finalize(x.data_ptr(), ld_of(x), rows, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
+                                          mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                          ws.data_ptr(), nws, st), "bn_stats_finalize")
+    elif training:
+        nws = lib.segmi_bn_stats_workspace(rows, C)
+        ws = workspace(nws, dev)
+        part = torch.empty(3 * C, device=dev, dtype=torch.float32)
+        check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st), "bn_stats")
+        # one all-gather; the global element count is summed from the gathered partials ON THE DEVICE (coef[4C]) — no host-side
+        # count exchange, so ragged / changing shard sizes cannot desynchronise the ranks' collectives
+        part, nparts = sync.gather_stats(part)
+        count = None
+        check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
+                                    mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                    coef.data_ptr() + 16 * C, st), "bn_finalize")
+    else:
+        check(lib.segmi_bn_eval_coeffs(running_mean.data_ptr(), running_var.data_ptr(), gp, bp, eps, C,
+                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
+              "bn_eval_coeffs")
+    return coef, count
+
+
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, num_batches_tracked, training, momentum,
@@ -1044,55 +1081,8 @@ class _BatchNormActFn(torch.autograd.Function):
         dev, st = x.device, _stream()
         if residual is not None:
             residual = to_nhwc(residual, "batch_norm.residual")
-        coef = torch.empty(4 * C + 4, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift | global count (SyncBN)
-        mean, invstd, scale, shift = (coef[i * C:(i + 1) * C] for i in range(4))
-        gp = gamma.data_ptr() if gamma is not None else None
-        bp = beta.data_ptr() if beta is not None else None
-        count = float(rows)
-        rm = running_mean.data_ptr() if running_mean is not None else None
-        rv = running_var.data_ptr() if running_var is not None else None
-        nbt = num_batches_tracked.data_ptr() if num_batches_tracked is not None else None
-        if training and pstats is not None and (sync is not None or rows > 1):
-            part, nparts = pstats
-            nws = lib.segmi_bn_parts_workspace(nparts, C)
-            ws = workspace(nws, dev)
-            _BN_FUSE["consumed"] += 1
-            if sync is None:
-                check(lib.segmi_bn_finalize_from_parts(part.data_ptr(), nparts, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
-                                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                       ws.data_ptr(), nws, st), "bn_finalize_from_parts")
-            else:
-                one = torch.empty(3 * C, device=dev, dtype=torch.float32)
-                check(lib.segmi_bn_stats_from_parts(part.data_ptr(), nparts, C, one.data_ptr(), ws.data_ptr(), nws, st), "bn_stats_from_parts")
-                allp, nall = sync.gather_stats(one)
-                count = None
-                check(lib.segmi_bn_finalize(allp.data_ptr(), nall, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
-                                            mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                            coef.data_ptr() + 16 * C, st), "bn_finalize")
-        elif training and sync is None:
-            if rows <= 1:
-                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
-            nws = lib.segmi_bn_stats_workspace(rows, C)
-            ws = workspace(nws, dev)
-            check(lib.segmi_bn_stats_finalize(x.data_ptr(), ld_of(x), rows, C, gp, bp, eps, momentum, 0, rm, rv, nbt,
-                                              mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                              ws.data_ptr(), nws, st), "bn_stats_finalize")
-        elif training:
-            nws = lib.segmi_bn_stats_workspace(rows, C)
-            ws = workspace(nws, dev)
-            part = torch.empty(3 * C, device=dev, dtype=torch.float32)
-            check(lib.segmi_bn_stats(x.data_ptr(), ld_of(x), rows, C, part.data_ptr(), ws.data_ptr(), nws, st), "bn_stats")
-            # one all-gather; the global element count is summed from the gathered partials ON THE DEVICE (coef[4C]) — no host-side
-            # count exchange, so ragged / changing shard sizes cannot desynchronise the ranks' collectives
-            part, nparts = sync.gather_stats(part)
-            count = None
-            check(lib.segmi_bn_finalize(part.data_ptr(), nparts, C, gp, bp, eps, momentum, sync.clamp_mode, rm, rv, nbt,
-                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                        coef.data_ptr() + 16 * C, st), "bn_finalize")
-        else:
-            check(lib.segmi_bn_eval_coeffs(running_mean.data_ptr(), running_var.data_ptr(), gp, bp, eps, C,
-                                           mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st),
-                  "bn_eval_coeffs")
+        coef, count = _bn_coefficients(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, sync, pstats)
+        scale, shift = coef[2 * C:3 * C], coef[3 * C:4 * C]
         y = empty_nhwc(N, C, H, W, dev)
         check(lib.segmi_bn_apply(x.data_ptr(), ld_of(x), residual.data_ptr() if residual is not None else None,
                                  ld_of(residual) if residual is not None else 0, y.data_ptr(), ld_of(y), rows, C,
@@ -1117,7 +1107,7 @@ class _BatchNormActFn(torch.autograd.Function):
         yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
         check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C,
                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                      1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, _bn_tickets(dev), st), "bn_bwd_reduce")
+                                      1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, st), "bn_bwd_reduce")
         dgamma = sums[C:2 * C] if ctx.needs_input_grad[1] else None
         dbeta = sums[0:C] if ctx.needs_input_grad[2] else None
         gsums = sums
@@ -1139,6 +1129,110 @@ class _BatchNormActFn(torch.autograd.Function):
         if want_res and not relu:
             dres = dy
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+
+
+class _BatchNormDepthwiseFn(torch.autograd.Function):
+    """depthwise3x3(relu?(batch_norm(z))) as ONE node (round 6): the normalised tensor is never materialised — the depthwise kernels
+    apply max(fmaf(z, scale, shift), 0) on every loaded tap (segmi_dwconv2d_fwd_pre / _wgrad_pre), bit-identical to
+    segmi_bn_apply followed by the plain depthwise kernel.  Xception: the BatchNorm(+ReLU) between a pointwise convolution and the
+    next SeparableConv2d (models/deeplabv3_plus.py:99-119, 225-232 of the reference).  Backward: depthwise data gradient -> the
+    BatchNorm backward passes with the ReLU mask recomputed from z (as _BatchNormActFn does without a residual); the depthwise
+    filter gradient reads z through the same fused load, on the filter-gradient side stream."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu, pstats,
+                weight, pad, dil, bn_stats):
+        z = to_nhwc(z, "batch_norm_depthwise")
+        _need_cuda(weight, "batch_norm_depthwise")
+        N, C, H, W = z.shape
+        dev, st = z.device, _stream()
+        coef, count = _bn_coefficients(z, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, None, pstats)
+        wrsc = _dw_rsc_view(weight.detach())
+        y = empty_nhwc(N, C, H, W, dev)
+        d = ConvDesc(N, H, W, C, C, 3, 3, H, W, 1, pad, dil, ld_of(z), ld_of(y))
+        parts = lib.segmi_dwconv2d_fwd_stats_parts(d) if bn_stats else 0
+        part = torch.empty(parts * 3 * C, device=dev, dtype=torch.float32) if parts > 0 else None
+        check(lib.segmi_dwconv2d_fwd_pre(d, z.data_ptr(), coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0, wrsc.data_ptr(),
+                                         y.data_ptr(), part.data_ptr() if part is not None else None, st), "dwconv2d_fwd_pre")
+        if part is not None:
+            _BN_FUSE["last"] = (part, parts)
+            _BN_FUSE["emitted"] += 1
+        ctx.save_for_backward(z, coef, wrsc, weight)
+        ctx.cfg = (training, relu, count, pad, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, coef, wrsc, weight = ctx.saved_tensors
+        training, relu, count, pad, dil = ctx.cfg
+        N, C, H, W = z.shape
+        rows = N * H * W
+        dev, st = z.device, _stream()
+        dy = to_nhwc(dy, "batch_norm_depthwise.backward")
+        dw = dz = dgamma = dbeta = None
+        if ctx.needs_input_grad[11]:
+            d = ConvDesc(N, H, W, C, C, 3, 3, H, W, 1, pad, dil, ld_of(z), ld_of(dy))
+            slot = _take_grad_slot(weight) if _GRAD_SLOTS else None
+            dwr = slot if slot is not None else torch.empty(9 * C, device=dev, dtype=torch.float32)
+
+            def run_wgrad():
+                nws = lib.segmi_dwconv2d_wgrad_workspace(d)
+                ws = workspace(nws, dev)             # (keyed by the stream the call runs on)
+                check(lib.segmi_dwconv2d_wgrad_pre(d, z.data_ptr(), coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0,
+                                                   dy.data_ptr(), dwr.data_ptr(), ws.data_ptr(), nws, _stream()), "dwconv2d_wgrad_pre")
+
+            if _DW_WGRAD_SIDE:
+                _on_wgrad_stream(weight, (z, dy, dwr, coef), run_wgrad)
+            else:
+                run_wgrad()
+            dw = slot if slot is not None else dwr.view(3, 3, C).permute(2, 0, 1).unsqueeze(1)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            da = empty_nhwc(N, C, H, W, dev)          # gradient with respect to the (never materialised) normalised tensor
+            d = ConvDesc(N, H, W, C, C, 3, 3, H, W, 1, pad, dil, ld_of(da), ld_of(dy))
+            check(lib.segmi_dwconv2d_dgrad(d, dy.data_ptr(), wrsc.data_ptr(), da.data_ptr(), st), "dwconv2d_dgrad")
+            mean, invstd, scale, shift = (coef.data_ptr() + 4 * i * C for i in range(4))
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+            nws = lib.segmi_bn_bwd_reduce_workspace(rows, C)
+            ws = workspace(nws, dev)
+            check(lib.segmi_bn_bwd_reduce(da.data_ptr(), ld_of(da), z.data_ptr(), ld_of(z), None, 0, rows, C, mean, invstd, scale, shift,
+                                          1 if relu else 0, sums.data_ptr(), ws.data_ptr(), nws, st), "bn_bwd_reduce")
+            dgamma = sums[C:2 * C] if ctx.needs_input_grad[1] else None
+            dbeta = sums[0:C] if ctx.needs_input_grad[2] else None
+            if ctx.needs_input_grad[0]:
+                dz = empty_nhwc(N, C, H, W, dev)
+                check(lib.segmi_bn_bwd_apply(da.data_ptr(), ld_of(da), z.data_ptr(), ld_of(z), None, 0, rows, C, mean, invstd, scale, shift,
+                                             sums.data_ptr(), count, None, 1 if relu else 0, 1 if training else 0, dz.data_ptr(), ld_of(dz),
+                                             None, 0, st), "bn_bwd_apply")
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, dw, None, None, None
+
+
+_DW_BN_FUSION = os.environ.get("SEGMI_DW_FUSED_BN", "1") == "1"      # A/B switch
+
+
+def batch_norm_depthwise_ok(bn, conv):
+    """Can `conv(relu?(bn(z)))` run as the fused node?  bn: a local (not synchronized) BatchNorm2d; conv: a depthwise 3x3 stride-1
+    pad == dil in {1, 2} segmi.nn.Conv2d whose filter lives tap-major (what the module stores)."""
+    if not _DW_BN_FUSION or getattr(bn, "sync", None) is not None or bn.momentum is None or not getattr(conv, "depthwise", False):
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != conv.dilation or conv.dilation[0] not in (1, 2):
+        return False
+    if conv.in_channels != bn.num_features or (conv.in_channels & 3) or not (bn.training or bn.track_running_stats):
+        return False
+    return _dw_rsc_view(conv.weight.detach()) is not None
+
+
+def batch_norm_depthwise(z, bn, conv, relu=True, bn_stats=False):
+    """conv(relu?(bn(z))) — see _BatchNormDepthwiseFn; the caller checked batch_norm_depthwise_ok(bn, conv)."""
+    training = bn.training or not bn.track_running_stats
+    _note_bn_consumer(z, training)
+    pstats = _producer_stats(z, z.shape[1]) if (training and z.dim() == 4) else None
+    _BN_FUSE["last"] = None
+    y = _BatchNormDepthwiseFn.apply(z, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                    bn.running_var if bn.track_running_stats else None,
+                                    bn.num_batches_tracked if (bn.track_running_stats and bn.training) else None,
+                                    bool(training), float(bn.momentum), float(bn.eps), bool(relu), pstats,
+                                    conv.weight, int(conv.padding[0]), int(conv.dilation[0]), bool(bn_stats) and _BN_FUSE["on"])
+    return _tag_bn_stats(y, conv)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, residual=None, training=True,
@@ -1205,7 +1299,7 @@ def _bn_member_bwd_reduce(dy, x, y, coef, relu):
     yp, ldy = (y.data_ptr(), ld_of(y)) if y is not None else (None, 0)
     check(lib.segmi_bn_bwd_reduce(dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), yp, ldy, rows, C, coef.data_ptr(),
                                   coef.data_ptr() + 4 * C, coef.data_ptr() + 8 * C, coef.data_ptr() + 12 * C, 1 if relu else 0,
-                                  sums.data_ptr(), ws.data_ptr(), nws, _bn_tickets(dev), _stream()), "bn_bwd_reduce")
+                                  sums.data_ptr(), ws.data_ptr(), nws, _stream()), "bn_bwd_reduce")
     return sums
 
 

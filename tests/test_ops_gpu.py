@@ -259,43 +259,6 @@ def test_batch_norm_act(cuda, shape, relu, res, training):
         assert int(nbt.item()) == 1
 
 
-@pytest.mark.parametrize("shape", [(8, 256, 64, 64), (8, 728, 32, 32), (2, 64, 256, 256), (4, 2048, 8, 8), (2, 16, 33, 35)])
-@pytest.mark.parametrize("relu", [False, True])
-@pytest.mark.skipif(os.environ.get("SEGMI_TEST_BN_TICKETS") != "1",
-                    reason="opt-in (SEGMI_TEST_BN_TICKETS=1): the one-launch form is itself opt-in and measured slower (profiles/r05_bn_tickets_ab.txt); "
-                           "passed on hardware in round 5 in both of its variants")
-def test_bn_backward_reduction_in_one_launch_equals_the_two_launch_form(cuda, shape, relu, monkeypatch):
-    """Round 5: the last workgroup of a channel column adds the column's fp64 row partials itself (ticket counters; the partials
-    travel as device-scope atomic stores / loads across the XCDs' L2s) instead of a second launch.  Both forms add the same fp64 partials and round once to fp32:
-    gradients agree to the last bit or two; repeated calls are bit-identical (the order of the additions is fixed, whichever
-    workgroup comes last) and every call hands its counters back at zero."""
-    from segmi import ops
-    N, C, H, W = shape
-    g = torch.Generator().manual_seed(11)
-    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(cuda)
-    gy = torch.randn(N, C, H, W, generator=g).to(cuda)
-    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
-
-    def run():
-        xd, gd, bd = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-        rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
-        y = ops.batch_norm_act(xd, gd, bd, rm, rv, None, training=True, relu=relu)
-        y.backward(gy)
-        torch.cuda.synchronize()
-        return xd.grad.clone(), gd.grad.clone(), bd.grad.clone()
-
-    monkeypatch.setattr(ops, "_BN_TICKETS_ON", True)
-    one = [run() for _ in range(4)]
-    tick = ops._BN_TICKETS[(cuda.index, ops._stream())]
-    assert int(tick.abs().sum()) == 0
-    for r in one[1:]:
-        assert all(torch.equal(a, b) for a, b in zip(one[0], r))
-    monkeypatch.setattr(ops, "_BN_TICKETS_ON", False)
-    two = run()
-    for a, b, what in zip(one[0], two, ("dx", "dgamma", "dbeta")):
-        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7 * float(b.abs().max())), (what, (a - b).abs().max().item())
-
-
 def test_batch_norm_large_mean_is_stable(cuda):
     """Welford/Chan statistics: a channel with |mean| >> std must not lose its variance."""
     from segmi import ops
@@ -542,6 +505,7 @@ def _lovasz_logits(case, mode, seed=23):
     x = torch.randn(N, C, H, W, generator=g) * 3
     t = torch.randint(0, max(2, C - 2), (N, H, W), generator=g)
     t[:, :1, :] = ign
+    t[torch.rand(N, H, W, generator=g) < 0.1] = ign          # scattered ignored pixels inside the 256-pixel units, not only whole rows
     if mode in ("trained", "saturated"):
         hit = torch.rand(N, H, W, generator=g) < 0.8
         boost = 40.0 if mode == "saturated" else 6.0
@@ -551,14 +515,17 @@ def _lovasz_logits(case, mode, seed=23):
 
 @pytest.mark.parametrize("mode", ["random", "trained", "saturated"])
 @pytest.mark.parametrize("case", [(2, 21, 48, 40, 255), (1, 150, 33, 31, -1), (3, 4, 64, 64, 255), (2, 19, 200, 210, 255), (1, 7, 5, 3, 255),
-                                  (2, 21, 256, 256, 255)])
+                                  (2, 21, 256, 256, 255), (2, 32, 24, 24, -1), (1, 300, 17, 19, 255)],
+                         ids=lambda c: "N%d-C%d-%dx%d" % c[:4])       # every register-row class of the kernels: C <= 32, <= 256 (150), > 256 (re-read form)
 def test_lovasz_tail_pruning_is_bit_identical_to_the_full_sort(cuda, case, mode, monkeypatch):
     """Round 5: only elements with error >= their class's smallest foreground error are sorted (lovasz_grad gives every element
     behind the last foreground one a Jaccard difference of exactly 0, utils/lovasz_losses.py:19-31).  The survivors are a prefix
     of the full stable order, so loss AND gradient must agree BIT FOR BIT with segmi_lovasz_set_prune(0) (every valid pixel of
     every present class sorted = the round-4 formulation) — on single-tile, multi-tile and ragged segments, with ignored pixels,
     absent classes, random targets (ties next to each other), confident logits and saturated probabilities (error 0 keeps a
-    whole class).  G is poisoned with NaN first: the backward may only read entries the forward wrote."""
+    whole class).  G is poisoned with NaN first (in the default suite, for every class-count form of the kernels and with
+    scattered ignored pixels): the backward may only read entries the forward wrote — its keep test is recomputed in a separately
+    compiled kernel, and a one-bit disagreement with the forward's would read uninitialised memory as a gradient."""
     import utils.losses as L
     from segmi import lib, ops
     monkeypatch.setenv("SEGMI_LOVASZ_POISON", "1")
