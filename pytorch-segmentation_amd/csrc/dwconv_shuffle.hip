@@ -186,7 +186,7 @@ __device__ __forceinline__ float4 dw_pre(float4 v, const float4& sc, const float
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
 }
-template <int D, bool FLIP, bool STATS, bool PRE>
+template <int D, bool FLIP, bool STATS, bool PRE, bool HOIST>
 __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, int ldy, int N, int H, int W, int C,
                                                           float* __restrict__ stats, const float* __restrict__ pre_scale,
@@ -209,6 +209,45 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
         const int p = (int)(t1 % H), n = (int)(t1 / H);
         const int q0 = qs * 4;
         float4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+        if (PRE || HOIST) {
+            // ALL 3 x (4 + 2D) taps of the strip are requested before the first one is used (loads at clamped, always valid addresses;
+            // the out-of-image ones are zeroed afterwards).  Left to itself the compiler emits load-row / wait / 48 FMAs three times
+            // per strip — three HBM round trips in series for 4 outputs (rounds 4-5: 17-18 us for a 10 us transfer on the
+            // 728-channel 32x32 layers) — and with the BatchNorm transform on the loaded value it waited tap by tap (first PRE build:
+            // 22.8 us, 200 against 125 us at 256x256).
+            float4 v[3][4 + 2 * D];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int h = p + (r - 1) * D;
+                const int hc = (unsigned)h < (unsigned)H ? h : p;
+                const float* rowp = x + ((long)(n * H + hc) * W) * ldx + c4 * 4;
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * D; ++j) {
+                    const int ww = q0 - D + j;
+                    v[r][j] = ld4(rowp + (long)((unsigned)ww < (unsigned)W ? ww : q0) * ldx);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool hok = (unsigned)(p + (r - 1) * D) < (unsigned)H;
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * D; ++j) {
+                    const int ww = q0 - D + j;
+                    v[r][j] = (hok && (unsigned)ww < (unsigned)W) ? (PRE ? dw_pre(v[r][j], psc, psh, pre_relu != 0) : v[r][j]) : zero4();
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const float4 f = wt[r * 3 + s2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 u = v[r][j + s2 * D];
+                        acc[j].x = fmaf(u.x, f.x, acc[j].x); acc[j].y = fmaf(u.y, f.y, acc[j].y);
+                        acc[j].z = fmaf(u.z, f.z, acc[j].z); acc[j].w = fmaf(u.w, f.w, acc[j].w);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int h = p + (r - 1) * D;
@@ -218,7 +257,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4 + 2 * D; ++j) {
                 const int ww = q0 - D + j;
-                v[j] = (unsigned)ww < (unsigned)W ? (PRE ? dw_pre(ld4(rowp + (long)ww * ldx), psc, psh, pre_relu != 0) : ld4(rowp + (long)ww * ldx)) : zero4();
+                v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
             }
 #pragma unroll
             for (int s2 = 0; s2 < 3; ++s2) {
@@ -230,6 +269,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
                     acc[j].z = fmaf(u.z, f.z, acc[j].z); acc[j].w = fmaf(u.w, f.w, acc[j].w);
                 }
             }
+        }
         }
         float* o = y + ((long)(n * H + p) * W + q0) * ldy + c4 * 4;
 #pragma unroll
@@ -244,7 +284,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_kernel(const float* __restric
 }
 
 // filter gradient of the same convolutions, same strips: part[blockIdx.y][t][C] = sum over this block's strips of dy (x) x-taps
-template <int D, bool PRE>
+template <int D, bool PRE, bool HOIST>
 __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                                 float* __restrict__ part, int N, int H, int W, int C,
                                                                 const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
@@ -267,6 +307,40 @@ __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __r
             const float* gp = dy + ((long)(n * H + p) * W + q0) * lddy + c4 * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) gy[j] = q0 + j < W ? ld4(gp + (long)j * lddy) : zero4();
+            if (PRE || HOIST) {
+                // all taps requested before the first use (see dw3x3_strip_kernel)
+                float4 v[3][4 + 2 * D];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int h = p + (r - 1) * D;
+                    const int hc = (unsigned)h < (unsigned)H ? h : p;
+                    const float* rowp = x + ((long)(n * H + hc) * W) * ldx + c4 * 4;
+#pragma unroll
+                    for (int j = 0; j < 4 + 2 * D; ++j) {
+                        const int ww = q0 - D + j;
+                        v[r][j] = ld4(rowp + (long)((unsigned)ww < (unsigned)W ? ww : q0) * ldx);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool hok = (unsigned)(p + (r - 1) * D) < (unsigned)H;
+#pragma unroll
+                    for (int j = 0; j < 4 + 2 * D; ++j) {
+                        const int ww = q0 - D + j;
+                        v[r][j] = (hok && (unsigned)ww < (unsigned)W) ? (PRE ? dw_pre(v[r][j], psc, psh, pre_relu != 0) : v[r][j]) : zero4();
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 u = v[r][j + s2 * D];
+                            float4& a = acc[r * 3 + s2];
+                            a.x = fmaf(u.x, gy[j].x, a.x); a.y = fmaf(u.y, gy[j].y, a.y);
+                            a.z = fmaf(u.z, gy[j].z, a.z); a.w = fmaf(u.w, gy[j].w, a.w);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int h = p + (r - 1) * D;
@@ -276,7 +350,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 4 + 2 * D; ++j) {
                     const int ww = q0 - D + j;
-                    v[j] = (unsigned)ww < (unsigned)W ? (PRE ? dw_pre(ld4(rowp + (long)ww * ldx), psc, psh, pre_relu != 0) : ld4(rowp + (long)ww * ldx)) : zero4();
+                    v[j] = (unsigned)ww < (unsigned)W ? ld4(rowp + (long)ww * ldx) : zero4();
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 3; ++s2)
@@ -287,6 +361,7 @@ __global__ __launch_bounds__(256) void dw3x3_strip_wgrad_kernel(const float* __r
                         a.x = fmaf(u.x, gy[j].x, a.x); a.y = fmaf(u.y, gy[j].y, a.y);
                         a.z = fmaf(u.z, gy[j].z, a.z); a.w = fmaf(u.w, gy[j].w, a.w);
                     }
+            }
             }
         }
     // block reduction over the thread rows: all nine taps go to LDS at once (36 KB), ONE barrier, then thread (tx, ty) adds the rows
@@ -412,8 +487,22 @@ int dw_strip(const segmi_conv_desc* d) {
 
 extern "C" {
 
+// strips per thread of the strip kernels (tuning hook SEGMI_DW_SPT; default 1 = one strip per thread, the whole grid resident at once)
+static int dw_spt() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SEGMI_DW_SPT"); v = (e && atoi(e) > 0) ? atoi(e) : 1; }
+    return v;
+}
+// SEGMI_DW_HOIST=1: the plain strip kernels with all taps requested up front too (A/B hook).  Default off: measured 154.5 against
+// 156.5 img/s at cfg5 in alternating runs (profiles/r06_dw_hoist_ab.txt) — without the BatchNorm transform on the loaded value the
+// compiler's row-by-row schedule already overlaps the rows, and the 18 live float4 taps cost occupancy.  The PRE kernels always hoist.
+static bool dw_hoist() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SEGMI_DW_HOIST"); v = (e && atoi(e) == 1) ? 1 : 0; }
+    return v == 1;
+}
 static RowGeom dw_fwd_geom(const segmi_conv_desc* d, int strip) {
-    if (strip) return row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
+    if (strip) return row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, dw_spt(), SEGMI_MAX_GRID);
     return row_geom((long)d->N * d->P * d->Q, d->C, 2, SEGMI_MAX_GRID);
 }
 static int dw_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w_rsc, float* y, float* stats, segmi_stream_t stream,
@@ -427,13 +516,16 @@ static int dw_fwd_impl(const segmi_conv_desc* d, const float* x, const float* w_
     const int D = dw_strip(d);
     const RowGeom g = dw_fwd_geom(d, D);
     if (D) {
-#define SEGMI_DW_STRIP(DV, SV, PV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, false, SV, PV>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C, stats, pre_scale, pre_shift, pre_relu)
+#define SEGMI_DW_STRIP(DV, SV, PV, HV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, false, SV, PV, HV>), g.grid, g.block, 0, st, x, d->ldx, w_rsc, y, d->ldy, d->N, d->H, d->W, d->C, stats, pre_scale, pre_shift, pre_relu)
         if (pre_scale) {
-            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, true); else SEGMI_DW_STRIP(1, false, true); }
-            else        { if (stats) SEGMI_DW_STRIP(2, true, true); else SEGMI_DW_STRIP(2, false, true); }
+            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, true, true); else SEGMI_DW_STRIP(1, false, true, true); }
+            else        { if (stats) SEGMI_DW_STRIP(2, true, true, true); else SEGMI_DW_STRIP(2, false, true, true); }
+        } else if (dw_hoist()) {
+            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, false, true); else SEGMI_DW_STRIP(1, false, false, true); }
+            else        { if (stats) SEGMI_DW_STRIP(2, true, false, true); else SEGMI_DW_STRIP(2, false, false, true); }
         } else {
-            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, false); else SEGMI_DW_STRIP(1, false, false); }
-            else        { if (stats) SEGMI_DW_STRIP(2, true, false); else SEGMI_DW_STRIP(2, false, false); }
+            if (D == 1) { if (stats) SEGMI_DW_STRIP(1, true, false, false); else SEGMI_DW_STRIP(1, false, false, false); }
+            else        { if (stats) SEGMI_DW_STRIP(2, true, false, false); else SEGMI_DW_STRIP(2, false, false, false); }
         }
 #undef SEGMI_DW_STRIP
         return segmi_launch_status();
@@ -471,9 +563,11 @@ int segmi_dwconv2d_dgrad(const segmi_conv_desc* d, const float* dy, const float*
     if ((d->C & 3) || (d->ldx & 3) || (d->ldy & 3) || d->ldx < d->C || d->ldy < d->C) return SEGMI_ERR_ALIGN;
     const long rows = (long)d->N * d->H * d->W;
     if (const int D = dw_strip(d)) {          // dx = dy (*) rot180(w): the forward strip kernel with the filter read flipped
-        RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, 1, SEGMI_MAX_GRID);
-        if (D == 1) hipLaunchKernelGGL((dw3x3_strip_kernel<1, true, false, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
-        else        hipLaunchKernelGGL((dw3x3_strip_kernel<2, true, false, false>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
+        RowGeom g = row_geom((long)d->N * d->H * ((d->W + 3) / 4), d->C, dw_spt(), SEGMI_MAX_GRID);
+#define SEGMI_DW_DG(DV, HV) hipLaunchKernelGGL((dw3x3_strip_kernel<DV, true, false, false, HV>), g.grid, g.block, 0, (hipStream_t)stream, dy, d->ldy, w_rsc, dx, d->ldx, d->N, d->H, d->W, d->C, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0)
+        if (dw_hoist()) { if (D == 1) SEGMI_DW_DG(1, true); else SEGMI_DW_DG(2, true); }
+        else            { if (D == 1) SEGMI_DW_DG(1, false); else SEGMI_DW_DG(2, false); }
+#undef SEGMI_DW_DG
         return segmi_launch_status();
     }
     RowGeom g = row_geom(rows, d->C, 2, SEGMI_MAX_GRID);
@@ -498,9 +592,10 @@ static int dw_wgrad_impl(const segmi_conv_desc* d, const float* x, const float* 
     g.grid.y = parts;
     hipStream_t st = (hipStream_t)stream;
     if (const int D = dw_strip(d)) {
-#define SEGMI_DW_WG(DV, PV) hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<DV, PV>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C, pre_scale, pre_shift, pre_relu)
-        if (pre_scale) { if (D == 1) SEGMI_DW_WG(1, true); else SEGMI_DW_WG(2, true); }
-        else           { if (D == 1) SEGMI_DW_WG(1, false); else SEGMI_DW_WG(2, false); }
+#define SEGMI_DW_WG(DV, PV, HV) hipLaunchKernelGGL((dw3x3_strip_wgrad_kernel<DV, PV, HV>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, d->N, d->H, d->W, d->C, pre_scale, pre_shift, pre_relu)
+        if (pre_scale)      { if (D == 1) SEGMI_DW_WG(1, true, true); else SEGMI_DW_WG(2, true, true); }
+        else if (dw_hoist()) { if (D == 1) SEGMI_DW_WG(1, false, true); else SEGMI_DW_WG(2, false, true); }
+        else                { if (D == 1) SEGMI_DW_WG(1, false, false); else SEGMI_DW_WG(2, false, false); }
 #undef SEGMI_DW_WG
     } else
     hipLaunchKernelGGL((dwconv_wgrad_kernel<9>), g.grid, g.block, 0, st, x, d->ldx, dy, d->ldy, (float*)workspace, dw_geom(d));

@@ -392,6 +392,26 @@ class DistributedModel(torch.nn.Module):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    def broadcast_buffers(self, src=0):
+        """Rank `src`'s floating-point buffers (the BatchNorm running statistics) to every rank, as ONE broadcast.  Without SyncBN
+        every rank updates its running statistics from ITS shard's batch statistics, so the replicas' buffers drift apart while
+        their parameters stay identical; the reference's nn.DataParallel keeps ONE set — the module's own, i.e. replica 0's
+        (base/base_trainer.py:33-38: replicas are re-made from the module at every forward) — and validates and checkpoints
+        with it.  Called before a validation pass (Trainer._valid_epoch) so that every rank evaluates its share of the validation
+        set with the statistics rank 0 would have used on all of it.  A collective: every rank calls it.  No-op for one rank."""
+        if not (_is_dist() and dist.get_world_size(self.reducer.group) > 1):
+            return
+        bufs = [b for b in self.module.buffers() if b.is_floating_point() and b.numel() > 0]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+        dist.broadcast(flat, src=src, group=self.reducer.group)
+        off = 0
+        for b in bufs:
+            n = b.numel()
+            b.detach().copy_(flat[off:off + n].view_as(b))
+            off += n
+
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
 

@@ -101,6 +101,10 @@ class Trainer(BaseTrainer):
             self.logger.warning("Not data loader was passed for the validation step, No validation is performed !")
             return {}
         self.logger.info("\n###### EVALUATION ######")
+        # one set of BatchNorm running statistics for the whole validation set — rank 0's, what the reference's single-process
+        # DataParallel validates (and checkpoints) with; without SyncBN the ranks' buffers follow their own shards
+        if self.world > 1 and hasattr(self.model, "broadcast_buffers"):
+            self.model.broadcast_buffers(src=0)
         self.model.eval()
         self.wrt_mode = "val"
         self._reset_metrics()

@@ -313,3 +313,27 @@ def test_bucket_layout_with_an_oversized_tensor_keeps_large_buckets():
     assert len(sizes) <= 9 and min(sizes) >= 1.0, sizes               # no run of 4 MiB buckets, no sliver bucket
     assert sizes[2] >= 40 and all(a >= b * 0.99 for a, b in zip(sizes[2:], sizes[3:-1])), sizes   # halves of what remains, in backward order
     red.remove()
+
+
+def _buffers_worker(rank, world):
+    from segmi.distributed import DistributedModel
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1), torch.nn.BatchNorm2d(2))
+    dm = DistributedModel(net)
+    g = torch.Generator().manual_seed(50 + rank)           # every rank its own shard -> its own batch statistics
+    net.train()
+    dm(torch.randn(4, 3, 5, 5, generator=g) * (1 + rank) + rank)
+    before = torch.cat([b.reshape(-1).float() for b in net.buffers()]).clone()
+    dm.broadcast_buffers(src=0)
+    after = torch.cat([b.reshape(-1).float() for b in net.buffers()])
+    return {"before": before, "after": after, "nbt": [int(m.num_batches_tracked) for m in net if isinstance(m, torch.nn.BatchNorm2d)]}
+
+
+def test_broadcast_buffers_gives_every_rank_rank0s_running_statistics():
+    """Without SyncBN the ranks' BatchNorm running statistics follow their own shards; before a validation pass every rank takes
+    rank 0's (DistributedModel.broadcast_buffers, one collective) — the one set the reference's single-process DataParallel keeps
+    (base/base_trainer.py:33-38).  Integer buffers (num_batches_tracked) are equal anyway and stay untouched."""
+    a, b = _spawn(_buffers_worker)
+    assert not torch.equal(a["before"], b["before"])                       # they did drift
+    assert torch.equal(a["after"], a["before"]) and torch.equal(b["after"], a["before"])
+    assert a["nbt"] == b["nbt"] == [1, 1]

@@ -282,7 +282,8 @@ def _cfg4_sync_worker(rank, world, port, ret):
         got = collect_step(rec, m.module, out, aux, loss)
         got["metrics"] = collect_metrics(rec, out, td)
         got["collectives"] = sum(mod.sync.collectives for mod in m.module.modules() if getattr(mod, "sync", None) is not None)
-        got["grad_samples"] = torch.stack(got["grad_samples"])      # one tensor instead of 187 (file descriptors of the manager dict)
+        got["grad_sample_sizes"] = [int(v.numel()) for v in got["grad_samples"]]
+        got["grad_samples"] = torch.cat(got["grad_samples"])        # one tensor instead of 187 (file descriptors of the manager dict)
         for k in list(got["wide"]):
             got["wide"][k] = {st: v.clone() for st, v in got["wide"][k].items()}
         ret[rank] = got
@@ -322,7 +323,7 @@ def test_cfg4_syncbn_two_ranks_match_the_reference_global_batch_fixture(cuda):
     # every rank back-propagates W * local_sum / global_count: the mean over ranks is the global-batch loss
     whole["loss"] = sum(g["loss"] for g in got) / world
     whole["metrics"] = sum(g["metrics"] for g in got)
-    whole["grad_samples"] = list(got[0]["grad_samples"])
+    whole["grad_samples"] = list(torch.split(got[0]["grad_samples"], got[0]["grad_sample_sizes"]))
     r = evaluate_audit(rec, whole, "cfg4_sync8")
     r["ranks"], r["collectives_per_rank"] = world, got[0]["collectives"]
     print("\n" + record_audit(r, "2 ranks x 4, SyncBN"))

@@ -42,14 +42,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-WIDE_STATS = ("knorm", "cnorm", "tapsum")
+WIDE_STATS = ("knorm", "cnorm", "tapnorm")
 
 
 def wide_stats(g):
     """Exact whole-tensor reductions of a filter gradient [K,C,R,S] (fp64 accumulation on the device): per-output-channel L2 norms,
-    per-input-channel L2 norms, per-tap sums — the same definition as oracle/gen_golden_fullsize.py `wide_stats`."""
+    per-input-channel L2 norms, per-tap L2 norms — the same definition as oracle/gen_golden_fullsize.py `wide_stats`."""
     g = g.detach().double()
-    return {"knorm": g.flatten(1).norm(dim=1).cpu(), "cnorm": g.transpose(0, 1).flatten(1).norm(dim=1).cpu(), "tapsum": g.sum(dim=(0, 1)).reshape(-1).cpu()}
+    return {"knorm": g.flatten(1).norm(dim=1).cpu(), "cnorm": g.transpose(0, 1).flatten(1).norm(dim=1).cpu(),
+            "tapnorm": g.pow(2).sum(dim=(0, 1)).sqrt().reshape(-1).cpu()}
 
 
 def collect_step(rec, module, out, aux, loss):
@@ -136,7 +137,7 @@ def evaluate_audit(rec, got, name):
     res["batch"] = N
     res["running_ok"] = all(torch.allclose(got["running"][k], v.float(), rtol=1e-4, atol=1e-5) for k, v in rec["running"].items())
     # ---- whole-tensor statistics of the largest filter gradients: a defect confined to one K-panel / C-panel / tap
-    # of a large gradient moves its row of knorm / cnorm / tapsum.  Worst ratio of the HIP path's distance from the fp64 oracle's
+    # of a large gradient moves its row of knorm / cnorm / tapnorm.  Worst ratio of the HIP path's distance from the fp64 oracle's
     # statistics to the reference fp32's own distance, and the worst absolute distance
     worst_ratio, worst_abs, worst_key = 0.0, 0.0, ""
     for k, w64 in rec.get("wide_f64", {}).items():
@@ -169,7 +170,7 @@ def evaluate_audit(rec, got, name):
 # statistics whose reference-fp32-vs-fp64 distance is below this are compared against this absolute distance instead (a ratio of two
 # numbers at the 1e-7 level is noise)
 WIDE_ABS_FLOOR = 5e-5
-WIDE_BAR = 3.0
+WIDE_BAR = 2.0        # measured on knorm / cnorm over all configs and both algorithms: 0.40-1.27 (profiles/r06_fullsize_audit.json)
 
 
 def run_fullsize_audit(name, device):
@@ -214,7 +215,7 @@ def audit_line(r, algo):
             "(max|logit| %.3f) | distance from the fp64 oracle: HIP %.3e, reference fp32 %.3e | mismatches outside 2*max|dlogit| %d | "
             "oracle pixels within that margin %d | loss %.6f (ref %.6f) | grad-norm rel err median %.2e max %.2e (%s) | "
             "grad-sample rel-L2 from the reference fp32 median %.2e max %.2e (%s) | from the fp64 oracle: HIP median %.2e max %.2e (%s), "
-            "reference fp32 median %.2e max %.2e | %d largest filter gradients, whole-tensor knorm / cnorm / tapsum vs fp64: worst %.2e "
+            "reference fp32 median %.2e max %.2e | %d largest filter gradients, whole-tensor knorm / cnorm / tapnorm vs fp64: worst %.2e "
             "= %.2f x the reference fp32's own (%s) | eval_metrics vs the reference's on its own logits: |d correct| %d, max |d inter| %d, "
             "max |d union| %d, mIoU %.6f (ref %.6f), pixAcc %.6f (ref %.6f)"
             % (r["pixels"], r["mismatches"], r["max_margin_among_mismatches"],

@@ -24,7 +24,7 @@ for w in $what; do
 case $w in
 suite)
   rm -f gpurun_out/audit.json
-  ( timeout 2400 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider --durations=15 2>&1 | grep -E "fullsize|2-rank|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64|s call|s setup" | tail -90 ) > gpurun_out/${T}_gpu_suite.txt
+  ( timeout 2400 python -m pytest tests -m gpu -q -rf -s -p no:cacheprovider --durations=15 2>&1 | grep -E "fullsize|2-rank|passed|failed|FAILED|ERROR|rel-L2|L2 error|Error|assert|UNet grad|distance from the fp64|s call|s setup" | tail -220 ) > gpurun_out/${T}_gpu_suite.txt
   tail -4 gpurun_out/${T}_gpu_suite.txt | cut -c1-300
   cp gpurun_out/audit.json gpurun_out/${T}_fullsize_audit.json 2>/dev/null ;;
 smoke)

@@ -31,6 +31,7 @@ def worker(rank, world, port, ret):
         dist.destroy_process_group()
     except Exception as e:       # noqa: BLE001 — the text IS the result
         ret[rank] = "rank %d: REFUSED at %s: %s: %s" % (rank, stage, type(e).__name__, " ".join(str(e).split())[:600])
+        os._exit(0)          # a half-made communicator can hang the interpreter's teardown: the answer is already with the parent
 
 
 if __name__ == "__main__":
