@@ -457,6 +457,22 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
 int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ignore_index, const float* lse, const float* G,
                      int ldg, long rows, int C, const float* loss_out, const float* grad_out, float* dlogits, int lddl,
                      segmi_stream_t stream);
+/* The same loss on bilinearly UPSAMPLED logits without materialising them: the reference feeds F.interpolate(low-resolution
+ * logits, input size, bilinear, align_corners=True) to the loss (models/deeplabv3_plus.py:361, models/pspnet.py:85-91 ->
+ * trainer.py:56-66 -> utils/losses.py:86-89).  logits_lo [N, H, W, C] (row stride ld); target / lse [N, OH, OW]; G
+ * [N*OH*OW, ldg] and loss_out as above.  Every pass interpolates its pixel's four low-resolution neighbours on the fly with
+ * the operation order of segmi_bilinear_fwd, so loss, lse, G and dlogits_lo are BIT-IDENTICAL to segmi_bilinear_fwd ->
+ * segmi_lovasz_fwd / segmi_lovasz_bwd -> segmi_bilinear_bwd; the backward reduces along the width while it evaluates the
+ * gradient, so d loss / d logits exists only at [N, OH, W] and [N, H, W].  N*OH*OW < 2^24.  One workspace size serves both
+ * calls (256-byte aligned). */
+size_t segmi_upsample_lovasz_workspace(int N, int H, int W, int C, int OH, int OW);
+int segmi_upsample_lovasz_fwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                              const int64_t* target, long ignore_index, float* lse, float* G, int ldg, float* loss_out,
+                              void* workspace, size_t workspace_bytes, segmi_stream_t stream);
+int segmi_upsample_lovasz_bwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                              const int64_t* target, long ignore_index, const float* lse, const float* G, int ldg,
+                              const float* loss_out, const float* grad_out, float* dlogits_lo, int lddl, void* workspace,
+                              size_t workspace_bytes, segmi_stream_t stream);
 
 /* eval_metrics (utils/metrics.py:42-67; trainer.py:84-86,128-129): argmax (first maximal class) + pixel-accuracy counts +
  * per-class intersection / prediction / label areas, ACCUMULATED into acc[2 + 3*C] int64 =

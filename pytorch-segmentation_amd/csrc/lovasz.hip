@@ -34,8 +34,13 @@
 // Ties: elements of one class with bit-equal errors are ranked in pixel order (stable sort of a pixel-ordered emission;
 // torch.sort is unstable); the loss value does not depend on that order, the per-pixel gradients inside a tie group do.
 #include "segmi_common.h"
+#include "bilinear.h"
 #include <cstdlib>
 #include <cstring>
+
+// pool_resize.hip: height pass of the separable bilinear backward on a width-reduced buffer (internal, C++ linkage)
+int segmi_internal_bilinear_bwd_height(const float* tmp, int ldt, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                                       int ac, hipStream_t st);
 
 namespace {
 
@@ -55,6 +60,52 @@ __device__ __forceinline__ unsigned lov_thr_eff(const unsigned* __restrict__ thr
     return counts[c] == 0 ? NO_THR : (prune ? thr[c] : 0u);
 }
 
+// WHERE A PIXEL'S LOGITS COME FROM (round 6).  UP == false: row r of a [rows, ld] matrix.  UP == true: the loss is evaluated on the
+// model's final bilinear upsample of low-resolution logits [N, H, W, C] to [N, OH, OW] (models/deeplabv3_plus.py:361,
+// models/pspnet.py:85-91 feed F.interpolate's result to the loss, trainer.py:56-66) WITHOUT that tensor ever existing: every pass
+// interpolates the four low-resolution neighbours of its pixel on the fly — at cfg5 they are 79 MB and stay in the L2 / MALL,
+// where the upsampled tensor is 1.26 GB that the forward read three times and the backward once more.  The interpolation is ONE
+// expression with explicit roundings (lov_up4: the operation order bilinear_fwd_kernel of pool_resize.hip compiles to), so every
+// pass — and the unfused path — sees the same bits, which the keep test relies on.
+struct LovSrc {
+    const float* base; int ld;
+    int H, W, OH, OW, ac;        // UP only
+    float sh, sw;                // bl_scale of the two axes (UP only)
+};
+__device__ __forceinline__ float lov_lerp(float w0, float v0, float w1, float v1) { return fmaf(w0, v0, __fmul_rn(w1, v1)); }
+template <bool UP>
+struct LovPix {
+    const float *p00, *p01, *p10, *p11;
+    float a0, a1, b0, b1;
+    __device__ __forceinline__ void init(const LovSrc& s, long r) {
+        if (!UP) { p00 = s.base + r * s.ld; return; }
+        const unsigned ur = (unsigned)r;                 // rows < 2^24 (lovasz_layout)
+        const unsigned tq = ur / (unsigned)s.OW, ow = ur - tq * (unsigned)s.OW;
+        const unsigned n = tq / (unsigned)s.OH, oh = tq - n * (unsigned)s.OH;
+        const Lerp a = bl_src((int)oh, s.sh, s.H, s.ac), b = bl_src((int)ow, s.sw, s.W, s.ac);
+        const float* img = s.base + (long)n * s.H * s.W * s.ld;
+        p00 = img + ((long)a.i0 * s.W + b.i0) * s.ld; p01 = img + ((long)a.i0 * s.W + b.i1) * s.ld;
+        p10 = img + ((long)a.i1 * s.W + b.i0) * s.ld; p11 = img + ((long)a.i1 * s.W + b.i1) * s.ld;
+        a0 = a.l0; a1 = a.l1; b0 = b.l0; b1 = b.l1;
+    }
+    __device__ __forceinline__ float4 get(int q) const {
+        if (!UP) return ld4(p00 + q * 4);
+        const float4 v00 = ld4(p00 + q * 4), v01 = ld4(p01 + q * 4), v10 = ld4(p10 + q * 4), v11 = ld4(p11 + q * 4);
+        float4 o;
+        o.x = lov_lerp(a0, lov_lerp(b0, v00.x, b1, v01.x), a1, lov_lerp(b0, v10.x, b1, v11.x));
+        o.y = lov_lerp(a0, lov_lerp(b0, v00.y, b1, v01.y), a1, lov_lerp(b0, v10.y, b1, v11.y));
+        o.z = lov_lerp(a0, lov_lerp(b0, v00.z, b1, v01.z), a1, lov_lerp(b0, v10.z, b1, v11.z));
+        o.w = lov_lerp(a0, lov_lerp(b0, v00.w, b1, v01.w), a1, lov_lerp(b0, v10.w, b1, v11.w));
+        return o;
+    }
+    __device__ __forceinline__ float at(int c) const {
+        if (!UP) return p00[c];
+        const float4 v = get(c >> 2);
+        const int o = c & 3;
+        return o == 0 ? v.x : o == 1 ? v.y : o == 2 ? v.z : v.w;
+    }
+};
+
 // A pixel's logits row held in registers by the 8 lanes that share the pixel: lane g owns the float4 groups g, g + 8, ...  KQ > 0:
 // ceil(C/32) <= KQ <= 8 groups per lane, ALL loaded up front (KQ 16-byte loads in flight per lane instead of one; the second
 // sweep of a kernel re-uses the registers instead of re-reading L1/L2) — the streaming passes went from 2.5-3.3 to 4-5 TB/s at
@@ -62,23 +113,25 @@ __device__ __forceinline__ unsigned lov_thr_eff(const unsigned* __restrict__ thr
 template <int KQ>
 struct LovRow {
     float4 v[KQ > 0 ? KQ : 1];
-    __device__ __forceinline__ void load(const float* __restrict__ row, int g, int c4n) {
+    template <class P>
+    __device__ __forceinline__ void load(const P& row, int g, int c4n) {
         if (KQ > 0) {
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
                 const int q = g + 8 * k;
-                v[k] = q < c4n ? ld4(row + q * 4) : zero4();
+                v[k] = q < c4n ? row.get(q) : zero4();
             }
         }
     }
-    __device__ __forceinline__ float4 get(const float* __restrict__ row, int k, int q) const { return KQ > 0 ? v[k] : ld4(row + q * 4); }
+    template <class P>
+    __device__ __forceinline__ float4 get(const P& row, int k, int q) const { return KQ > 0 ? v[k] : row.get(q); }
 };
 // trips of lane g over its groups (KQ > 0: compile-time, groups past the row are zeros and every use is guarded by c < C)
 #define LOV_TRIPS(KQ, g, c4n) (KQ > 0 ? KQ : ((c4n) - (g) + 7) / 8)
 
 // 8 lanes share a pixel (float4 channel groups, xor-shuffle reductions): coalesced 128-byte row segments
-template <int KQ>
-__global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+template <int KQ, bool UP>
+__global__ __launch_bounds__(256) void lovasz_prepare_kernel(const LovSrc src, const int64_t* __restrict__ target,
                                                              long rows, int C, long ignore, float* __restrict__ lse,
                                                              unsigned* __restrict__ counts /* [C] fg counts, [C] n_valid */,
                                                              unsigned* __restrict__ thr /* [C], pre-set to NO_THR */) {
@@ -91,7 +144,8 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
     const int c4n = (C + 3) >> 2;
     const int trips = LOV_TRIPS(KQ, g, c4n);
     for (long r = (long)blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += (long)gridDim.x * 32) {
-        const float* row = logits + r * ld;
+        LovPix<UP> row;
+        row.init(src, r);
         LovRow<KQ> R;
         R.load(row, g, c4n);
         float m = -INFINITY;
@@ -124,7 +178,7 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
                 atomicAdd(&hist[C], 1u);
                 if (t >= 0 && t < C) {
                     atomicAdd(&hist[(int)t], 1u);
-                    atomicMin(&thr_s[(int)t], lov_err_bits(row[t], l, true));   // unsigned order == float order for errors >= 0
+                    atomicMin(&thr_s[(int)t], lov_err_bits(row.at((int)t), l, true));   // unsigned order == float order for errors >= 0
                 }
             }
         }
@@ -138,8 +192,8 @@ __global__ __launch_bounds__(256) void lovasz_prepare_kernel(const float* __rest
 
 // cnt[c][unit] = number of survivors of class c among the unit's UPX pixels.  Same thread layout as prepare (a wave reads 8
 // pixel rows per step as 128-byte segments); a survivor costs one LDS atomic on its wave's counter row.
-template <int KQ>
-__global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+template <int KQ, bool UP>
+__global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const LovSrc src, const int64_t* __restrict__ target,
                                                                 const float* __restrict__ lse, long rows, int C, long ignore,
                                                                 const unsigned* __restrict__ thr, const unsigned* __restrict__ counts,
                                                                 int prune, long nunits, unsigned* __restrict__ cnt) {
@@ -161,7 +215,8 @@ __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const float* __r
             if (r >= rows) continue;
             const long t = target[r];
             if (t == ignore) continue;
-            const float* row = logits + r * ld;
+            LovPix<UP> row;
+            row.init(src, r);
             LovRow<KQ> R;
             R.load(row, g, c4n);
             const float l = lse[r];
@@ -213,8 +268,8 @@ __global__ __launch_bounds__(KS_T) void lovasz_keep_scan_kernel(unsigned* __rest
 // at a time; the 8 lanes holding the same class (same lane & 7, same float4 component) rank themselves with one ballot, the
 // wave's running slot of the class lives in LDS (a wave's LDS operations execute in order: every lane reads the slot before
 // the group's first lane advances it).
-template <int KQ>
-__global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+template <int KQ, bool UP>
+__global__ __launch_bounds__(256) void lovasz_emit_kernel(const LovSrc src, const int64_t* __restrict__ target,
                                                           const float* __restrict__ lse, long rows, int C, long ignore, int PB,
                                                           const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int prune,
                                                           long nunits, const unsigned* __restrict__ cnt, unsigned long long* __restrict__ keys) {
@@ -240,7 +295,8 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const float* __restric
         const bool valid = rok && t != ignore;
         if (__ballot(valid) == 0ull) continue;
         const float l = valid ? lse[r] : 0.f;
-        const float* row = logits + (valid ? r : 0) * ld;
+        LovPix<UP> row;
+        row.init(src, valid ? r : 0);
         LovRow<KQ> R;
         if (valid) R.load(row, g, c4n);
         const int trips = KQ > 0 ? KQ : (c4n + 7) / 8;                 // uniform trip count: the ballots below see the whole wave
@@ -684,7 +740,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
             continue;
         }
         const float l = lse[r];
-        const float* row = logits + r * ld;
+        LovPix<false> row;
+        row.p00 = logits + r * ld;
         const float* grow = G + r * ldg;
         LovRow<KQ> R;
         R.load(row, g, c4n);
@@ -711,7 +768,7 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
             float4 p;
             if (KQ > 0) p = R.v[k];
             else {
-                const float4 v = ld4(row + q * 4);
+                const float4 v = row.get(q);
                 p = make_float4(lov_p(v.x, l), lov_p(v.y, l), lov_p(v.z, l), lov_p(v.w, l));
             }
             float4 d = zero4();
@@ -721,6 +778,105 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
             if (c + 3 < C) d.w = gs * p.w * (lov_g(grow, thr_s, p.w, t, c + 3) - s);
             st4(drow + q * 4, d);
         }
+    }
+}
+
+// ---- backward on upsampled logits (UP): the gradient never exists at full resolution.
+// dot[r] = sum_j G_j p_j of output pixel r — sweep 1 of lovasz_bwd_kernel, same lane layout and summation order, the logits
+// interpolated from the low-resolution tensor (L2-resident).
+__global__ __launch_bounds__(256) void lovasz_up_dot_kernel(const LovSrc src, const int64_t* __restrict__ target, long ignore,
+                                                            const float* __restrict__ lse, const float* __restrict__ G, int ldg, long rows,
+                                                            int C, const float* __restrict__ loss_out, float* __restrict__ dot) {
+    extern __shared__ unsigned thr_s[];                  // C
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    __syncthreads();
+    const int g = threadIdx.x & (LPP - 1);
+    const int c4n = (C + 3) >> 2;
+    for (long r = (long)blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += (long)gridDim.x * 32) {
+        const long t = target[r];
+        if (t == ignore) { if (g == 0) dot[r] = 0.f; continue; }
+        const float l = lse[r];
+        LovPix<true> row;
+        row.init(src, r);
+        const float* grow = G + r * ldg;
+        float s = 0.f;
+        for (int q = g; q < c4n; q += LPP) {
+            const int c = q * 4;
+            const float4 v = row.get(q);
+            if (c < C) { const float p = lov_p(v.x, l); s += lov_g(grow, thr_s, p, t, c) * p; }
+            if (c + 1 < C) { const float p = lov_p(v.y, l); s += lov_g(grow, thr_s, p, t, c + 1) * p; }
+            if (c + 2 < C) { const float p = lov_p(v.z, l); s += lov_g(grow, thr_s, p, t, c + 2) * p; }
+            if (c + 3 < C) { const float p = lov_p(v.w, l); s += lov_g(grow, thr_s, p, t, c + 3) * p; }
+        }
+        s = grp_sum8(s);
+        if (g == 0) dot[r] = s;
+    }
+}
+
+// pass W of the bilinear transpose with the Lovasz gradient evaluated on the way:
+//   tmp[(n, oh, wl), c] = sum_ow ww(ow -> wl) * dz(n, oh, ow)[c],   dz_c = gs * p_c * (G_c - dot)
+// thread = one float4 channel group of one (n, oh, wl) row (flat index: no idle lanes at C = 150), ~2 * OW / W candidate output
+// columns each; the two low-resolution rows of `oh` are loaded once for the columns wl-1, wl, wl+1 and every candidate's logits
+// are interpolated from them with lov_lerp in the forward's operation order (same bits -> same keep decisions).  The summation
+// order over ow and the fused multiply-add are those of bilinear_bwd_axis_kernel<0>, so the result equals the unfused path's.
+__global__ __launch_bounds__(256) void lovasz_up_bwd_w_kernel(const LovSrc src, int N, const int64_t* __restrict__ target, long ignore,
+                                                              const float* __restrict__ lse, const float* __restrict__ dot,
+                                                              const float* __restrict__ G, int ldg, int C,
+                                                              const float* __restrict__ loss_out, const float* __restrict__ grad_out,
+                                                              float* __restrict__ tmp, int ldt) {
+    extern __shared__ unsigned thr_s[];                  // C
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    __syncthreads();
+    const int c4n = (C + 3) >> 2;
+    const int H = src.H, W = src.W, OH = src.OH, OW = src.OW, ac = src.ac;
+    const long total = (long)N * OH * W * c4n;
+    const float np = loss_out[1];
+    const float gs = np > 0.f ? grad_out[0] / np : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned r = (unsigned)(i / c4n);                      // (n * OH + oh) * W + wl  < 2^24
+        const int c4 = (int)(i - (long)r * c4n), c = c4 * 4;
+        const unsigned tq = r / (unsigned)W;
+        const int wl = (int)(r - tq * (unsigned)W);
+        const unsigned n = tq / (unsigned)OH;
+        const int oh = (int)(tq - n * (unsigned)OH);
+        const Lerp a = bl_src(oh, src.sh, H, ac);
+        int lo_c, hi_c;
+        bl_range(wl, src.sw, W, OW, ac, lo_c, hi_c);
+        const float* base = src.base + (long)n * H * W * src.ld + c;
+        const int wm = max(wl - 1, 0), wp = min(wl + 1, W - 1);
+        const int cols[3] = {wm, wl, wp};
+        float4 T0[3], T1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T0[j] = ld4(base + ((long)a.i0 * W + cols[j]) * src.ld);
+            T1[j] = ld4(base + ((long)a.i1 * W + cols[j]) * src.ld);
+        }
+        float4 acc = zero4();
+        for (int ow = lo_c; ow <= hi_c; ++ow) {
+            const Lerp b = bl_src(ow, src.sw, W, ac);
+            const float wt = (b.i0 == wl ? b.l0 : 0.f) + (b.i1 == wl ? b.l1 : 0.f);
+            if (wt == 0.f) continue;
+            const long hp = (long)tq * OW + ow;
+            const long t = target[hp];
+            if (t == ignore) continue;                   // dz = 0
+            const int j0 = b.i0 == wl ? 1 : (b.i0 < wl ? 0 : 2), j1 = b.i1 == wl ? 1 : (b.i1 < wl ? 0 : 2);
+            const float4 v00 = j0 == 1 ? T0[1] : (j0 == 0 ? T0[0] : T0[2]), v01 = j1 == 1 ? T0[1] : (j1 == 0 ? T0[0] : T0[2]);
+            const float4 v10 = j0 == 1 ? T1[1] : (j0 == 0 ? T1[0] : T1[2]), v11 = j1 == 1 ? T1[1] : (j1 == 0 ? T1[0] : T1[2]);
+            const float l = lse[hp], d = dot[hp];
+            const float* grow = G + hp * ldg;
+            float zz, p, dz;
+#define LOV_UPW(comp, cc)                                                                                                         \
+            zz = lov_lerp(a.l0, lov_lerp(b.l0, v00.comp, b.l1, v01.comp), a.l1, lov_lerp(b.l0, v10.comp, b.l1, v11.comp));             \
+            p = lov_p(zz, l);                                                                                                     \
+            dz = __fmul_rn(__fmul_rn(gs, p), __fsub_rn(lov_g(grow, thr_s, p, t, cc), d));                                         \
+            acc.comp = fmaf(wt, dz, acc.comp);
+            LOV_UPW(x, c)
+            if (c + 1 < C) { LOV_UPW(y, c + 1) }
+            if (c + 2 < C) { LOV_UPW(z, c + 2) }
+            if (c + 3 < C) { LOV_UPW(w, c + 3) }
+#undef LOV_UPW
+        }
+        st4(tmp + (long)r * ldt + c, acc);
     }
 }
 
@@ -794,11 +950,16 @@ size_t segmi_lovasz_workspace(long rows, int C) {
     return lovasz_layout(rows, C, &L) ? L.total : 0;
 }
 
-int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
-                     float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
-    if (!logits || !target || !lse || !G || !loss_out || C <= 0) return SEGMI_ERR_BADARG;
+}  // extern "C"
+
+namespace {
+// the forward on either source of logits (LovSrc / `up`): segmi_lovasz_fwd and segmi_upsample_lovasz_fwd
+int lovasz_fwd_impl(const LovSrc lsrc, bool up, const int64_t* target, long rows, int C, long ignore_index, float* lse,
+                    float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (!lsrc.base || !target || !lse || !G || !loss_out || C <= 0) return SEGMI_ERR_BADARG;
     LovaszLayout L;
     if (!lovasz_layout(rows, C, &L)) return SEGMI_ERR_BADARG;
+    const int ld = lsrc.ld;
     if ((ld & 3) || ld < ((C + 3) & ~3) || (ldg & 3) || ldg < ((C + 3) & ~3)) return SEGMI_ERR_ALIGN;
     if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return SEGMI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -819,12 +980,15 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     if (pb > SEGMI_MAX_GRID) pb = SEGMI_MAX_GRID;
     const int kq = lov_kq(C);
     const unsigned ublocks = (unsigned)((L.nunits + 3) / 4);
-#define LOV_PREPARE(K) hipLaunchKernelGGL(lovasz_prepare_kernel<K>, dim3((unsigned)pb), dim3(256), (size_t)(2 * C + 1) * 4, st, logits, ld, target, rows, C, \
-                                          ignore_index, lse, counts, thr)
-#define LOV_COUNT(K) hipLaunchKernelGGL(lovasz_keep_count_kernel<K>, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, \
-                                        rows, C, ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt)
-#define LOV_EMIT(K) hipLaunchKernelGGL(lovasz_emit_kernel<K>, dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, logits, ld, target, (const float*)lse, rows, C, \
-                                       ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka)
+#define LOV_PREPARE_(K, U) hipLaunchKernelGGL((lovasz_prepare_kernel<K, U>), dim3((unsigned)pb), dim3(256), (size_t)(2 * C + 1) * 4, st, lsrc, target, rows, C, \
+                                              ignore_index, lse, counts, thr)
+#define LOV_PREPARE(K) do { if (up) LOV_PREPARE_(K, true); else LOV_PREPARE_(K, false); } while (0)
+#define LOV_COUNT_(K, U) hipLaunchKernelGGL((lovasz_keep_count_kernel<K, U>), dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, lsrc, target, (const float*)lse, \
+                                            rows, C, ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt)
+#define LOV_COUNT(K) do { if (up) LOV_COUNT_(K, true); else LOV_COUNT_(K, false); } while (0)
+#define LOV_EMIT_(K, U) hipLaunchKernelGGL((lovasz_emit_kernel<K, U>), dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, lsrc, target, (const float*)lse, rows, C, \
+                                           ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka)
+#define LOV_EMIT(K) do { if (up) LOV_EMIT_(K, true); else LOV_EMIT_(K, false); } while (0)
     // measured at C = 150 (profiles/r05_lovasz_alone_kernel_stats*.csv): prepare<5> 267 us against 384 us for the re-reading form;
     // count<5> 255 against 258 (no gain); emit<5> 667 against 410 (the unrolled ballot groups need 212 VGPRs: 2 waves per SIMD) —
     // the selection passes stay on the re-reading form
@@ -835,6 +999,9 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
 #undef LOV_PREPARE
 #undef LOV_COUNT
 #undef LOV_EMIT
+#undef LOV_PREPARE_
+#undef LOV_COUNT_
+#undef LOV_EMIT_
     const bool fused_fg = L.nchunks <= SEG_FG_LDS;         // chunk fg counts come out of the last scatter pass
     // four stable 8-bit passes over the 31-bit field [invalid | ~error] above the fg bit: ka -> kb -> ka -> kb -> ka
     unsigned* hist = (unsigned*)(ws + L.temp);
@@ -861,6 +1028,74 @@ int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long ro
     hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts,
                        (const unsigned*)nkept, (const unsigned*)thr, prune, C, loss_out);
     return segmi_launch_status();
+}
+
+LovSrc lov_up_src(const float* lo, int ld, int H, int W, int OH, int OW, int ac) {
+    LovSrc s;
+    s.base = lo; s.ld = ld; s.H = H; s.W = W; s.OH = OH; s.OW = OW; s.ac = ac ? 1 : 0;
+    // the host evaluates bl_scale's expression in the same fp32 arithmetic as the device does in bilinear_fwd_kernel
+    s.sh = ac ? (OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f) : (float)H / (float)OH;
+    s.sw = ac ? (OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f) : (float)W / (float)OW;
+    return s;
+}
+}  // namespace
+
+extern "C" {
+
+int segmi_lovasz_fwd(const float* logits, int ld, const int64_t* target, long rows, int C, long ignore_index, float* lse,
+                     float* G, int ldg, float* loss_out, void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    LovSrc s;
+    memset(&s, 0, sizeof(s));
+    s.base = logits; s.ld = ld;
+    return lovasz_fwd_impl(s, false, target, rows, C, ignore_index, lse, G, ldg, loss_out, workspace, workspace_bytes, stream);
+}
+
+// Lovasz-Softmax on bilinearly upsampled logits without materialising them (see LovSrc).  logits_lo [N, H, W, C] (row stride ld),
+// target / lse [N, OH, OW], G [N*OH*OW, ldg] (survivor entries only, like segmi_lovasz_fwd).  Workspace: the forward needs
+// segmi_lovasz_workspace(N*OH*OW, C); the backward the pass-W buffer [N, OH, W, C4] + one float per output pixel —
+// segmi_upsample_lovasz_workspace covers both.
+size_t segmi_upsample_lovasz_workspace(int N, int H, int W, int C, int OH, int OW) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return 0;
+    const size_t a = segmi_lovasz_workspace((long)N * OH * OW, C);
+    if (!a) return 0;
+    const size_t b = align256((size_t)N * OH * W * ((C + 3) & ~3) * sizeof(float)) + align256((size_t)N * OH * OW * sizeof(float));
+    return a > b ? a : b;
+}
+
+int segmi_upsample_lovasz_fwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                              const int64_t* target, long ignore_index, float* lse, float* G, int ldg, float* loss_out,
+                              void* workspace, size_t workspace_bytes, segmi_stream_t stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
+    return lovasz_fwd_impl(lov_up_src(logits_lo, ld, H, W, OH, OW, align_corners), true, target, (long)N * OH * OW, C, ignore_index, lse, G,
+                           ldg, loss_out, workspace, workspace_bytes, stream);
+}
+
+int segmi_upsample_lovasz_bwd(const float* logits_lo, int ld, int N, int H, int W, int C, int OH, int OW, int align_corners,
+                              const int64_t* target, long ignore_index, const float* lse, const float* G, int ldg,
+                              const float* loss_out, const float* grad_out, float* dlogits_lo, int lddl, void* workspace,
+                              size_t workspace_bytes, segmi_stream_t stream) {
+    if (!logits_lo || !target || !lse || !G || !loss_out || !grad_out || !dlogits_lo || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 1820 ||
+        OH <= 0 || OW <= 0)
+        return SEGMI_ERR_BADARG;
+    const long rows = (long)N * OH * OW;
+    if (rows >= (1L << 24) || (long)N * OH * W >= (1L << 24)) return SEGMI_ERR_BADARG;
+    const int ldt = (C + 3) & ~3;
+    if ((ld & 3) || ld < ldt || (ldg & 3) || ldg < ldt || (lddl & 3) || lddl < ldt) return SEGMI_ERR_ALIGN;
+    const size_t tmp_bytes = align256((size_t)N * OH * W * ldt * sizeof(float));
+    if (!workspace || workspace_bytes < tmp_bytes + align256((size_t)rows * sizeof(float)) || ((uintptr_t)workspace & 255)) return SEGMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* tmp = (float*)workspace;
+    float* dot = (float*)((char*)workspace + tmp_bytes);
+    const LovSrc src = lov_up_src(logits_lo, ld, H, W, OH, OW, align_corners);
+    long b = (rows + 31) / 32;
+    if (b > 4 * SEGMI_MAX_GRID) b = 4 * SEGMI_MAX_GRID;
+    hipLaunchKernelGGL(lovasz_up_dot_kernel, dim3((unsigned)b), dim3(256), (size_t)C * 4, st, src, target, ignore_index, lse, G, ldg, rows, C, loss_out, dot);
+    const long total = (long)N * OH * W * (ldt / 4);
+    long wb = (total + 255) / 256;
+    if (wb > 4 * SEGMI_MAX_GRID) wb = 4 * SEGMI_MAX_GRID;
+    hipLaunchKernelGGL(lovasz_up_bwd_w_kernel, dim3((unsigned)wb), dim3(256), (size_t)C * 4, st, src, N, target, ignore_index, lse, (const float*)dot, G, ldg,
+                       C, loss_out, grad_out, tmp, ldt);
+    return segmi_internal_bilinear_bwd_height(tmp, ldt, dlogits_lo, lddl, N, H, W, C, OH, OW, src.ac, st);
 }
 
 int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ignore_index, const float* lse, const float* G, int ldg,

@@ -133,6 +133,9 @@ SIGNATURES = {
     "segmi_lovasz_workspace": (sz, [i64, i32]),
     "segmi_lovasz_fwd": (i32, [vp, i32, vp, i64, i32, i64, vp, vp, i32, vp, vp, sz, vp]),
     "segmi_lovasz_bwd": (i32, [vp, i32, vp, i64, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp]),
+    "segmi_upsample_lovasz_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
+    "segmi_upsample_lovasz_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, i32, vp, vp, sz, vp]),
+    "segmi_upsample_lovasz_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, i32, vp, vp, vp, i32, vp, sz, vp]),
     "segmi_seg_metrics": (i32, [vp, i32, vp, i64, i32, vp, vp]),
     "segmi_sgd_chunk_elems": (i32, []),
     "segmi_sgd_step": (i32, [vp, i32, vp, vp, vp, i32, vp]),

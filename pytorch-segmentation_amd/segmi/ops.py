@@ -20,7 +20,7 @@ from .profile import span
 
 __all__ = [
     "conv2d", "conv2d_skip", "conv2d_fan", "depthwise_conv2d", "conv_transpose2x2", "batch_norm_act", "relu", "add", "max_pool2d", "adaptive_avg_pool2d", "pyramid_pool", "pyramid_bottleneck_conv", "interpolate_bilinear",
-    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "batch_norm_depthwise", "batch_norm_depthwise_ok", "sync_groupable", "set_dropout_epoch",
+    "cat", "dropout", "cross_entropy", "upsampled_cross_entropy", "upsample_source", "dice_loss", "focal_loss", "lovasz_softmax", "upsampled_lovasz_softmax", "lovasz_last_stats", "seg_metrics_accumulate", "to_nhwc", "empty_nhwc", "is_nhwc", "pad4", "set_conv_winograd", "get_conv_winograd", "set_wgrad_stream", "get_wgrad_stream", "set_conv_bn_stats", "get_conv_bn_stats", "wgrad_stream_join", "register_grad_slots", "reset_grad_slots", "sync_batch_norm_group", "sync_batch_norm_residual_tail", "batch_norm_depthwise", "batch_norm_depthwise_ok", "sync_groupable", "set_dropout_epoch",
 ]
 
 
@@ -2063,26 +2063,44 @@ _LOVASZ_LAST = {"out": None}
 
 class _LovaszFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index):
-        logits, rows, C = _loss_inputs(logits, target, "lovasz_softmax")
+    def forward(ctx, logits, target, ignore_index, up):
+        # up = None: logits are at the target's resolution.  up = align_corners flag: logits are LOW resolution and the loss is
+        # that of their bilinear upsampling to the target's size (interpolation inside the kernels, like _CrossEntropyFn)
+        if up is None:
+            logits, rows, C = _loss_inputs(logits, target, "lovasz_softmax")
+            N, _, H, W = logits.shape
+            OH, OW = H, W
+        else:
+            logits = to_nhwc(logits, "lovasz_softmax")
+            N, C, H, W = logits.shape
+            if target.dtype != torch.int64 or not target.is_cuda or target.dim() != 3 or target.shape[0] != N:
+                raise SegmiError("lovasz_softmax: target must be an int64 CUDA tensor [N,OH,OW] (got %s for logits %s)"
+                                 % (tuple(target.shape), tuple(logits.shape)))
+            OH, OW = int(target.shape[1]), int(target.shape[2])
+            rows = N * OH * OW
         target = target.contiguous()
-        N, _, H, W = logits.shape
         dev, st = logits.device, _stream()
-        nws = lib.segmi_lovasz_workspace(rows, C)
+        nws = lib.segmi_lovasz_workspace(rows, C) if up is None else lib.segmi_upsample_lovasz_workspace(N, H, W, C, OH, OW)
         if nws == 0:
             raise SegmiError("lovasz_softmax: unsupported size (needs 0 < pixels < 2^24 and at most 1820 classes, got %d x %d)" % (rows, C))
         ws = workspace(nws + 256, dev)
         wp = (ws.data_ptr() + 255) & ~255
         lse = torch.empty(rows, device=dev, dtype=torch.float32)
         # G is written and read at the SURVIVOR entries only (see include/segmi.h): never cleared
-        G = empty_nhwc(N, C, H, W, dev)
+        G = empty_nhwc(N, C, OH, OW, dev)
         if os.environ.get("SEGMI_LOVASZ_POISON") == "1":          # tests: any read of an unwritten entry turns the gradient NaN
             G.fill_(float("nan"))
         out = torch.empty(4 + C, device=dev, dtype=torch.float32)
-        check(lib.segmi_lovasz_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
-                                   G.data_ptr(), ld_of(G), out.data_ptr(), wp, nws, st), "lovasz_fwd")
+        if up is None:
+            check(lib.segmi_lovasz_fwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), rows, C, ignore_index, lse.data_ptr(),
+                                       G.data_ptr(), ld_of(G), out.data_ptr(), wp, nws, st), "lovasz_fwd")
+        else:
+            check(lib.segmi_upsample_lovasz_fwd(logits.data_ptr(), ld_of(logits), N, H, W, C, OH, OW, 1 if up else 0, target.data_ptr(),
+                                                ignore_index, lse.data_ptr(), G.data_ptr(), ld_of(G), out.data_ptr(), wp, nws, st),
+                  "upsample_lovasz_fwd")
         ctx.save_for_backward(logits, target, lse, G, out)
         ctx.ignore_index = ignore_index
+        ctx.up = up
         _LOVASZ_LAST["out"] = out
         return out[0]
 
@@ -2092,14 +2110,30 @@ class _LovaszFn(torch.autograd.Function):
         N, C, H, W = logits.shape
         g = g.contiguous().float()
         dl = empty_nhwc(N, C, H, W, logits.device)
-        check(lib.segmi_lovasz_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), ctx.ignore_index, lse.data_ptr(), G.data_ptr(),
-                                   ld_of(G), N * H * W, C, out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "lovasz_bwd")
-        return dl, None, None
+        if ctx.up is None:
+            check(lib.segmi_lovasz_bwd(logits.data_ptr(), ld_of(logits), target.data_ptr(), ctx.ignore_index, lse.data_ptr(), G.data_ptr(),
+                                       ld_of(G), N * H * W, C, out.data_ptr(), g.data_ptr(), dl.data_ptr(), ld_of(dl), _stream()), "lovasz_bwd")
+        else:
+            OH, OW = int(target.shape[1]), int(target.shape[2])
+            nws = lib.segmi_upsample_lovasz_workspace(N, H, W, C, OH, OW)
+            ws = workspace(nws + 256, logits.device)
+            wp = (ws.data_ptr() + 255) & ~255
+            check(lib.segmi_upsample_lovasz_bwd(logits.data_ptr(), ld_of(logits), N, H, W, C, OH, OW, 1 if ctx.up else 0, target.data_ptr(),
+                                                ctx.ignore_index, lse.data_ptr(), G.data_ptr(), ld_of(G), out.data_ptr(), g.data_ptr(),
+                                                dl.data_ptr(), ld_of(dl), wp, nws, _stream()), "upsample_lovasz_bwd")
+        return dl, None, None, None
 
 
 def lovasz_softmax(logits, target, ignore_index=255):
     """LovaszSoftmax.forward of the reference (softmax + lovasz_softmax(classes='present', per_image=False, ignore=...))."""
-    return _LovaszFn.apply(logits, target, int(ignore_index))
+    return _LovaszFn.apply(logits, target, int(ignore_index), None)
+
+
+def upsampled_lovasz_softmax(logits_lo, target, align_corners=False, ignore_index=255):
+    """lovasz_softmax(F.interpolate(logits_lo, size=target.shape[1:], mode='bilinear', align_corners=...), target, ...) with the
+    interpolation evaluated inside the loss kernels: no [N,C,H,W] logits, no [N,C,H,W] gradient (include/segmi.h
+    segmi_upsample_lovasz_fwd / _bwd).  Bit-identical to the unfused form (tests/test_ops_gpu.py)."""
+    return _LovaszFn.apply(logits_lo, target, int(ignore_index), bool(align_corners))
 
 
 def lovasz_last_stats():

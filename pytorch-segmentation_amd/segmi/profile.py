@@ -53,12 +53,19 @@ MEMBOUND_BYTES = {
     "segmi_dwconv2d_fwd_stats": lambda a: _dw_bytes(a[0]),            # + the BN statistics partials (a few KB)
     "segmi_dwconv2d_dgrad": lambda a: _dw_bytes(a[0]),
     "segmi_dwconv2d_wgrad": lambda a: _dw_bytes(a[0]),
+    # the same with BatchNorm(+ReLU) applied to the loaded operand (round 6): the pre-normalisation tensor in, the output (or dy) once
+    "segmi_dwconv2d_fwd_pre": lambda a: _dw_bytes(a[0]),
+    "segmi_dwconv2d_wgrad_pre": lambda a: _dw_bytes(a[0]),
     # Lovasz forward, tail-pruned (round 5): the threshold of a class is a reduction over ALL its pixels, so the logits are read at
     # least twice (4 B each: threshold pass, selection pass) — the survivors' sort traffic (~0.7 % of the elements x 88 B) is below
     # 1 B per element and not counted.  The implementation reads them three times (threshold, count, emit).
     "segmi_lovasz_fwd": lambda a: 8 * a[3] * a[4],
     # backward: logits read, dlogits written (G only at the survivor entries)
     "segmi_lovasz_bwd": lambda a: _b4(2 * a[7] * a[8]),
+    # on upsampled logits: the low-resolution logits + target (8 B) and lse (4 B) per output pixel forward; backward the same reads,
+    # the per-pixel dot (4 B written + read), the pass-W buffer [N, OH, W, C] written + read, the low-resolution gradient written
+    "segmi_upsample_lovasz_fwd": lambda a: _b4(a[2] * a[3] * a[4] * a[5]) + 12 * a[2] * a[6] * a[7],
+    "segmi_upsample_lovasz_bwd": lambda a: 20 * a[2] * a[6] * a[7] + _b4(2 * a[2] * a[6] * a[4] * ((a[5] + 3) & ~3), 2 * a[2] * a[3] * a[4] * a[5]),
     "segmi_relu_fwd": lambda a: _b4(2 * a[4] * a[5]),
     "segmi_add": lambda a: _b4(3 * a[6] * a[7]),
 }

@@ -3,6 +3,8 @@
 `getattr(losses, config['loss'])(ignore_index=...)` (train.py:30) resolves these by name;
 forward(logits [N,C,H,W] fp32, target [N,H,W] int64) -> scalar.
 """
+import os
+
 import torch.nn as nn
 
 from segmi import ops
@@ -95,13 +97,19 @@ class LovaszSoftmax(nn.Module):
     (`classes` is stored in an attribute the reference never reads — utils/losses.py:82 — so 'present' is what runs.)
     Data parallel: the batch-level sort is not shard-decomposable, so each rank evaluates its own shard."""
 
-    def __init__(self, classes="present", per_image=False, ignore_index=255):
+    def __init__(self, classes="present", per_image=False, ignore_index=255, fuse_upsample=True):
         super().__init__()
         if per_image:
             raise NotImplementedError("per_image=True is never passed through by the reference's LovaszSoftmax.forward")
         self.smooth = classes
         self.per_image = per_image
         self.ignore_index = ignore_index
+        self.fuse_upsample = bool(fuse_upsample) and os.environ.get("SEGMI_LOVASZ_FUSE_UP", "1") != "0"      # (A/B hook)
 
     def forward(self, output, target):
+        src = ops.upsample_source(output) if self.fuse_upsample else None
+        if src is not None and tuple(output.shape[2:]) == tuple(target.shape[1:]):
+            # `output` is the model's final F.interpolate of low-resolution logits, untouched: the loss kernels interpolate on
+            # the fly (bit-identical value and gradient; at cfg5 the 1.26 GB logits and their gradient never exist)
+            return ops.upsampled_lovasz_softmax(src[0], target, src[1], self.ignore_index)
         return ops.lovasz_softmax(output, target, self.ignore_index)

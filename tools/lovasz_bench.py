@@ -2,6 +2,8 @@
 pruning, for three kinds of logits and with the pruning switched off (the round-4 full sort).
 
     python tools/lovasz_bench.py [--iters 10] [--modes random trained saturated] [--prune 1 0]
+    python tools/lovasz_bench.py --up 4 --prune 1      # the model's tail: logits at 1/4 resolution -> bilinear x4 (align_corners) -> loss,
+                                                       # forward + backward down to the low-resolution gradient, fused and unfused
 
 random    = random-init-like logits (what bench.py's synthetic step feeds the loss)
 trained   = the target logit boosted by 6 on 80 % of the pixels (confident and mostly right)
@@ -36,12 +38,36 @@ def main():
     ap.add_argument("--modes", nargs="+", default=["random", "trained", "saturated"])
     ap.add_argument("--prune", nargs="+", type=int, default=[1, 0])
     ap.add_argument("--shape", nargs=4, type=int, default=[8, 150, 512, 512])
+    ap.add_argument("--up", type=int, default=0, help="logits live at 1/UP of the target resolution (models/deeplabv3_plus.py:361)")
     a = ap.parse_args()
     from segmi import lib, ops
     import utils.losses as L
     dev = torch.device("cuda:0")
     N, C, H, W = a.shape
     crit = L.LovaszSoftmax(ignore_index=-1)
+    if a.up:
+        for mode in a.modes:
+            x, t = make(mode, N, C, H, W, dev)
+            lo = ops.to_nhwc(torch.nn.functional.avg_pool2d(x, a.up) * (2.0 if mode == "random" else 1.0)).detach()
+            del x
+            for fuse in (1, 0):
+                c2 = L.LovaszSoftmax(ignore_index=-1, fuse_upsample=bool(fuse))
+                ld = lo.clone().requires_grad_(True)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                tt = 0.0
+                for it in range(a.iters + 2):
+                    ld.grad = None
+                    ev[0].record()
+                    loss = c2(ops.interpolate_bilinear(ld, (H, W), True), t)
+                    loss.backward()
+                    ev[1].record()
+                    torch.cuda.synchronize()
+                    if it >= 2:
+                        tt += ev[0].elapsed_time(ev[1])
+                kept, full = ops.lovasz_last_stats()
+                print("%-9s up x%d fused=%d  upsample + fwd + bwd %7.3f ms  loss %.6f  survivors %.3f %% of C*P  |grad| %.6e"
+                      % (mode, a.up, fuse, tt / a.iters, loss.item(), 100.0 * kept / (C * N * H * W), ld.grad.abs().sum().item()), flush=True)
+        return
     for mode in a.modes:
         x, t = make(mode, N, C, H, W, dev)
         for prune in a.prune:
