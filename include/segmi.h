@@ -440,11 +440,13 @@ int segmi_focal_bwd(const float* logits, int ld, const int64_t* target, const fl
  * per_image=False: softmax; ignored pixels dropped; per present class sort |fg - p_c| descending, Jaccard-gradient dot;
  * mean over present classes.  The C per-class sorts run as ONE segmented radix sort over the elements that can matter: an
  * element ranked after its class's last foreground element has Jaccard difference exactly 0 (lovasz_grad :19-31), so only
- * elements with error >= the class's smallest foreground error are sorted ("survivors", a prefix of the full order: loss and
- * gradient are bit-identical to the full sort).
+ * elements with error >= the class's smallest foreground error need sorting.  The "survivors" are the foreground elements plus
+ * the background elements with z - lse >= xthr[c] = log(that error) minus a rounding margin — a slight superset of that prefix of
+ * the full order, selected without evaluating exp; the extra elements rank where the Jaccard difference is 0, so loss and gradient
+ * are bit-identical to the full sort.
  * G (rows*ldg floats, ldg >= round_up(C,4), pixel-major) receives d loss_c / d p (un-normalised) for SURVIVOR entries only; it
  * is neither cleared nor read elsewhere: the backward re-derives the survivor set from logits, lse, target and the thresholds.
- * loss_out[4 + C] = {loss, n_present, survivors, n_present * n_valid (= keys of the full sort), thr[C] (uint32 error bits)}
+ * loss_out[4 + C] = {loss, n_present, survivors, n_present * n_valid (= keys of the full sort), xthr[C] (keep thresholds on z - lse)}
  * must reach segmi_lovasz_bwd unchanged together with lse and G.  At most 1820 classes.
  * rows < 2^24 (the reference's fp32 cumsums are exact only below that) and log2(C) + log2(rows) <= 32.  workspace must be
  * 256-byte aligned; its size covers the worst case (every element survives). */

@@ -177,12 +177,11 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const fl
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res,
                                                        int ldr, float* __restrict__ y, int ldy, long rows, int c4n,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift, long rflip) {
+                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= c4n) return;
     const float4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
-    for (long r0 = (long)blockIdx.y * blockDim.y + threadIdx.y; r0 < rows; r0 += (long)gridDim.y * blockDim.y) {
-        const long r = rflip >= 0 ? rflip - r0 : r0;          // row order in TIME (see bn_row_order)
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
         float4 v = ld4(x + r * ldx + c4 * 4);
         v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
         if (RES) {
@@ -205,14 +204,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int ldx, const float* __restrict__ y, int ldy, long rows, int c4n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            double* __restrict__ part, long rflip) {
+                                                            double* __restrict__ part) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool cok = c4 < c4n;
     D4 s0 = dzero4(), s1 = dzero4();
-    if (rflip >= 0) {          // the same rows, walked from the last one down: offset the three tensors to their last row, negate the strides
-        dy += rflip * lddy; x += rflip * ldx; if (y) y += rflip * ldy;
-        lddy = -lddy; ldx = -ldx; ldy = -ldy;
-    }
     if (cok) {
         const float4 mu = ld4(mean + c4 * 4);
         float4 sc = zero4(), sh = zero4();
@@ -312,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sums,
                                                            float inv_count, const float* __restrict__ count_dev,
                                                            float* __restrict__ dx, int lddx,
-                                                           float* __restrict__ dres, int lddres, long rflip) {
+                                                           float* __restrict__ dres, int lddres) {
     const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c4 >= c4n) return;
     if (TRAIN && count_dev) inv_count = 1.f / count_dev[0];
@@ -327,8 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         k0 = make_float4(a.x * inv_count, a.y * inv_count, a.z * inv_count, a.w * inv_count);
         k1 = make_float4(b.x * inv_count, b.y * inv_count, b.z * inv_count, b.w * inv_count);
     }
-    for (long r0 = (long)blockIdx.y * blockDim.y + threadIdx.y; r0 < rows; r0 += (long)gridDim.y * blockDim.y) {
-        const long r = rflip >= 0 ? rflip - r0 : r0;
+    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
         float4 g = ld4(dy + r * lddy + c4 * 4);
         float4 v = zero4();
         if (TRAIN || (RELU && !y)) v = ld4(x + r * ldx + c4 * 4);
@@ -591,24 +585,13 @@ int segmi_bn_eval_coeffs(const float* running_mean, const float* running_var, co
     return segmi_launch_status();
 }
 
-// ORDER IN TIME of the row sweeps (experiment, SEGMI_BN_REV bit mask: 1 = bn_bwd_reduce, 2 = bn_bwd_apply, 4 = bn_apply walk their rows
-// from the last one down).  Every kernel here is a grid-stride sweep, i.e. the chip moves through a tensor from row 0 upwards; the
-// kernel before it (a convolution writing dy, bn_bwd_reduce reading dy and x) did the same, so with an LRU-like memory-side cache
-// (256 MB MALL) smaller than the tensors the rows a sweep starts with are exactly the ones evicted longest ago.  Walking the
-// opposite way starts with the most recently touched rows.
-static long bn_rflip(int bit, long rows) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SEGMI_BN_REV"); v = e ? atoi(e) : 0; }
-    return (v & bit) ? rows - 1 : -1;
-}
-
 int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, long rows, int C,
                    const float* scale, const float* shift, int relu, segmi_stream_t stream) {
     if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return SEGMI_ERR_BADARG;
     if ((C & 3) || !ld_ok(ldx, C) || !ld_ok(ldy, C) || (residual && !ld_ok(ldr, C))) return SEGMI_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
-#define LAUNCH_APPLY(R, S) hipLaunchKernelGGL((bn_apply_kernel<R, S>), g.grid, g.block, 0, st, x, ldx, residual, ldr, y, ldy, rows, g.c4, scale, shift, bn_rflip(4, rows))
+#define LAUNCH_APPLY(R, S) hipLaunchKernelGGL((bn_apply_kernel<R, S>), g.grid, g.block, 0, st, x, ldx, residual, ldr, y, ldy, rows, g.c4, scale, shift)
     if (relu) { if (residual) LAUNCH_APPLY(true, true); else LAUNCH_APPLY(true, false); }
     else      { if (residual) LAUNCH_APPLY(false, true); else LAUNCH_APPLY(false, false); }
 #undef LAUNCH_APPLY
@@ -619,6 +602,11 @@ int segmi_bn_apply(const float* x, int ldx, const float* residual, int ldr, floa
 // layer is one block column wide and ran on half the chip with the former rows/256 rule — but >= 16 rows per thread.
 static int bwd_parts(long rows, int C) {
     const RowGeom g = row_geom(rows, C, 1, 1);
+    // (round 6, alternating cfg2 runs: 1024 / 1536 / 3072 workgroups 57.21 / 57.15 / 57.03 ms against 56.4-56.9 for 2048 — the kernel
+    //  holds 116 VGPRs, 4 workgroups per CU: 2048 is two full rounds.  Walking the rows of bn_bwd_reduce / bn_bwd_apply / bn_apply from
+    //  the last one down, so that a sweep starts with the rows the kernel before it touched last, changed nothing either: 56.2-56.8
+    //  against 56.0-56.8 ms for every combination — the 256 MB memory-side cache does not turn that recency into hits.
+    //  profiles/r06_bn_order_and_blocks_ab.txt)
     long p = 2048 / (long)g.grid.x;
     const long cap = (rows + (long)g.ry * 16 - 1) / ((long)g.ry * 16);
     if (p > cap) p = cap;
@@ -642,8 +630,8 @@ int segmi_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, cons
     RowGeom g = row_geom(rows, C, 1, 1);
     g.grid.y = parts;
     if ((uintptr_t)workspace & 7) return SEGMI_ERR_ALIGN;
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, bn_rflip(1, rows));
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace, bn_rflip(1, rows));
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, (double*)workspace);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(segmi_cdiv(2 * C, 32)), dim3(32, 32), 0, st, (const double*)workspace, parts, 2 * C, sums);
     return segmi_launch_status();
 }
@@ -661,7 +649,7 @@ int segmi_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const
     hipStream_t st = (hipStream_t)stream;
     RowGeom g = row_geom(rows, C, 4, SEGMI_MAX_GRID);
     const float inv = (training && !count_dev) ? 1.f / count : 0.f;
-#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, sums, inv, count_dev, dx, lddx, dres, lddres, bn_rflip(2, rows))
+#define LAUNCH_BA(R, T, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, T, D>), g.grid, g.block, 0, st, dy, lddy, x, ldx, y, ldy, rows, g.c4, mean, invstd, scale, shift, sums, inv, count_dev, dx, lddx, dres, lddres)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH_BA(false, false, false); break;

@@ -15,7 +15,8 @@
 // beyond a class's survivor count leave at once):
 //   1. lovasz_prepare     per pixel: log-sum-exp; histogram of labels (class presence, |fg_c|), number of valid pixels,
 //                         thr[c] = atomicMin over fg pixels of the error bits (LDS first, then global)
-//   2. lovasz_keep_count  per (class, 256-pixel unit): number of survivors;  lovasz_keep_scan: exclusive scan per class
+//   2. lovasz_keep_count  per (class, 256-pixel unit): number of survivors (keep test in the logit domain, see lov_xthr: no exp);
+//                         lovasz_keep_scan: exclusive scan per class
 //   3. lovasz_emit        one 64-bit word per SURVIVOR, compacted class-major in pixel order (deterministic: unit offsets +
 //                         ballot ranks):  [class | invalid(0) | ~bits30(|fg - p_c|) | fg | pixel index]
 //                         (errors lie in [0, 2): their float bits fit 30 bits).
@@ -28,8 +29,8 @@
 //      sorted errors, and scatter of d loss / d p into the pixel-major G[pixel][class] — SURVIVOR entries only.
 //   6. lovasz_finalize    loss = mean over present classes; survivor statistics; effective thresholds for the backward.
 //   backward: dz_c = g * p_c * (G_c - sum_j G_j p_j) / n_present   (softmax Jacobian).  G is read ONLY where the forward's
-//   keep test (recomputed from logits, lse, target and the saved thresholds: same instructions, same bits) says an entry was
-//   written; everything else is 0 by the identity above — G is never cleared and never read densely.
+//   keep test (recomputed from logits, lse, target and the saved logit-domain thresholds: same subtraction, same compare) says an
+//   entry was written; everything else is 0 by the identity above — G is never cleared and never read densely.
 //
 // Ties: elements of one class with bit-equal errors are ranked in pixel order (stable sort of a pixel-ordered emission;
 // torch.sort is unstable); the loss value does not depend on that order, the per-pixel gradients inside a tie group do.
@@ -54,6 +55,21 @@ constexpr unsigned NO_THR = 0xFFFFFFFFu;   // threshold of a class without foreg
 __device__ __forceinline__ float lov_p(float z, float l) { return expf(__fsub_rn(z, l)); }
 __device__ __forceinline__ unsigned lov_p_err_bits(float p, bool fg) { return __float_as_uint(fabsf(__fsub_rn(fg ? 1.f : 0.f, p))); }
 __device__ __forceinline__ unsigned lov_err_bits(float z, float l, bool fg) { return lov_p_err_bits(lov_p(z, l), fg); }
+// THE KEEP TEST, IN THE LOGIT DOMAIN (round 6).  A foreground element always survives (thr[c] is the minimum over the class's
+// foreground errors).  A background element's error is p itself, so "p >= thr" is "z - lse >= log thr": ONE subtraction and a
+// compare instead of an exp per element in the count, emit and dot passes (they were as ALU-bound — 315 M expf at cfg5 — as they
+// are HBM-bound).  xthr = log(thr) lowered by more than the rounding of expf and logf, so that every element with
+// expf(z - lse) >= thr passes: the survivors are a SUPERSET of the exact prefix, and the extra elements (p within ~1e-6 relative
+// below thr) rank after the class's last foreground element, where the Jaccard difference is exactly 0 — loss and gradient stay
+// bit-identical to the full sort.  All passes compare the SAME float d = __fsub_rn(z, lse) with the SAME xthr[c] (computed once, by
+// the count kernel, and handed on through the workspace and loss_out), so they decide alike.
+__device__ __forceinline__ float lov_xthr(unsigned thr_eff) {
+    if (thr_eff == NO_THR) return INFINITY;              // absent class: nothing survives
+    if (thr_eff == 0u) return -INFINITY;                 // pruning off, or a foreground probability that rounds to 1: every valid pixel
+    const float lg = logf(__uint_as_float(thr_eff));     // thr in (0, 1]: lg <= 0
+    return lg - (fabsf(lg) * 1e-6f + 4e-6f);
+}
+__device__ __forceinline__ bool lov_keep(float d, bool fg, float xthr) { return fg || d >= xthr; }
 // effective threshold of class c: absent classes keep nothing; prune == 0 keeps every valid pixel of a present class (the
 // round-4 full sort, kept for A/B and as the bit-identity reference of the tests)
 __device__ __forceinline__ unsigned lov_thr_eff(const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int c, int prune) {
@@ -196,12 +212,16 @@ template <int KQ, bool UP>
 __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const LovSrc src, const int64_t* __restrict__ target,
                                                                 const float* __restrict__ lse, long rows, int C, long ignore,
                                                                 const unsigned* __restrict__ thr, const unsigned* __restrict__ counts,
-                                                                int prune, long nunits, unsigned* __restrict__ cnt) {
-    extern __shared__ unsigned sh[];     // thr_s[C], run[4][C]
-    unsigned* thr_s = sh;
+                                                                int prune, long nunits, unsigned* __restrict__ cnt, float* __restrict__ xthr_out) {
+    extern __shared__ unsigned sh[];     // xthr_s[C], run[4][C]
+    float* xthr_s = reinterpret_cast<float*>(sh);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 7, pj = lane >> 3;
     unsigned* run = sh + C + w * C;
-    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = lov_thr_eff(thr, counts, i, prune);
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const float xt = lov_xthr(lov_thr_eff(thr, counts, i, prune));
+        xthr_s[i] = xt;
+        if (blockIdx.x == 0) xthr_out[i] = xt;           // for the emit pass and (through loss_out) the backward
+    }
     for (int i = threadIdx.x; i < 4 * C; i += 256) sh[C + i] = 0u;
     __syncthreads();
     const long unit = (long)blockIdx.x * 4 + w;
@@ -224,10 +244,10 @@ __global__ __launch_bounds__(256) void lovasz_keep_count_kernel(const LovSrc src
             for (int k = 0; k < trips; ++k) {
                 const int q = g + 8 * k, c = q * 4;
                 const float4 v = R.get(row, k, q);
-                if (c < C && lov_err_bits(v.x, l, t == c) >= thr_s[c]) atomicAdd(&run[c], 1u);
-                if (c + 1 < C && lov_err_bits(v.y, l, t == c + 1) >= thr_s[c + 1]) atomicAdd(&run[c + 1], 1u);
-                if (c + 2 < C && lov_err_bits(v.z, l, t == c + 2) >= thr_s[c + 2]) atomicAdd(&run[c + 2], 1u);
-                if (c + 3 < C && lov_err_bits(v.w, l, t == c + 3) >= thr_s[c + 3]) atomicAdd(&run[c + 3], 1u);
+                if (c < C && lov_keep(__fsub_rn(v.x, l), t == c, xthr_s[c])) atomicAdd(&run[c], 1u);
+                if (c + 1 < C && lov_keep(__fsub_rn(v.y, l), t == c + 1, xthr_s[c + 1])) atomicAdd(&run[c + 1], 1u);
+                if (c + 2 < C && lov_keep(__fsub_rn(v.z, l), t == c + 2, xthr_s[c + 2])) atomicAdd(&run[c + 2], 1u);
+                if (c + 3 < C && lov_keep(__fsub_rn(v.w, l), t == c + 3, xthr_s[c + 3])) atomicAdd(&run[c + 3], 1u);
             }
         }
     }
@@ -271,14 +291,14 @@ __global__ __launch_bounds__(KS_T) void lovasz_keep_scan_kernel(unsigned* __rest
 template <int KQ, bool UP>
 __global__ __launch_bounds__(256) void lovasz_emit_kernel(const LovSrc src, const int64_t* __restrict__ target,
                                                           const float* __restrict__ lse, long rows, int C, long ignore, int PB,
-                                                          const unsigned* __restrict__ thr, const unsigned* __restrict__ counts, int prune,
+                                                          const float* __restrict__ xthr,
                                                           long nunits, const unsigned* __restrict__ cnt, unsigned long long* __restrict__ keys) {
-    extern __shared__ unsigned sh[];     // thr_s[C], slot[4][C]
-    unsigned* thr_s = sh;
+    extern __shared__ unsigned sh[];     // xthr_s[C], slot[4][C]
+    float* xthr_s = reinterpret_cast<float*>(sh);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 7, pj = lane >> 3;
     volatile unsigned* slot = sh + C + w * C;
     const long unit = (long)blockIdx.x * 4 + w;
-    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = lov_thr_eff(thr, counts, i, prune);
+    for (int i = threadIdx.x; i < C; i += 256) xthr_s[i] = xthr[i];
     if (unit < nunits)
         for (int c = lane; c < C; c += 64) slot[c] = cnt[(long)c * nunits + unit];
     __syncthreads();
@@ -307,17 +327,9 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const LovSrc src, cons
             float4 v = zero4();
             if (qok) v = R.get(row, k, q);
             const float zs[4] = {v.x, v.y, v.z, v.w};
-            unsigned eb[4];
             bool kp[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                eb[j] = 0u;
-                kp[j] = false;
-                if (qok && c + j < C) {
-                    eb[j] = lov_err_bits(zs[j], l, t == c + j);
-                    kp[j] = eb[j] >= thr_s[c + j];
-                }
-            }
+            for (int j = 0; j < 4; ++j) kp[j] = qok && c + j < C && lov_keep(__fsub_rn(zs[j], l), t == c + j, xthr_s[c + j]);
             if (__ballot(kp[0] || kp[1] || kp[2] || kp[3]) == 0ull) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -328,7 +340,8 @@ __global__ __launch_bounds__(256) void lovasz_emit_kernel(const LovSrc src, cons
                     const unsigned before = slot[cc];
                     if (rank == 0) slot[cc] = before + n;
                     const bool fg = t == cc;
-                    const unsigned long long inv30 = (unsigned long long)((~eb[j]) & 0x3FFFFFFFu);
+                    const unsigned eb = lov_err_bits(zs[j], l, fg);              // the exp: survivors only
+                    const unsigned long long inv30 = (unsigned long long)((~eb) & 0x3FFFFFFFu);
                     keys[(long)cc * rows + before + rank] = ((((unsigned long long)cc << 1) << 30 | inv30) << 1 | (fg ? 1ull : 0ull)) << PB |
                                                             (unsigned long long)r;
                 }
@@ -670,10 +683,10 @@ __global__ __launch_bounds__(256) void lovasz_grad_dot_kernel(const unsigned lon
 }
 
 // loss_out = {mean over present classes of loss_c, n_present, survivors, n_present * n_valid (the keys of the unpruned
-// formulation), thr_eff[C] (bits)}: the thresholds travel to the backward inside the caller's tensor
+// formulation), xthr[C] (the keep thresholds in the logit domain)}: the thresholds travel to the backward inside the caller's tensor
 constexpr int FIN_T = 1024;
 __global__ __launch_bounds__(FIN_T) void lovasz_finalize_kernel(const double* __restrict__ part, int nchunks, const unsigned* __restrict__ counts,
-                                                                const unsigned* __restrict__ nkept, const unsigned* __restrict__ thr, int prune,
+                                                                const unsigned* __restrict__ nkept, const float* __restrict__ xthr,
                                                                 int C, float* __restrict__ loss_out) {
     __shared__ double sm[FIN_T], sk[FIN_T];
     __shared__ int np[FIN_T];
@@ -684,7 +697,7 @@ __global__ __launch_bounds__(FIN_T) void lovasz_finalize_kernel(const double* __
     for (int c = threadIdx.x; c < C; c += FIN_T) {
         present += counts[c] != 0;
         kept += (double)nkept[c];
-        reinterpret_cast<unsigned*>(loss_out)[4 + c] = lov_thr_eff(thr, counts, c, prune);
+        loss_out[4 + c] = xthr[c];
     }
     // wave w sums classes w, w + 16, ...: lane l takes chunks l, l + 64, ... of the class (fixed order -> deterministic)
     double t0 = 0.0;
@@ -716,8 +729,8 @@ __device__ __forceinline__ float grp_sum8(float v) {
 // dz_c = g / n_present * p_c * (G_c - sum_j G_j p_j), streaming: 8 lanes share a pixel like the forward's passes.  G_c is
 // fetched only where the forward's keep test holds (the same lov_err_bits against the thresholds the forward saved) — a
 // sparse gather of the survivor entries; every other G_c is exactly 0.
-__device__ __forceinline__ float lov_g(const float* __restrict__ grow, const unsigned* thr_s, float p, long t, int c) {
-    return lov_p_err_bits(p, t == c) >= thr_s[c] ? grow[c] : 0.f;      // p = lov_p(z, lse): ONE exp per element serves the keep test and the product
+__device__ __forceinline__ float lov_g(const float* __restrict__ grow, const float* xthr_s, float d, long t, int c) {
+    return lov_keep(d, t == c, xthr_s[c]) ? grow[c] : 0.f;             // d = __fsub_rn(z, lse), the forward's test
 }
 template <int KQ>
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
@@ -725,8 +738,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ G, int ldg, long rows, int C,
                                                          const float* __restrict__ loss_out, const float* __restrict__ grad_out,
                                                          float* __restrict__ dl, int lddl) {
-    extern __shared__ unsigned thr_s[];                  // C
-    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    extern __shared__ float thr_s[];                     // C: xthr
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = loss_out[4 + i];
     __syncthreads();
     const int g = threadIdx.x & (LPP - 1);
     const int c4n = (C + 3) >> 2;
@@ -752,12 +765,11 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
         for (int k = 0; k < trips; ++k) {
             const int q = g + 8 * k, c = q * 4;
             const float4 v = R.get(row, k, q);
-            float4 p = zero4();
-            if (c < C) { p.x = lov_p(v.x, l); s += lov_g(grow, thr_s, p.x, t, c) * p.x; }
-            if (c + 1 < C) { p.y = lov_p(v.y, l); s += lov_g(grow, thr_s, p.y, t, c + 1) * p.y; }
-            if (c + 2 < C) { p.z = lov_p(v.z, l); s += lov_g(grow, thr_s, p.z, t, c + 2) * p.z; }
-            if (c + 3 < C) { p.w = lov_p(v.w, l); s += lov_g(grow, thr_s, p.w, t, c + 3) * p.w; }
-            if (KQ > 0) R.v[k] = p;
+            // (only survivors contribute: G_j = 0 elsewhere — the exp is evaluated for them alone)
+            if (c < C) { const float d = __fsub_rn(v.x, l); const float gj = lov_g(grow, thr_s, d, t, c); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 1 < C) { const float d = __fsub_rn(v.y, l); const float gj = lov_g(grow, thr_s, d, t, c + 1); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 2 < C) { const float d = __fsub_rn(v.z, l); const float gj = lov_g(grow, thr_s, d, t, c + 2); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 3 < C) { const float d = __fsub_rn(v.w, l); const float gj = lov_g(grow, thr_s, d, t, c + 3); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
         }
         s = grp_sum8(s);
         // sweep 2: dz_c = gs * p_c * (G_c - s)
@@ -765,17 +777,13 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
         for (int k = 0; k < trips; ++k) {
             const int q = g + 8 * k, c = q * 4;
             if (q >= c4n) continue;
-            float4 p;
-            if (KQ > 0) p = R.v[k];
-            else {
-                const float4 v = row.get(q);
-                p = make_float4(lov_p(v.x, l), lov_p(v.y, l), lov_p(v.z, l), lov_p(v.w, l));
-            }
+            const float4 v = R.get(row, k, q);
+            const float4 e = make_float4(__fsub_rn(v.x, l), __fsub_rn(v.y, l), __fsub_rn(v.z, l), __fsub_rn(v.w, l));
             float4 d = zero4();
-            d.x = gs * p.x * (lov_g(grow, thr_s, p.x, t, c) - s);
-            if (c + 1 < C) d.y = gs * p.y * (lov_g(grow, thr_s, p.y, t, c + 1) - s);
-            if (c + 2 < C) d.z = gs * p.z * (lov_g(grow, thr_s, p.z, t, c + 2) - s);
-            if (c + 3 < C) d.w = gs * p.w * (lov_g(grow, thr_s, p.w, t, c + 3) - s);
+            d.x = __fmul_rn(__fmul_rn(gs, expf(e.x)), __fsub_rn(lov_g(grow, thr_s, e.x, t, c), s));
+            if (c + 1 < C) d.y = __fmul_rn(__fmul_rn(gs, expf(e.y)), __fsub_rn(lov_g(grow, thr_s, e.y, t, c + 1), s));
+            if (c + 2 < C) d.z = __fmul_rn(__fmul_rn(gs, expf(e.z)), __fsub_rn(lov_g(grow, thr_s, e.z, t, c + 2), s));
+            if (c + 3 < C) d.w = __fmul_rn(__fmul_rn(gs, expf(e.w)), __fsub_rn(lov_g(grow, thr_s, e.w, t, c + 3), s));
             st4(drow + q * 4, d);
         }
     }
@@ -787,8 +795,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void lovasz_up_dot_kernel(const LovSrc src, const int64_t* __restrict__ target, long ignore,
                                                             const float* __restrict__ lse, const float* __restrict__ G, int ldg, long rows,
                                                             int C, const float* __restrict__ loss_out, float* __restrict__ dot) {
-    extern __shared__ unsigned thr_s[];                  // C
-    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    extern __shared__ float thr_s[];                     // C: xthr
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = loss_out[4 + i];
     __syncthreads();
     const int g = threadIdx.x & (LPP - 1);
     const int c4n = (C + 3) >> 2;
@@ -803,10 +811,10 @@ __global__ __launch_bounds__(256) void lovasz_up_dot_kernel(const LovSrc src, co
         for (int q = g; q < c4n; q += LPP) {
             const int c = q * 4;
             const float4 v = row.get(q);
-            if (c < C) { const float p = lov_p(v.x, l); s += lov_g(grow, thr_s, p, t, c) * p; }
-            if (c + 1 < C) { const float p = lov_p(v.y, l); s += lov_g(grow, thr_s, p, t, c + 1) * p; }
-            if (c + 2 < C) { const float p = lov_p(v.z, l); s += lov_g(grow, thr_s, p, t, c + 2) * p; }
-            if (c + 3 < C) { const float p = lov_p(v.w, l); s += lov_g(grow, thr_s, p, t, c + 3) * p; }
+            if (c < C) { const float d = __fsub_rn(v.x, l); const float gj = lov_g(grow, thr_s, d, t, c); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 1 < C) { const float d = __fsub_rn(v.y, l); const float gj = lov_g(grow, thr_s, d, t, c + 1); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 2 < C) { const float d = __fsub_rn(v.z, l); const float gj = lov_g(grow, thr_s, d, t, c + 2); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
+            if (c + 3 < C) { const float d = __fsub_rn(v.w, l); const float gj = lov_g(grow, thr_s, d, t, c + 3); if (gj != 0.f) s = fmaf(gj, expf(d), s); }
         }
         s = grp_sum8(s);
         if (g == 0) dot[r] = s;
@@ -824,8 +832,8 @@ __global__ __launch_bounds__(256) void lovasz_up_bwd_w_kernel(const LovSrc src, 
                                                               const float* __restrict__ G, int ldg, int C,
                                                               const float* __restrict__ loss_out, const float* __restrict__ grad_out,
                                                               float* __restrict__ tmp, int ldt) {
-    extern __shared__ unsigned thr_s[];                  // C
-    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = reinterpret_cast<const unsigned*>(loss_out)[4 + i];
+    extern __shared__ float thr_s[];                     // C: xthr
+    for (int i = threadIdx.x; i < C; i += 256) thr_s[i] = loss_out[4 + i];
     __syncthreads();
     const int c4n = (C + 3) >> 2;
     const int H = src.H, W = src.W, OH = src.OH, OW = src.OW, ac = src.ac;
@@ -867,8 +875,8 @@ __global__ __launch_bounds__(256) void lovasz_up_bwd_w_kernel(const LovSrc src, 
             float zz, p, dz;
 #define LOV_UPW(comp, cc)                                                                                                         \
             zz = lov_lerp(a.l0, lov_lerp(b.l0, v00.comp, b.l1, v01.comp), a.l1, lov_lerp(b.l0, v10.comp, b.l1, v11.comp));             \
-            p = lov_p(zz, l);                                                                                                     \
-            dz = __fmul_rn(__fmul_rn(gs, p), __fsub_rn(lov_g(grow, thr_s, p, t, cc), d));                                         \
+            p = __fsub_rn(zz, l);                                                                                                 \
+            dz = __fmul_rn(__fmul_rn(gs, expf(p)), __fsub_rn(lov_g(grow, thr_s, p, t, cc), d));                                   \
             acc.comp = fmaf(wt, dz, acc.comp);
             LOV_UPW(x, c)
             if (c + 1 < C) { LOV_UPW(y, c + 1) }
@@ -893,7 +901,7 @@ int lov_kq(int C) {
     }
 
 struct LovaszLayout {
-    size_t keys_a, keys_b, chunk_fg, counts, thr, nkept, part, cnt, temp, total;
+    size_t keys_a, keys_b, chunk_fg, counts, thr, xthr, nkept, part, cnt, temp, total;
     int nchunks, PB, ntiles;
     long nunits;
 };
@@ -926,6 +934,7 @@ bool lovasz_layout(long rows, int C, LovaszLayout* L) {
     L->chunk_fg = off; off += align256((size_t)C * L->nchunks * 4);
     L->counts = off; off += align256((size_t)(C + 1) * 4);
     L->thr = off; off += align256((size_t)C * 4);
+    L->xthr = off; off += align256((size_t)C * 4);
     L->nkept = off; off += align256((size_t)C * 4);
     L->part = off; off += align256((size_t)C * L->nchunks * 8);
     L->cnt = off; off += align256((size_t)C * L->nunits * 4);
@@ -969,6 +978,7 @@ int lovasz_fwd_impl(const LovSrc lsrc, bool up, const int64_t* target, long rows
     unsigned* chunk_fg = (unsigned*)(ws + L.chunk_fg);
     unsigned* counts = (unsigned*)(ws + L.counts);
     unsigned* thr = (unsigned*)(ws + L.thr);
+    float* xthr = (float*)(ws + L.xthr);
     unsigned* nkept = (unsigned*)(ws + L.nkept);
     unsigned* cnt = (unsigned*)(ws + L.cnt);
     double* part = (double*)(ws + L.part);
@@ -984,10 +994,10 @@ int lovasz_fwd_impl(const LovSrc lsrc, bool up, const int64_t* target, long rows
                                               ignore_index, lse, counts, thr)
 #define LOV_PREPARE(K) do { if (up) LOV_PREPARE_(K, true); else LOV_PREPARE_(K, false); } while (0)
 #define LOV_COUNT_(K, U) hipLaunchKernelGGL((lovasz_keep_count_kernel<K, U>), dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, lsrc, target, (const float*)lse, \
-                                            rows, C, ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt)
+                                            rows, C, ignore_index, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, cnt, xthr)
 #define LOV_COUNT(K) do { if (up) LOV_COUNT_(K, true); else LOV_COUNT_(K, false); } while (0)
 #define LOV_EMIT_(K, U) hipLaunchKernelGGL((lovasz_emit_kernel<K, U>), dim3(ublocks), dim3(256), (size_t)(5 * C) * 4, st, lsrc, target, (const float*)lse, rows, C, \
-                                           ignore_index, L.PB, (const unsigned*)thr, (const unsigned*)counts, prune, L.nunits, (const unsigned*)cnt, ka)
+                                           ignore_index, L.PB, (const float*)xthr, L.nunits, (const unsigned*)cnt, ka)
 #define LOV_EMIT(K) do { if (up) LOV_EMIT_(K, true); else LOV_EMIT_(K, false); } while (0)
     // measured at C = 150 (profiles/r05_lovasz_alone_kernel_stats*.csv): prepare<5> 267 us against 384 us for the re-reading form;
     // count<5> 255 against 258 (no gain); emit<5> 667 against 410 (the unrolled ballot groups need 212 VGPRs: 2 waves per SIMD) —
@@ -1026,7 +1036,7 @@ int lovasz_fwd_impl(const LovSrc lsrc, bool up, const int64_t* target, long rows
     hipLaunchKernelGGL(lovasz_grad_dot_kernel, jgrid, dim3(256), 0, st, ks, rows, L.nchunks, (const unsigned*)counts, (const unsigned*)nkept, L.PB,
                        (const unsigned*)chunk_fg, G, ldg, part);
     hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const double*)part, L.nchunks, (const unsigned*)counts,
-                       (const unsigned*)nkept, (const unsigned*)thr, prune, C, loss_out);
+                       (const unsigned*)nkept, (const float*)xthr, C, loss_out);
     return segmi_launch_status();
 }
 

@@ -95,21 +95,23 @@ class CE_DiceLoss(nn.Module):
 class LovaszSoftmax(nn.Module):
     """Reference utils/losses.py:79-89: softmax + Lovasz-Softmax over the whole batch, classes present in the labels.
     (`classes` is stored in an attribute the reference never reads — utils/losses.py:82 — so 'present' is what runs.)
-    Data parallel: the batch-level sort is not shard-decomposable, so each rank evaluates its own shard."""
+    Data parallel: the batch-level sort is not shard-decomposable, so each rank evaluates its own shard.
+    fuse_upsample (default off; SEGMI_LOVASZ_FUSE_UP=1 turns it on): evaluate the loss of the model's final F.interpolate from the
+    LOW-resolution logits (ops.upsampled_lovasz_softmax: bit-identical value and gradient, the 1.26 GB logits gradient of cfg5
+    never exists) — built and measured in round 6: the Lovasz passes are latency- and ALU-bound, not HBM-bound, at 150 classes,
+    and interpolating on the fly made the step 0.1-0.7 ms SLOWER (profiles/r06_lovasz_fused_upsample.txt)."""
 
-    def __init__(self, classes="present", per_image=False, ignore_index=255, fuse_upsample=True):
+    def __init__(self, classes="present", per_image=False, ignore_index=255, fuse_upsample=None):
         super().__init__()
         if per_image:
             raise NotImplementedError("per_image=True is never passed through by the reference's LovaszSoftmax.forward")
         self.smooth = classes
         self.per_image = per_image
         self.ignore_index = ignore_index
-        self.fuse_upsample = bool(fuse_upsample) and os.environ.get("SEGMI_LOVASZ_FUSE_UP", "1") != "0"      # (A/B hook)
+        self.fuse_upsample = os.environ.get("SEGMI_LOVASZ_FUSE_UP", "0") == "1" if fuse_upsample is None else bool(fuse_upsample)
 
     def forward(self, output, target):
         src = ops.upsample_source(output) if self.fuse_upsample else None
         if src is not None and tuple(output.shape[2:]) == tuple(target.shape[1:]):
-            # `output` is the model's final F.interpolate of low-resolution logits, untouched: the loss kernels interpolate on
-            # the fly (bit-identical value and gradient; at cfg5 the 1.26 GB logits and their gradient never exist)
             return ops.upsampled_lovasz_softmax(src[0], target, src[1], self.ignore_index)
         return ops.lovasz_softmax(output, target, self.ignore_index)
