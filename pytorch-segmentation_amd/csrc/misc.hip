@@ -103,7 +103,7 @@ const char* segmi_strerror(int status) {
         default: return "unknown segmi status";
     }
 }
-int segmi_abi_version(void) { return 9; }
+int segmi_abi_version(void) { return 10; }
 
 int segmi_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, segmi_stream_t stream) {
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C || N > 65535) return SEGMI_ERR_BADARG;

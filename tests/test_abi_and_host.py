@@ -46,7 +46,7 @@ def test_library_is_gfx950_only_and_has_no_rocm_runpath():
 def test_status_strings_and_queries():
     from segmi import lib
     from segmi._lib import ConvDesc
-    assert lib.segmi_abi_version() == 9
+    assert lib.segmi_abi_version() == 10
     assert lib.segmi_strerror(0) == b"ok"
     assert b"workspace" in lib.segmi_strerror(-3)
     # bad descriptor -> argument error before any launch (no GPU needed)
