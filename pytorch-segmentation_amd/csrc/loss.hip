@@ -161,10 +161,11 @@ __global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__
     const long rows = (long)N * OH * OW;
     const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
     float lsum = 0.f, lcnt = 0.f;
-    for (long r = (long)blockIdx.x * ppb + (threadIdx.x / LPP); r < rows; r += (long)gridDim.x * ppb) {
-        const int ow = (int)(r % OW);
-        const long tq = r / OW;
-        const int oh = (int)(tq % OH), n = (int)(tq / OH);
+    const long r0 = (long)blockIdx.x * ppb + (threadIdx.x / LPP), stride = (long)gridDim.x * ppb;
+    RowWalk3 rw;
+    rw.init(r0, stride, OH, OW);
+    for (long r = r0; r < rows; r += stride, rw.step()) {
+        const int ow = rw.b, oh = rw.a, n = rw.n;
         const UpPix u = up_pix(lo, ld, n, H, W, bl_src(oh, sh, H, ac), bl_src(ow, sw, W, ac));
         const long t = target[r];
         const bool valid = t != ignore && t >= 0 && t < C;
@@ -245,10 +246,11 @@ __global__ __launch_bounds__(256) void upce_fwd_small_kernel(const float* __rest
     const long rows = (long)N * OH * OW;
     const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
     float lsum = 0.f, lcnt = 0.f;
-    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
-        const int ow = (int)(r % OW);
-        const long tq = r / OW;
-        const int oh = (int)(tq % OH), n = (int)(tq / OH);
+    const long r0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    RowWalk3 rw;
+    rw.init(r0, stride, OH, OW);
+    for (long r = r0; r < rows; r += stride, rw.step()) {
+        const int ow = rw.b, oh = rw.a, n = rw.n;
         const UpPix u = up_pix(lo, ld, n, H, W, bl_src(oh, sh, H, ac), bl_src(ow, sw, W, ac));
         const long t = target[r];
         const bool valid = t != ignore && t >= 0 && t < C;
@@ -305,10 +307,12 @@ __global__ __launch_bounds__(256) void upce_bwd_w_kernel(const float* __restrict
     const long rows = (long)N * OH * W;
     const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
     const float gs0 = grad_out[0] / loss_out[1];
-    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
-        const int wl = (int)(r % W);
-        const long tq = r / W;                    // n * OH + oh
-        const int oh = (int)(tq % OH), n = (int)(tq / OH);
+    const long r0 = (long)blockIdx.y * blockDim.y + threadIdx.y, stride = (long)gridDim.y * blockDim.y;
+    RowWalk3 rw;
+    rw.init(r0, stride, OH, W);
+    for (long r = r0; r < rows; r += stride, rw.step()) {
+        const int wl = rw.b, oh = rw.a, n = rw.n;
+        const long tq = (long)n * OH + oh;
         const Lerp a = bl_src(oh, sh, H, ac);
         int lo_c, hi_c;
         bl_range(wl, sw, W, OW, ac, lo_c, hi_c);
@@ -679,7 +683,7 @@ int segmi_upsample_ce_bwd(const float* logits_lo, int ld, int N, int H, int W, i
     hipStream_t st = (hipStream_t)stream;
     const int ldt = (C + 3) & ~3, ac = align_corners ? 1 : 0;
     float* tmp = (float*)workspace;
-    RowGeom g0 = row_geom((long)N * OH * W, C, 1, SEGMI_MAX_GRID);
+    RowGeom g0 = row_geom_dense((long)N * OH * W, C, 1, SEGMI_MAX_GRID);
     hipLaunchKernelGGL(upce_bwd_w_kernel, g0.grid, g0.block, 0, st, logits_lo, ld, N, H, W, C, OH, OW, ac, target, lse, ignore_index,
                        class_weight, loss_out, grad_out, tmp, ldt);
     return segmi_internal_bilinear_bwd_height(tmp, ldt, dlogits_lo, lddl, N, H, W, C, OH, OW, ac, st);

@@ -164,10 +164,11 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     if (c4 >= c4n) return;
     const float sh = bl_scale(H, OH, ac), sw = bl_scale(W, OW, ac);
     const long rows = (long)N * OH * OW;
-    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
-        const int ow = (int)(r % OW);
-        const long t = r / OW;
-        const int oh = (int)(t % OH), n = (int)(t / OH);
+    const long r0 = (long)blockIdx.y * blockDim.y + threadIdx.y, stride = (long)gridDim.y * blockDim.y;
+    RowWalk3 rw;
+    rw.init(r0, stride, OH, OW);
+    for (long r = r0; r < rows; r += stride, rw.step()) {
+        const int ow = rw.b, oh = rw.a, n = rw.n;
         const Lerp a = bl_src(oh, sh, H, ac), b = bl_src(ow, sw, W, ac);
         const float* base = x + (long)n * H * W * ldx + c4 * 4;
         const float4 v00 = ld4(base + ((long)a.i0 * W + b.i0) * ldx), v01 = ld4(base + ((long)a.i0 * W + b.i1) * ldx);
@@ -194,9 +195,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __r
     if (c4 >= c4n) return;
     const long rows = AXIS == 0 ? (long)N * OH * W : (long)N * H * W;
     const float scale = AXIS == 0 ? bl_scale(W, OW, ac) : bl_scale(H, OH, ac);
-    for (long r = (long)blockIdx.y * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.y * blockDim.y) {
-        const int w = (int)(r % W);
-        const long t = r / W;                     // AXIS 0: n*OH + oh ; AXIS 1: n*H + h
+    const long r0 = (long)blockIdx.y * blockDim.y + threadIdx.y, stride = (long)gridDim.y * blockDim.y;
+    RowWalk3 rw;                                  // r = (n * A + a) * W + w with A = OH (AXIS 0) or H (AXIS 1)
+    rw.init(r0, stride, AXIS == 0 ? OH : H, W);
+    for (long r = r0; r < rows; r += stride, rw.step()) {
+        const int w = rw.b;
+        const long t = (long)rw.n * rw.A + rw.a;  // AXIS 0: n*OH + oh ; AXIS 1: n*H + h
         int lo, hi;
         float4 acc = zero4();
         if (AXIS == 0) {
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __r
                 }
             }
         } else {
-            const int h = (int)(t % H);
-            const long n = t / H;
+            const int h = rw.a;
+            const long n = rw.n;
             bl_range(h, scale, H, OH, ac, lo, hi);
             const float* base = src + (n * OH * W + w) * lds + c4 * 4;
             for (int oh = lo; oh <= hi; ++oh) {
@@ -429,7 +433,7 @@ int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H,
                        int align_corners, segmi_stream_t stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return SEGMI_ERR_BADARG;
     if (!ldok(ldx, C) || !ldok(ldy, C)) return SEGMI_ERR_ALIGN;
-    RowGeom g = row_geom((long)N * OH * OW, C, 2, SEGMI_MAX_GRID * 4);
+    RowGeom g = row_geom_dense((long)N * OH * OW, C, 2, SEGMI_MAX_GRID * 4);
     hipLaunchKernelGGL(bilinear_fwd_kernel, g.grid, g.block, 0, (hipStream_t)stream, x, ldx, y, ldy, N, H, W, C, OH, OW, align_corners ? 1 : 0);
     return segmi_launch_status();
 }
@@ -440,7 +444,7 @@ int segmi_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H,
 // of the C ABI): the fused upsample + cross-entropy backward of loss.hip produces tmp itself.
 int segmi_internal_bilinear_bwd_height(const float* tmp, int ldt, float* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
                                        int ac, hipStream_t st) {
-    RowGeom g1 = row_geom((long)N * H * W, C, 2, SEGMI_MAX_GRID);
+    RowGeom g1 = row_geom_dense((long)N * H * W, C, 2, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), g1.grid, g1.block, 0, st, tmp, ldt, dx, lddx, N, H, W, C, OH, OW, ac);
     return segmi_launch_status();
 }
@@ -461,9 +465,9 @@ int segmi_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, in
     float* tmp = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const int ac = align_corners ? 1 : 0;
-    RowGeom g0 = row_geom((long)N * OH * W, C, 2, SEGMI_MAX_GRID);
+    RowGeom g0 = row_geom_dense((long)N * OH * W, C, 2, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0>), g0.grid, g0.block, 0, st, dy, lddy, tmp, ldt, N, H, W, C, OH, OW, ac);
-    RowGeom g1 = row_geom((long)N * H * W, C, 1, SEGMI_MAX_GRID);
+    RowGeom g1 = row_geom_dense((long)N * H * W, C, 1, SEGMI_MAX_GRID);
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), g1.grid, g1.block, 0, st, (const float*)tmp, ldt, dx, lddx, N, H, W, C, OH, OW, ac);
     return segmi_launch_status();
 }

@@ -49,3 +49,32 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
     unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// A grid-stride loop over rows r = (n * A + a) * B + b needs (n, a, b) in every trip: two 64-bit divisions per trip cost more
+// instructions than the 4 loads + 1 store of a float4 elementwise kernel (bilinear_fwd at 150 classes: 42 trips per thread, measured
+// ALU-bound at 2.8 TB/s).  RowWalk3 divides ONCE (the start row and the stride) and then carries.
+struct RowWalk3 {
+    int b, a, n;          // current coordinates
+    int db, da, dn;       // the stride, decomposed the same way
+    int A, B;
+    __device__ __forceinline__ void init(long r, long stride, int A_, int B_) {
+        A = A_; B = B_;
+        long t = r / B;
+        b = (int)(r - t * B);
+        long nn = t / A;
+        a = (int)(t - nn * A); n = (int)nn;
+        t = stride / B;
+        db = (int)(stride - t * B);
+        nn = t / A;
+        da = (int)(t - nn * A); dn = (int)nn;
+    }
+    __device__ __forceinline__ void step() {
+        b += db;
+        const int c = b >= B ? 1 : 0;
+        b -= c ? B : 0;
+        a += da + c;
+        const int c2 = a >= A ? 1 : 0;
+        a -= c2 ? A : 0;
+        n += dn + c2;
+    }
+};
