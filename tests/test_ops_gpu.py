@@ -308,7 +308,8 @@ def test_adaptive_avg_pool(cuda, case):
 @pytest.mark.parametrize("case", [(2, 16, 1, 1, 16, 16, True), (2, 16, 2, 2, 16, 16, True), (2, 16, 3, 3, 16, 16, True),
                                   (2, 16, 6, 6, 16, 16, True), (2, 21, 8, 8, 64, 64, False), (2, 19, 13, 13, 97, 97, False),
                                   (2, 8, 9, 9, 33, 33, True), (1, 12, 33, 33, 129, 129, True), (2, 4, 10, 12, 7, 5, False),
-                                  (2, 4, 10, 12, 7, 5, True)])
+                                  (2, 4, 10, 12, 7, 5, True),
+                                  (2, 150, 64, 64, 256, 256, True), (3, 21, 40, 48, 320, 384, False)])     # grid-capped launches: every thread walks several rows (RowWalk3 carries), 38 / 6 float4 groups per row (row_geom_dense)
 def test_bilinear(cuda, case):
     from segmi import ops
     N, C, H, W, OH, OW, ac = case
