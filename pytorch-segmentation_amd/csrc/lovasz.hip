@@ -915,6 +915,15 @@ bool lovasz_prune() {
     return g_lovasz_prune == 1;
 }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// which of count (1) / emit (2) / backward (4) hold the pixel's row in registers, all loads issued up front (SEGMI_LOVASZ_ROWREGS).
+// Re-measured in round 6 with the exp gone from the keep test (profiles/r06_lovasz_fused_upsample.txt, loss forward / backward at the
+// cfg5 shard): count 1.566 -> 1.521 ms forward (86 VGPRs) — on by default; emit 1.566 -> 1.781 (208 VGPRs, the unrolled ballot groups);
+// backward 2.675 -> 2.900 (135 VGPRs: the unrolled exp chains) — both stay on the re-reading form.
+int lovasz_rowregs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SEGMI_LOVASZ_ROWREGS"); v = e ? atoi(e) : 1; }
+    return v;
+}
 
 bool lovasz_layout(long rows, int C, LovaszLayout* L) {
     if (rows <= 0 || C <= 0 || C > 1820 || rows >= (1L << 24)) return false;   // fp32-exact cumsums like the reference
@@ -1000,12 +1009,13 @@ int lovasz_fwd_impl(const LovSrc lsrc, bool up, const int64_t* target, long rows
                                            ignore_index, L.PB, (const float*)xthr, L.nunits, (const unsigned*)cnt, ka)
 #define LOV_EMIT(K) do { if (up) LOV_EMIT_(K, true); else LOV_EMIT_(K, false); } while (0)
     // measured at C = 150 (profiles/r05_lovasz_alone_kernel_stats*.csv): prepare<5> 267 us against 384 us for the re-reading form;
-    // count<5> 255 against 258 (no gain); emit<5> 667 against 410 (the unrolled ballot groups need 212 VGPRs: 2 waves per SIMD) —
-    // the selection passes stay on the re-reading form
+    // count<5> 255 against 258 (no gain in round 5; -45 us in round 6 without the exp: lovasz_rowregs); emit<5> 667 against 410 (the
+    // unrolled ballot groups need 212 VGPRs: 2 waves per SIMD) — emit stays on the re-reading form
+    const int rowregs = lovasz_rowregs();
     LOV_DISPATCH(kq, LOV_PREPARE)
-    LOV_COUNT(0);
+    if (rowregs & 1) { LOV_DISPATCH(kq, LOV_COUNT) } else LOV_COUNT(0);
     hipLaunchKernelGGL(lovasz_keep_scan_kernel, dim3((unsigned)C), dim3(KS_T), 0, st, cnt, L.nunits, nkept);
-    LOV_EMIT(0);
+    if (rowregs & 2) { LOV_DISPATCH(kq, LOV_EMIT) } else LOV_EMIT(0);
 #undef LOV_PREPARE
 #undef LOV_COUNT
 #undef LOV_EMIT
@@ -1121,7 +1131,7 @@ int segmi_lovasz_bwd(const float* logits, int ld, const int64_t* target, long ig
                                       lse, G, ldg, rows, C, loss_out, grad_out, dlogits, lddl)
     // the re-reading form: with the row (and its probabilities) held in registers the kernel needs 131 VGPRs at C = 150 and ran
     // 1018 us against 794 us (profiles/r05_lovasz_alone_kernel_stats_rowregs{1,0}.csv)
-    LOV_BWD(0);
+    if (lovasz_rowregs() & 4) { LOV_DISPATCH(lov_kq(C), LOV_BWD) } else LOV_BWD(0);
 #undef LOV_BWD
     return segmi_launch_status();
 }
