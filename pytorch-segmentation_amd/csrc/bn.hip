@@ -58,20 +58,35 @@ struct FinalizeArgs {               // per-channel epilogue of the statistics (b
     float* running_mean; float* running_var; int64_t* num_batches_tracked;
     float* mean; float* invstd; float* scale; float* shift;
 };
-__device__ __forceinline__ void finalize_channel(const FinalizeArgs& f, int c, float n, float m, float q) {
+// the per-channel operands of the finalisation that do not depend on the statistics: requested at the START of a merge kernel, so
+// their HBM round trip overlaps the partials' instead of following the merge (these kernels are 4-7 us of pure latency, 61-141 of
+// them per step)
+struct FinalizeOperands { float g, b, rm, rv; };
+__device__ __forceinline__ FinalizeOperands finalize_operands(const FinalizeArgs& f, int c) {
+    FinalizeOperands o;
+    o.g = f.gamma ? f.gamma[c] : 1.f; o.b = f.beta ? f.beta[c] : 0.f;
+    o.rm = f.running_mean ? f.running_mean[c] : 0.f; o.rv = f.running_mean ? f.running_var[c] : 0.f;
+    return o;
+}
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& f, int c, float n, float m, float q, const FinalizeOperands& o) {
+    // no contraction in here: the fused and the two-call paths inline this function into different kernels and must round alike
+    // (HIP's __fmul_rn / __fadd_rn are plain operators, which the compiler contracts as it sees fit; the one fma below is explicit)
+#pragma clang fp contract(off)
     const float var = q / n;  // biased
     const float is = f.clamp_mode ? 1.f / sqrtf(fmaxf(var, f.eps)) : 1.f / sqrtf(var + f.eps);
     f.mean[c] = m;
     f.invstd[c] = is;
-    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-    const float sc = g * is;
+    const float sc = o.g * is;
     f.scale[c] = sc;
-    f.shift[c] = b - m * sc;
+    f.shift[c] = __builtin_fmaf(-m, sc, o.b);
     if (f.running_mean) {
         const float unbiased = q / fmaxf(n - 1.f, 1.f);
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+        f.running_mean[c] = (1.f - f.momentum) * o.rm + f.momentum * m;          // aten's CPU update: no fma
+        f.running_var[c] = (1.f - f.momentum) * o.rv + f.momentum * unbiased;
     }
+}
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& f, int c, float n, float m, float q) {
+    finalize_channel(f, c, n, m, q, finalize_operands(f, c));
 }
 
 // merge nparts packed partials (stride 3*Cp each) into out[3*Cp].  Block = (16 channels, 16 part lanes):
@@ -90,6 +105,8 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
         nparts = min(slice, nparts - (int)blockIdx.y * slice);
         out += (long)blockIdx.y * 3 * Cp;
     }
+    FinalizeOperands fo = {1.f, 0.f, 0.f, 0.f};
+    if (FINAL && threadIdx.y == 0 && cok) fo = finalize_operands(fin, c);
     float n = 0.f, m = 0.f, q = 0.f;
     if (cok) {
         // four partials per step are loaded unconditionally BEFORE the (serial) Chan merges, so 12 loads are in flight at once
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
     if (threadIdx.y == 0 && cok) {
         if (FINAL) {
             if (c == 0 && fin.num_batches_tracked) *fin.num_batches_tracked += 1;
-            finalize_channel(fin, c, sn[0][threadIdx.x], sm[0][threadIdx.x], sq[0][threadIdx.x]);
+            finalize_channel(fin, c, sn[0][threadIdx.x], sm[0][threadIdx.x], sq[0][threadIdx.x], fo);
         } else {
             out[c] = sn[0][threadIdx.x]; out[Cp + c] = sm[0][threadIdx.x]; out[2 * Cp + c] = sq[0][threadIdx.x];
         }

@@ -60,6 +60,7 @@ struct GatherParams {
     // folds (csrc/bn.hip) — so the statistics pass of the BN layer never reads the tensor again
     float* stats;
     int stats_cp;
+    int dbg;    // ablation hook (SEGMI_CONV_DBG, tools/experiments): 1 no epilogue stores, 2 no operand traffic after the first chunk, 4 no epilogue, 8 every chunk re-reads the first one (cache-hot operands)
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -266,10 +267,20 @@ __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voffset, unsig
                  :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
+// the same with a scalar byte offset on top of the lane's (soffset field of the instruction)
+__device__ __forceinline__ void dma16s(const i32x4& rsrc, unsigned voffset, unsigned soffset, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voffset), "s"(rsrc), "s"(soffset), "s"(lds_dst) : "memory");
+}
+
 // FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
 // keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
 // an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
+// PW (FAST, one tap, no parity classes, Cs % 32 == 0 — the 1x1 layers and the batched Winograd contractions): a lane's offsets do
+// not change from chunk to chunk, the chunk's channel offset rides in the instruction's scalar offset, and a piece of the K loop is
+// the DMA instruction alone.  Measured with the address arithmetic in place but no DMA (tools/experiments/r06t.sh,
+// profiles/r06_conv_loop_ablation.txt): the ~6 VALU instructions per piece, not the loads, were what the matrix pipe waited for.
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, bool PW = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -352,6 +363,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     for (int i = 0; i < B_IT; ++i) {
         const int k = n0 + i * 32 + rl;
         b_off[i] = k < p.Cd ? (unsigned)k * (unsigned)((subm ? p.wRS : RS) * p.Cs) : OOB;
+    }
+
+    static_assert(!PW || FAST, "the pointwise form is a special case of the tap-mask form");
+    unsigned pw_a[A_IT], pw_b[B_IT];                     // PW: byte offsets of the lane's 16 bytes in chunk 0 (OOB: row past M / Cd)
+    if (PW) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) pw_a[i] = (a_mask[i] & 1u) ? (unsigned)(a_base[i] + kg * 4) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) pw_b[i] = b_off[i] != OOB ? (b_off[i] + (unsigned)(kg * 4)) * 4u : OOB;
     }
 
     auto issue = [&](int r, int s, int c0, int buf) {
@@ -463,33 +483,110 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
             for (int e = 0; e < 16; ++e) total[i][j][e] = 0.f;
     // (groups of FLUSH chunks: the inner loop is the plain pipelined K loop, untouched by the flush logic — a flush test inside it
     //  cost the ds_read / MFMA interleave 4 extra s_waitcnt per chunk and 3.7 % of the kernel)
-    for (int it = it0; it < T;) {
-    const int gend = min(T, it + FLUSH);
-    for (; it < gend; ++it) {
-        if (it + 1 < T) { advance(); issue(r, s, c0, buf ^ 1); }
-        const float* Ab = smem + buf * STAGE;
+    // (round 6) operand fragments double-buffered by hand, like the filter-gradient kernel's: the ds_reads of k-step kk+1 are in
+    // flight while the MFMAs of step kk issue (the compiler's own schedule reused the A registers of the wave's first tile row for
+    // the second and waited out the LDS latency behind every 8 MFMAs), and the second half of a chunk's last step is held back
+    // behind the barrier, where it covers the ds_read latency of the next chunk's first fragments.
+    // FAST: the DMA of the chunk after the next leaves in NP pieces of one wave-instruction each (~7 VALU + the load), one piece
+    // behind every second MFMA of the chunk's first steps — in the 64-cycle shadow of a matrix instruction instead of ~300 cycles in
+    // which the wave issues none.  A tile's last chunk issues the pieces with out-of-range offsets (zero fill, no memory traffic)
+    // so that the chunk body stays one basic block.
+    constexpr int NP = A_IT + B_IT;
+    float4 fa[2][TM], fb[2][TN];
+    auto fetch = [&](int stage_buf, int kk, int sb) {
+        const float* Ab = smem + stage_buf * STAGE;
         const float* Bb = Ab + BM * BK;
+        const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
-            float4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) fa[sb][i] = ld4(Ab + (wm0 + i * 32 + lrow32) * BK + slot);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ld4(Ab + (wm0 + i * 32 + lrow32) * BK + slot);
+        for (int j = 0; j < TN; ++j) fb[sb][j] = ld4(Bb + (wn0 + j * 32 + lrow32) * BK + slot);
+    };
+    int q_tap = 0, q_tapoff = 0, q_c0 = 0;
+    unsigned q_wtap = 0;
+    bool q_have = false;
+    auto prep = [&](bool have) {                             // chunk-level scalars of the pieces (after advance())
+        q_have = have && !(p.dbg & 2); q_c0 = (p.dbg & 8) ? 0 : c0; q_tap = r * p.S + s;
+        if (subm) { q_tapoff = (p.tab_r[q_tap] * p.Ws + p.tab_s[q_tap]) * p.lds; q_wtap = (unsigned)(p.tab_w[q_tap] * p.Cs); }
+        else      { q_tapoff = (MODE == MODE_FPROP ? 1 : -1) * (r * p.dil * p.Ws + s * p.dil) * p.lds; q_wtap = (unsigned)(q_tap * p.Cs); }
+    };
+    auto piece = [&](int idx, int dstbuf) {
+        const unsigned As = lds0 + (unsigned)dstbuf * (STAGE * 4), Bs = As + BM * BK * 4;
+        if (PW) {
+            if (q_have) {                                      // (scalar branch around one instruction; no chunk behind a tile's last)
+                const unsigned soff = (unsigned)q_c0 * 4u;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = ld4(Bb + (wn0 + j * 32 + lrow32) * BK + slot);
+                for (int i = 0; i < A_IT; ++i) if (i == idx) dma16s(src_rsrc, pw_a[i], soff, As + i * (32 * BK * 4));
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) if (A_IT + i == idx) dma16s(wgt_rsrc, pw_b[i], soff, Bs + i * (32 * BK * 4));
+            }
+            return;
+        }
+        const int c = q_c0 + kg * 4;
+        const unsigned live = ((unsigned)q_have & (unsigned)(c < p.Cs)) & 1u;      // (bitwise on purpose: `&&` became exec-masked branches)
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (i == idx) {
+                const unsigned ok = (a_mask[i] >> q_tap) & live;
+                dma16(src_rsrc, ok ? (unsigned)(a_base[i] + q_tapoff + c) * 4u : OOB, As + i * (32 * BK * 4));
+            }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (A_IT + i == idx) {
+                const unsigned ok = live & (unsigned)(b_off[i] != OOB);
+                dma16(wgt_rsrc, ok ? (b_off[i] + q_wtap + (unsigned)c) * 4u : OOB, Bs + i * (32 * BK * 4));
+            }
+    };
+    auto mfmas = [&](int sb, int q0, int q1, int& pc, int dstbuf) {   // reduction elements q0 .. q1-1 of fragment buffer sb
+        int cnt = 0;
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    const float av = q == 0 ? fa[sb][i].x : q == 1 ? fa[sb][i].y : q == 2 ? fa[sb][i].z : fa[sb][i].w;
+                    const float bv = q == 0 ? fb[sb][j].x : q == 1 ? fb[sb][j].y : q == 2 ? fb[sb][j].z : fb[sb][j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    if (FAST && (++cnt & 1) == 0 && pc < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(pc++, dstbuf);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-        }
+    };
+    fetch(buf, 0, 0);
+    for (int it = it0; it < T;) {
+    const int gend = min(T, it + FLUSH);
+    for (; it < gend; ++it) {
+        static_assert(BK / 8 == 4, "four k-steps per chunk");
+        const bool have = it + 1 < T;
+        if (have) advance();
+        if (FAST) prep(have);
+        else if (have) issue(r, s, c0, buf ^ 1);
+        int pc = 0;
+        fetch(buf, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 0, 4, pc, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 0, 4, pc, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 0, 4, pc, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 0, 2, pc, buf ^ 1);
+        static_assert(!FAST || NP <= 7 * TM * TN, "every piece has a slot before the barrier");
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
         __syncthreads();                                     // ... for every wave, and this stage is free again
         buf ^= 1;
+        fetch(buf, 0, 0);                                    // (after the tile's last chunk: a dead read of the other stage)
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 2, 4, pc, buf);                             // (pc == NP here: no piece behind the barrier)
+        __builtin_amdgcn_sched_barrier(0);
     }
         if (it < T) {
 #pragma unroll
@@ -509,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     }
 
     // ---- epilogue (same C/D mapping as the register-staged kernel)
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) dst_base[0] = 0.f; return; }
     const int cd4 = min((p.Cd + 3) & ~3, p.ldd);
     if (p.ksplit > 1) {                                  // partial tile -> workspace slice of this split (no bias / accumulate)
         float* out = p.ws + (long)bidy * p.M * p.ldd;
@@ -585,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (kok && roff[q] >= 0) st4(dst_base + roff[q] + k, v[q]);
+            if (kok && roff[q] >= 0 && !(p.dbg & 1)) st4(dst_base + roff[q] + k, v[q]);
         if (MODE == MODE_FPROP && p.stats) {
             // BN statistics of the tile while its values are in registers: a lane holds NQ rows x 4 channels — exact two-pass
             // {count, mean, M2} per lane, Chan merge across the 8 lanes that share the channel group (lane bits 3..5), then the
@@ -1012,6 +1110,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
     for (; i < n4; i += step) {
         float4 a = w[i];
         int s = 1;
+        // (round 6) eight slices per step first: the 14- and 16-way splits of the Xception / bottleneck filter gradients took four
+        // dependent round trips of four loads; the summation order (slice order) is unchanged
+        for (; s + 7 < nsplit; s += 8) {
+            float4 b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b[u] = w[i + (long)(s + u) * stride4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+        }
         for (; s + 3 < nsplit; s += 4) {
             const float4 b0 = w[i + (long)s * stride4], b1 = w[i + (long)(s + 1) * stride4];
             const float4 b2 = w[i + (long)(s + 2) * stride4], b3 = w[i + (long)(s + 3) * stride4];
@@ -1137,18 +1244,32 @@ int conv_bk() {
     return g_bk;
 }
 
+// the K loop's pointwise form (conv_dma_kernel<..., PW>)
+static bool dma_pointwise(bool fast, int RS, int Cs, int sub) { return fast && RS == 1 && !sub && (Cs & 31) == 0; }
+
 template <int BM, int BN, int WM, int WN, int MODE>
 int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SEGMI_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     p.tiles_m = segmi_cdiv(p.M, BM);
     p.tiles_n = segmi_cdiv(p.Cd, BN);
-    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    if (p.dbg & 16) {                                          // ablation: one workgroup per CU (LDS request of 100 KB)
+        lds = 100 * 1024;
+        static bool once = false;
+        if (!once) { once = true;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+    }
     p.pack4 = (MODE == MODE_FPROP && p.Cs == 4 && p.R * p.S > 1 && p.ksplit <= 1) ? 1 : 0;
     const bool fast = !p.pack4 && p.R * p.S <= 32 && (MODE == MODE_FPROP || p.stride == 1);
     const int Tall = p.pack4 ? segmi_cdiv(p.R * p.S * 4, 32) : segmi_cdiv(p.Cs, 32) * p.R * p.S;
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)(p.batch > 1 ? p.batch : p.ksplit));
-    if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    else      hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    const bool pw = dma_pointwise(fast, p.R * p.S, p.Cs, p.sub);
+    if (pw)        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    else if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    else           hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
     if (p.ksplit > 1) {
         const long n4 = (long)p.M * p.ldd / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -1502,7 +1623,8 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false");
+        const bool pw = dma_pointwise(fast, d->R * d->S, Cs, op == 1 && d->stride > 1);
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s%s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false", pw ? ", true" : "");
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
@@ -1569,11 +1691,11 @@ int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* 
     return dispatch_gather<MODE_FPROP>(p, st);
 }
 
-int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len) {
+int segmi_internal_gemm_variant(int M, int Cs, int Cd, char* buf, size_t len) {
     if (!buf || len < 64) return SEGMI_ERR_BADARG;
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
     const int bm = dma_half_m(M, Cd, 16) ? 64 : 128;                         // the 16 batched contractions of a Winograd pass
-    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true>", bm, bn, bn == 32 ? "4, 1" : "2, 2");
+    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true%s>", bm, bn, bn == 32 ? "4, 1" : "2, 2", dma_pointwise(true, 1, Cs, 0) ? ", true" : "");
     return SEGMI_OK;
 }
 

@@ -8,7 +8,7 @@
 int segmi_internal_gemm_batched(const float* a, int lda, const float* w, float* d, int ldd, int M, int Cs, int Cd, int batch,
                                 long bs_a, long bs_w, long bs_d, hipStream_t st);
 // Name of the kernel variant segmi_internal_gemm_batched launches for this shape (as a rocprofv3 trace shows it).
-int segmi_internal_gemm_variant(int M, int Cd, char* buf, size_t len);
+int segmi_internal_gemm_variant(int M, int Cs, int Cd, char* buf, size_t len);
 // Whether segmi_internal_gemm_batched can run this shape (LDS-DMA kernels enabled, operands within 32-bit buffer offsets).
 bool segmi_internal_gemm_ok(long M, int lda, int Cs, int Cd);
 

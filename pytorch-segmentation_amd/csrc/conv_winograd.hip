@@ -500,7 +500,7 @@ int segmi_conv2d_winograd_variant(const segmi_conv_desc* d, int op, char* buf, s
     WinoPlan pl;
     if (!buf || len < 96 || (op != 0 && op != 1) || !wino_plan(d, op, &pl)) return SEGMI_ERR_BADARG;
     char gemm[64];
-    if (segmi_internal_gemm_variant((int)pl.g.T, pl.Cout, gemm, sizeof gemm) != SEGMI_OK) return SEGMI_ERR_BADARG;
+    if (segmi_internal_gemm_variant((int)pl.g.T, pl.Cin, pl.Cout, gemm, sizeof gemm) != SEGMI_OK) return SEGMI_ERR_BADARG;
     snprintf(buf, len, "winograd_f2x2_3x3 %s: 16 x %s", op == 0 ? "fwd" : "dgrad", gemm);
     return SEGMI_OK;
 }

@@ -37,11 +37,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("names", nargs="*", default=list(PROBLEMS))
 ap.add_argument("--op", default="all")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--ldpad", type=int, default=0, help="x is a channel slice of a tensor with this many extra channels (pixel stride C + ldpad)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 for name in args.names:
     N, C, H, W, K, R, stride, pad, dil = PROBLEMS[name]
-    x = ops.to_nhwc(torch.randn(N, C, H, W, device=dev)).requires_grad_(True)
+    x = ops.to_nhwc(torch.randn(N, C + args.ldpad, H, W, device=dev))[:, :C].requires_grad_(True)
+    assert ops.ld_of(x) == C + args.ldpad
     w = torch.randn(K, C, R, R, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y_dx = ops.conv2d(x, w.detach(), None, stride, pad, dil)      # backward = dgrad only
     y_dw = ops.conv2d(x.detach(), w, None, stride, pad, dil)      # backward = wgrad only
