@@ -60,7 +60,7 @@ struct GatherParams {
     // folds (csrc/bn.hip) — so the statistics pass of the BN layer never reads the tensor again
     float* stats;
     int stats_cp;
-    int dbg;    // ablation hook (SEGMI_CONV_DBG, tools/experiments): 1 no epilogue stores, 2 no operand traffic after the first chunk, 4 no epilogue, 8 every chunk re-reads the first one (cache-hot operands)
+    int dbg;    // ablation hook (SEGMI_CONV_DBG, tools/experiments): 1 no epilogue stores, 2 no operand traffic after the first chunk, 4 no epilogue, 8 every chunk re-reads the first one (cache-hot operands), 16 one workgroup per CU, 32 no two-level summation
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         mfmas(1, 2, 4, pc, buf);                             // (pc == NP here: no piece behind the barrier)
         __builtin_amdgcn_sched_barrier(0);
     }
-        if (it < T) {
+        if (it < T && !(p.dbg & 32)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -903,7 +903,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // ROWQ (Q % 32 == 0): a 32-pixel chunk never straddles an output row, so (n, p, q0) of the chunk are wave-uniform scalars
 // advanced with SALU, and a lane only adds its fixed in-chunk column: ~20 VALU per chunk instead of ~130 (the m -> (n,p,q)
 // bookkeeping per lane and per load is what kept the generic path's waves off the matrix pipe: 125 vs 136 TF/s of fprop).
-template <int BM, int BN, bool ROWQ>
+// PW (1x1, stride 1, no padding, M % 32 == 0 — the pointwise layers and the batched Winograd filter gradients): pixel m of dy IS pixel
+// m of x, a lane's DMA offsets never change and the chunk's pixel offset is the instruction's scalar offset.
+template <int BM, int BN, bool ROWQ, bool PW = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int BKP = 32, WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -983,49 +985,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         for (int i = 0; i < B_IT; ++i) b_ws[i] = ((i * 4 + wave) * B_RPI + b_rl) * p.stride + tap_w;
     }
 
-    auto issue = [&](int mb, int buf) {
-        const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BKP * BM * 4;
+    // One DMA wave-instruction of a stage (idx < A_IT: dy rows, else x rows).  PW: the lane's offset never changes and the chunk's
+    // pixel offset rides in the instruction's scalar offset (no VALU at all); ROWQ: chunk-uniform scalars + a few VALU per x load;
+    // generic: per-lane (n, p, q) bookkeeping.  The chunk-level scalars of ROWQ / PW are set by prep() before the first piece.
+    unsigned pw_b[B_IT];
+    if (PW) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            a_const[i] = a_cok ? ((unsigned)(((i * 4 + wave) * A_RPI + a_rl) * p.ldy + k0 + a_col)) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            pw_b[i] = b_cok ? ((unsigned)(((i * 4 + wave) * B_RPI + b_rl) * p.ldx + b_ch)) * 4u : OOB;
+    }
+    unsigned q_achunk = 0, q_bchunk = 0;
+    int q_rowbase = 0, q_wq = 0, q_mb = 0;
+    bool q_hok = false;
+    auto prep = [&](int mb) {
+        q_mb = mb;
+        if (PW) { q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u; q_bchunk = (unsigned)mb * (unsigned)p.ldx * 4u; return; }
         if (ROWQ) {
-            const unsigned a_chunk = (unsigned)mb * (unsigned)p.ldy * 4u;                       // scalar
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i)
-                dma16(dy_rsrc, a_const[i] == OOB ? OOB : a_chunk + a_const[i], As + (i * 4 + wave) * A_RPI * (BM * 4));
+            q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u;                                     // scalar
             const int hs = cp * p.stride + tap_h;                                               // scalar
-            const bool hok = (unsigned)hs < (unsigned)p.H;
-            const int rowbase = ((cn * p.H + hs) * p.W) * p.ldx + b_ch;
-            const int wq = cq * p.stride;
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int ws = wq + b_ws[i];
-                const bool ok = hok && b_cok && (unsigned)ws < (unsigned)p.W;
-                dma16(x_rsrc, ok ? (unsigned)(rowbase + ws * p.ldx) * 4u : OOB, Bs + (i * 4 + wave) * B_RPI * (BN * 4));
-            }
+            q_hok = (unsigned)hs < (unsigned)p.H;
+            q_rowbase = ((cn * p.H + hs) * p.W) * p.ldx + b_ch;
+            q_wq = cq * p.stride;
             cq += BKP;
             if (cq >= p.Q) { cq = 0; if (++cp == p.P) { cp = 0; ++cn; } }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int row0 = (i * 4 + wave) * A_RPI;
-            const int m = mb + row0 + a_rl;
-            const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)(k0 + a_col)) * 4u;
-            dma16(dy_rsrc, (a_cok && m < mend) ? off : OOB, As + row0 * (BM * 4));
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int row0 = (i * 4 + wave) * B_RPI;
-            const int m = mb + row0 + b_rl;
-            const int hs = b_p[i] * p.stride + tap_h, ws = b_q[i] * p.stride + tap_w;
-            const bool ok = b_cok && m < mend && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
-            const unsigned off = ((unsigned)((b_n[i] * p.H + hs) * p.W + ws) * (unsigned)p.ldx + (unsigned)b_ch) * 4u;
-            dma16(x_rsrc, ok ? off : OOB, Bs + row0 * (BN * 4));
-            b_q[i] += BKP;
-            while (b_q[i] >= p.Q) {
-                b_q[i] -= p.Q;
-                if (++b_p[i] == p.P) { b_p[i] = 0; ++b_n[i]; }
-            }
         }
     };
+    auto piece = [&](int idx, int buf) {
+        const unsigned As = lds0 + (unsigned)buf * (STAGE * 4), Bs = As + BKP * BM * 4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (i == idx) {
+                const unsigned dst = As + (i * 4 + wave) * A_RPI * (BM * 4);
+                if (PW || ROWQ) dma16s(dy_rsrc, a_const[i], q_achunk, dst);
+                else {
+                    const int m = q_mb + (i * 4 + wave) * A_RPI + a_rl;
+                    const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)(k0 + a_col)) * 4u;
+                    dma16(dy_rsrc, (a_cok && m < mend) ? off : OOB, dst);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (A_IT + i == idx) {
+                const unsigned dst = Bs + (i * 4 + wave) * B_RPI * (BN * 4);
+                if (PW) dma16s(x_rsrc, pw_b[i], q_bchunk, dst);
+                else if (ROWQ) {
+                    const int ws = q_wq + b_ws[i];
+                    const unsigned ok = (unsigned)q_hok & (unsigned)b_cok & (unsigned)((unsigned)ws < (unsigned)p.W);
+                    dma16(x_rsrc, ok ? (unsigned)(q_rowbase + ws * p.ldx) * 4u : OOB, dst);
+                } else {
+                    const int m = q_mb + (i * 4 + wave) * B_RPI + b_rl;
+                    const int hs = b_p[i] * p.stride + tap_h, ws = b_q[i] * p.stride + tap_w;
+                    const bool ok = b_cok && m < mend && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+                    const unsigned off = ((unsigned)((b_n[i] * p.H + hs) * p.W + ws) * (unsigned)p.ldx + (unsigned)b_ch) * 4u;
+                    dma16(x_rsrc, ok ? off : OOB, dst);
+                    b_q[i] += BKP;
+                    while (b_q[i] >= p.Q) {
+                        b_q[i] -= p.Q;
+                        if (++b_p[i] == p.P) { b_p[i] = 0; ++b_n[i]; }
+                    }
+                }
+            }
+    };
+    constexpr int NP = A_IT + B_IT;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1036,40 +1060,79 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (mbeg < mend) {
-        issue(mbeg, 0);
+        prep(mbeg);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) piece(q, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
+        // (round 6) Operand reads are ds_read_b32 with IMMEDIATE offsets, issued from inline asm and counted by hand: the compiler
+        // merged a k-step's two A (B) reads into ds_read2_b32, whose 8-bit offsets cannot reach past the first k-steps, and paid two
+        // v_add per k-step for it — VALU instructions between the MFMAs are what the matrix pipe waits for (profiles/
+        // r06_conv_loop_ablation.txt), LDS instructions are not.  Four fragment slots: k-step kk+2 is in flight while kk issues;
+        // the last two k-steps of a chunk are held back behind the barrier, where they cover the first reads of the next stage;
+        // the DMA of the chunk after the next leaves in NP pieces behind the first k-steps (no VALU in the PW form).
+        constexpr int KS = BKP / 2;                                  // k-steps per chunk
+        static_assert(KS % 4 == 0 && NP <= KS - 2, "slot rotation / piece slots");
+        const unsigned a_lane = lds0 + (unsigned)((lhalf * BM + wm0 + lrow32) * 4);
+        const unsigned b_lane = lds0 + (unsigned)(BKP * BM * 4 + (lhalf * BN + wn0 + lrow32) * 4);
+        float fa[4][TM], fb[4][TN];
+        auto fetch = [&](unsigned abase, unsigned bbase, int kk, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[slot][i]) : "v"(abase), "n"(kk * 2 * BM * 4 + i * 128));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[slot][j]) : "v"(bbase), "n"(kk * 2 * BN * 4 + j * 128));
+        };
+        auto landed = [&](int slot) {                                 // (after an s_waitcnt: ties the MFMAs to it)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[slot][i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[slot][j]));
+        };
+        auto mfmas = [&](int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+        };
+        fetch(a_lane, b_lane, 0, 0);
+        fetch(a_lane, b_lane, 1, 1);
         for (int mb = mbeg; mb < mend; mb += BKP) {
-            if (mb + BKP < mend) issue(mb + BKP, buf ^ 1);
-            const float* Ab = smem + buf * STAGE;
-            const float* Bb = Ab + BKP * BM;
-            // operand registers are double-buffered by hand: the ds_reads of step kk+2 are in flight while the
-            // MFMAs of step kk issue (without it the wave waits out the LDS latency every 4 MFMAs: 115 vs 130 TF/s)
-            float a[3][TM], b[3][TN];
-            auto fetch = [&](int kk, int slot) {
+            const bool have = mb + BKP < mend;
+            if (have) prep(mb + BKP);
+            const unsigned abase = a_lane + (unsigned)buf * (STAGE * 4), bbase = b_lane + (unsigned)buf * (STAGE * 4);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[slot][i] = Ab[(kk * 2 + lhalf) * BM + wm0 + i * 32 + lrow32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[slot][j] = Bb[(kk * 2 + lhalf) * BN + wn0 + j * 32 + lrow32];
-            };
-            fetch(0, 0);
-            fetch(1, 1);
-#pragma unroll
-            for (int kk = 0; kk < BKP / 2; ++kk) {
-                if (kk + 2 < BKP / 2) fetch(kk + 2, (kk + 2) % 3);
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % 3][i], b[kk % 3][j], acc[i][j], 0, 0, 0);
+            for (int kk = 0; kk < KS - 2; ++kk) {
+                fetch(abase, bbase, kk + 2, (kk + 2) & 3);
+                if ((TM + TN) * 2 == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if ((TM + TN) * 2 == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                landed(kk & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kk & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < NP && have) piece(kk, buf ^ 1);              // (scalar branch; a split's last chunk has nothing to fetch)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of this stage is in registers
+            landed((KS - 2) & 3); landed((KS - 1) & 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next stage has landed
             __syncthreads();
             buf ^= 1;
+            {
+                const unsigned an = a_lane + (unsigned)buf * (STAGE * 4), bn = b_lane + (unsigned)buf * (STAGE * 4);
+                fetch(an, bn, 0, 0);                                     // (after the split's last chunk: dead reads)
+                fetch(an, bn, 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas((KS - 2) & 3);
+            mfmas((KS - 1) & 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the dead reads, before the epilogue reuses the registers)
     }
 
     // epilogue through LDS like the fprop kernel: 16-byte stores of 4 consecutive input channels
@@ -1432,6 +1495,11 @@ bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
     return conv_dma() && *xb && *dyb;
 }
 
+// the filter-gradient kernel's pointwise form (conv_wgrad_dma_kernel<..., PW>)
+static bool wgrad_pointwise(int R, int S, int stride, int pad, int M, int pack4) {
+    return R == 1 && S == 1 && stride == 1 && pad == 0 && (M % WG_BKP) == 0 && !pack4;
+}
+
 int g_wgrad_flat = -1;  // SEGMI_WGRAD_FLAT=0: the round-3 workgroup order (A/B hook)
 int wgrad_flat() {
     if (g_wgrad_flat < 0) {
@@ -1450,8 +1518,13 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     if (p.batch > 1 && !wgrad_dma(p, &xb, &dyb)) return SEGMI_ERR_BADARG;     // batch exists in the LDS-DMA kernel only
     if (wgrad_dma(p, &xb, &dyb)) {
         // ROWQ needs whole 32-pixel chunks inside one output row and splits that start on a chunk boundary (they do)
-        if (p.Q % WG_BKP == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
-        else                   hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
+        const bool rowq = p.Q % WG_BKP == 0;
+        if (wgrad_pointwise(p.R, p.S, p.stride, p.pad, p.M, p.pack4)) {
+            if (rowq) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true, true>), grid, dim3(256), lds, st, p, xb, dyb);
+            else      hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, p, xb, dyb);
+        }
+        else if (rowq) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
+        else           hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
     }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();

@@ -173,7 +173,7 @@ def test_conv_kernels_are_compiled_without_scratch(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
         kern[name]["agpr_count"] = int(blk.split()[0])
     dma = {n: v for n, v in kern.items() if "dma_kernel" in n}
-    assert len(dma) == 38, sorted(dma)          # 5 tile shapes x {fprop, dgrad} x {pointwise, fast, generic} + 4 tiles x {ROWQ, generic} wgrad
+    assert len(dma) == 46, sorted(dma)          # 5 tile shapes x {fprop, dgrad} x {pointwise, fast, generic} + 4 tiles x {ROWQ, generic} x {pointwise, taps} wgrad
     for n, v in dma.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
         # .vgpr_count is the unified total (arch VGPRs up to the accumulator offset + AGPRs); 2 x 256 = one SIMD's file
