@@ -276,7 +276,7 @@ __device__ __forceinline__ void dma16s(const i32x4& rsrc, unsigned voffset, unsi
 // FAST (R*S <= 32 taps, fprop or unit-stride dgrad): the source pixel of tap (r,s) is affine in the tap, so each DMA row
 // keeps ONE base offset plus a 32-bit tap-validity mask computed once per workgroup; the per-chunk address work drops to
 // an add, a bit test and a select per load (the issue phase is what keeps a wave off the matrix pipe: 124 -> ~60 VALU per chunk).
-// PW (FAST, one tap, no parity classes, Cs % 32 == 0 — the 1x1 layers and the batched Winograd contractions): a lane's offsets do
+// PW (FAST, one tap, no parity classes — the 1x1 layers and the batched Winograd contractions): a lane's offsets do
 // not change from chunk to chunk, the chunk's channel offset rides in the instruction's scalar offset, and a piece of the K loop is
 // the DMA instruction alone.  Measured with the address arithmetic in place but no DMA (tools/experiments/r06t.sh,
 // profiles/r06_conv_loop_ablation.txt): the ~6 VALU instructions per piece, not the loads, were what the matrix pipe waited for.
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
 
     static_assert(!PW || FAST, "the pointwise form is a special case of the tap-mask form");
     unsigned pw_a[A_IT], pw_b[B_IT];                     // PW: byte offsets of the lane's 16 bytes in chunk 0 (OOB: row past M / Cd)
+    const bool pw_tail_ok = kg * 4 < (p.Cs & 31);        // PW, Cs % 32 != 0: does the lane's channel group exist in the last, partial chunk
     if (PW) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) pw_a[i] = (a_mask[i] & 1u) ? (unsigned)(a_base[i] + kg * 4) * 4u : OOB;
@@ -504,9 +505,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     };
     int q_tap = 0, q_tapoff = 0, q_c0 = 0;
     unsigned q_wtap = 0;
-    bool q_have = false;
+    bool q_have = false, q_tail = false;
     auto prep = [&](bool have) {                             // chunk-level scalars of the pieces (after advance())
         q_have = have && !(p.dbg & 2); q_c0 = (p.dbg & 8) ? 0 : c0; q_tap = r * p.S + s;
+        q_tail = c0 + BK > p.Cs;
         if (subm) { q_tapoff = (p.tab_r[q_tap] * p.Ws + p.tab_s[q_tap]) * p.lds; q_wtap = (unsigned)(p.tab_w[q_tap] * p.Cs); }
         else      { q_tapoff = (MODE == MODE_FPROP ? 1 : -1) * (r * p.dil * p.Ws + s * p.dil) * p.lds; q_wtap = (unsigned)(q_tap * p.Cs); }
     };
@@ -515,10 +517,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         if (PW) {
             if (q_have) {                                      // (scalar branch around one instruction; no chunk behind a tile's last)
                 const unsigned soff = (unsigned)q_c0 * 4u;
+                if (!q_tail) {
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) if (i == idx) dma16s(src_rsrc, pw_a[i], soff, As + i * (32 * BK * 4));
+                    for (int i = 0; i < A_IT; ++i) if (i == idx) dma16s(src_rsrc, pw_a[i], soff, As + i * (32 * BK * 4));
 #pragma unroll
-                for (int i = 0; i < B_IT; ++i) if (A_IT + i == idx) dma16s(wgt_rsrc, pw_b[i], soff, Bs + i * (32 * BK * 4));
+                    for (int i = 0; i < B_IT; ++i) if (A_IT + i == idx) dma16s(wgt_rsrc, pw_b[i], soff, Bs + i * (32 * BK * 4));
+                } else {                                       // the partial chunk of a channel count that is no multiple of 32
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) if (i == idx) dma16s(src_rsrc, pw_tail_ok ? pw_a[i] : OOB, soff, As + i * (32 * BK * 4));
+#pragma unroll
+                    for (int i = 0; i < B_IT; ++i) if (A_IT + i == idx) dma16s(wgt_rsrc, pw_tail_ok ? pw_b[i] : OOB, soff, Bs + i * (32 * BK * 4));
+                }
             }
             return;
         }
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // ROWQ (Q % 32 == 0): a 32-pixel chunk never straddles an output row, so (n, p, q0) of the chunk are wave-uniform scalars
 // advanced with SALU, and a lane only adds its fixed in-chunk column: ~20 VALU per chunk instead of ~130 (the m -> (n,p,q)
 // bookkeeping per lane and per load is what kept the generic path's waves off the matrix pipe: 125 vs 136 TF/s of fprop).
-// PW (1x1, stride 1, no padding, M % 32 == 0 — the pointwise layers and the batched Winograd filter gradients): pixel m of dy IS pixel
+// PW (1x1, stride 1, no padding — the pointwise layers and the batched Winograd filter gradients): pixel m of dy IS pixel
 // m of x, a lane's DMA offsets never change and the chunk's pixel offset is the instruction's scalar offset.
 template <int BM, int BN, bool ROWQ, bool PW = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
@@ -999,9 +1008,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     }
     unsigned q_achunk = 0, q_bchunk = 0;
     int q_rowbase = 0, q_wq = 0, q_mb = 0;
-    bool q_hok = false;
+    bool q_hok = false, q_tail = false;
     auto prep = [&](int mb) {
         q_mb = mb;
+        q_tail = mb + BKP > mend;                                // (PW: the one chunk with rows past the last pixel)
         if (PW) { q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u; q_bchunk = (unsigned)mb * (unsigned)p.ldx * 4u; return; }
         if (ROWQ) {
             q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u;                                     // scalar
@@ -1019,7 +1029,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         for (int i = 0; i < A_IT; ++i)
             if (i == idx) {
                 const unsigned dst = As + (i * 4 + wave) * A_RPI * (BM * 4);
-                if (PW || ROWQ) dma16s(dy_rsrc, a_const[i], q_achunk, dst);
+                if (PW && q_tail) dma16s(dy_rsrc, q_mb + (i * 4 + wave) * A_RPI + a_rl < mend ? a_const[i] : OOB, q_achunk, dst);
+                else if (PW || ROWQ) dma16s(dy_rsrc, a_const[i], q_achunk, dst);
                 else {
                     const int m = q_mb + (i * 4 + wave) * A_RPI + a_rl;
                     const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)(k0 + a_col)) * 4u;
@@ -1030,7 +1041,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         for (int i = 0; i < B_IT; ++i)
             if (A_IT + i == idx) {
                 const unsigned dst = Bs + (i * 4 + wave) * B_RPI * (BN * 4);
-                if (PW) dma16s(x_rsrc, pw_b[i], q_bchunk, dst);
+                if (PW && q_tail) dma16s(x_rsrc, q_mb + (i * 4 + wave) * B_RPI + b_rl < mend ? pw_b[i] : OOB, q_bchunk, dst);
+                else if (PW) dma16s(x_rsrc, pw_b[i], q_bchunk, dst);
                 else if (ROWQ) {
                     const int ws = q_wq + b_ws[i];
                     const unsigned ok = (unsigned)q_hok & (unsigned)b_cok & (unsigned)((unsigned)ws < (unsigned)p.W);
@@ -1308,7 +1320,7 @@ int conv_bk() {
 }
 
 // the K loop's pointwise form (conv_dma_kernel<..., PW>)
-static bool dma_pointwise(bool fast, int RS, int Cs, int sub) { return fast && RS == 1 && !sub && (Cs & 31) == 0; }
+static bool dma_pointwise(bool fast, int RS, int Cs, int sub) { (void)Cs; return fast && RS == 1 && !sub; }
 
 template <int BM, int BN, int WM, int WN, int MODE>
 int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
@@ -1497,7 +1509,8 @@ bool wgrad_dma(const WgradParams& p, unsigned* xb, unsigned* dyb) {
 
 // the filter-gradient kernel's pointwise form (conv_wgrad_dma_kernel<..., PW>)
 static bool wgrad_pointwise(int R, int S, int stride, int pad, int M, int pack4) {
-    return R == 1 && S == 1 && stride == 1 && pad == 0 && (M % WG_BKP) == 0 && !pack4;
+    (void)M;
+    return R == 1 && S == 1 && stride == 1 && pad == 0 && !pack4;
 }
 
 int g_wgrad_flat = -1;  // SEGMI_WGRAD_FLAT=0: the round-3 workgroup order (A/B hook)
