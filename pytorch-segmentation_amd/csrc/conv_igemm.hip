@@ -17,6 +17,7 @@
 // Operand tiles are staged global -> VGPR -> LDS (register staging so out-of-image taps can be
 // zero-filled), double-buffered, one barrier per K-chunk.  LDS rows are padded by 4 floats so the
 // ds_read_b128 fragment reads are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+#include <type_traits>
 #include "segmi_common.h"
 #include "conv_internal.h"
 #include <cstdio>
@@ -460,7 +461,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     if (it0 < T) issue(r, s, c0, 0);                     // T == 0: a parity class without taps (its pixels are zeros)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int buf = 0;
     const int lrow32 = lane & 31, lhalf = lane >> 5;
     const int swz = (lrow32 >> 1) & 7;                   // read-side swizzle (rows wm0 + i*32 + lrow32: same low bits)
     {
@@ -493,15 +493,36 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     // which the wave issues none.  A tile's last chunk issues the pieces with out-of-range offsets (zero fill, no memory traffic)
     // so that the chunk body stays one basic block.
     constexpr int NP = A_IT + B_IT;
-    float4 fa[2][TM], fb[2][TN];
-    auto fetch = [&](int stage_buf, int kk, int sb) {
-        const float* Ab = smem + stage_buf * STAGE;
-        const float* Bb = Ab + BM * BK;
-        const int slot = ((kk * 2 + lhalf) ^ swz) * 4;
+    // Fragment reads: ds_read_b128 from inline asm with IMMEDIATE offsets (stage, tile row) on one of four lane addresses per
+    // operand (one per k-step: the XOR swizzle is not additive), waits counted by hand — the compiler's own address arithmetic was
+    // 3 VALU per k-step, and VALU between the MFMAs is what the matrix pipe waits for.  The stage is a compile-time argument of
+    // the chunk body (two copies, even / odd chunk).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 fa[2][TM], fb[2][TN];
+    unsigned fa_addr[4], fb_addr[4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[sb][i] = ld4(Ab + (wm0 + i * 32 + lrow32) * BK + slot);
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned slotb = (unsigned)(((kk * 2 + lhalf) ^ swz) * 16);
+        fa_addr[kk] = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)((wm0 + lrow32) * BK * 4) + slotb;
+        fb_addr[kk] = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (unsigned)((BM + wn0 + lrow32) * BK * 4) + slotb;
+    }
+    auto fetch = [&](int stg, int kk, int sb) {              // (stg, kk, sb: constants once the chunk body is inlined)
+        const int SO = stg * STAGE * 4;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[sb][j] = ld4(Bb + (wn0 + j * 32 + lrow32) * BK + slot);
+        for (int i = 0; i < TM; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[sb][i]) : "v"(fa_addr[kk]), "n"(SO + i * 32 * BK * 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[sb][j]) : "v"(fb_addr[kk]), "n"(SO + j * 32 * BK * 4));
+    };
+    auto landed = [&](int sb) {                              // behind an s_waitcnt: all but the newest TM + TN reads are in registers
+        if (TM + TN == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (TM + TN == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[sb][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[sb][j]));
     };
     int q_tap = 0, q_tapoff = 0, q_c0 = 0;
     unsigned q_wtap = 0;
@@ -554,9 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float av = q == 0 ? fa[sb][i].x : q == 1 ? fa[sb][i].y : q == 2 ? fa[sb][i].z : fa[sb][i].w;
-                    const float bv = q == 0 ? fb[sb][j].x : q == 1 ? fb[sb][j].y : q == 2 ? fb[sb][j].z : fb[sb][j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i][q], fb[sb][j][q], acc[i][j], 0, 0, 0);
                     if (FAST && (++cnt & 1) == 0 && pc < NP) {
                         __builtin_amdgcn_sched_barrier(0);
                         piece(pc++, dstbuf);
@@ -564,38 +583,54 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
                     }
                 }
     };
-    fetch(buf, 0, 0);
-    for (int it = it0; it < T;) {
-    const int gend = min(T, it + FLUSH);
-    for (; it < gend; ++it) {
+    int it = it0;
+    auto chunk = [&](const int B) __attribute__((always_inline)) {   // one K chunk out of stage B (a constant at both call sites)
+        const int STG = B, OTH = B ^ 1;
         static_assert(BK / 8 == 4, "four k-steps per chunk");
         const bool have = it + 1 < T;
         if (have) advance();
         if (FAST) prep(have);
-        else if (have) issue(r, s, c0, buf ^ 1);
+        else if (have) issue(r, s, c0, B ^ 1);
         int pc = 0;
-        fetch(buf, 1, 1);
+        fetch(STG, 1, 1);
+        landed(0);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(0, 0, 4, pc, buf ^ 1);
+        mfmas(0, 0, 4, pc, B ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(buf, 2, 0);
+        fetch(STG, 2, 0);
+        landed(1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(1, 0, 4, pc, buf ^ 1);
+        mfmas(1, 0, 4, pc, B ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(buf, 3, 1);
+        fetch(STG, 3, 1);
+        landed(0);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(0, 0, 4, pc, buf ^ 1);
+        mfmas(0, 0, 4, pc, B ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(1, 0, 2, pc, buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the chunk's last fragments: every read of this stage is in registers
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[1][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[1][j]));
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 0, 2, pc, B ^ 1);
         static_assert(!FAST || NP <= 7 * TM * TN, "every piece has a slot before the barrier");
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed in LDS
         __syncthreads();                                     // ... for every wave, and this stage is free again
-        buf ^= 1;
-        fetch(buf, 0, 0);                                    // (after the tile's last chunk: a dead read of the other stage)
+        fetch(OTH, 0, 0);                                    // (after the tile's last chunk: a dead read of the other stage)
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(1, 2, 4, pc, buf);                             // (pc == NP here: no piece behind the barrier)
+        mfmas(1, 2, 4, pc, B);                               // (pc == NP here: no piece behind the barrier)
         __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(0, 0, 0);
+    while (it < T) {
+    const int gend = min(T, it + FLUSH);                     // (FLUSH is even: every group starts on stage 0)
+    while (it < gend) {
+        chunk(0);
+        if (++it >= gend) break;
+        chunk(1);
+        ++it;
     }
         if (it < T && !(p.dbg & 32)) {
 #pragma unroll
@@ -606,6 +641,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
                     for (int e = 0; e < 16; ++e) { total[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.f; }
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the dead read behind the last chunk, before its registers are reused)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1699,7 +1735,8 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
         const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
-        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false", pl.nsplit);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s%s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false",
+                          wgrad_pointwise(d->R, d->S, d->stride, d->pad, 0, pl.pack4) ? ", true" : "", pl.nsplit);
         else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
@@ -1823,7 +1860,7 @@ int segmi_internal_wgrad_batched(const float* x, const float* dy, float* ws, int
 int segmi_internal_wgrad_batched_variant(int M, int C, int K, int batch, char* buf, size_t len) {
     const int nsplit = segmi_internal_wgrad_batched_splits(M, C, K, batch);
     if (!buf || len < 64 || nsplit < 1) return SEGMI_ERR_BADARG;
-    snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, true> splitk=%d", K > 64 ? 128 : 64, C > 64 ? 128 : 64, nsplit);
+    snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, true, true> splitk=%d", K > 64 ? 128 : 64, C > 64 ? 128 : 64, nsplit);
     return SEGMI_OK;
 }
 

@@ -25,7 +25,7 @@ descs = st.builds(_desc, st.integers(1, 16), st.integers(1, 200), st.integers(1,
                   st.sampled_from([1, 2, 4, 6, 12, 18])).filter(lambda d: d is not None)
 
 VARIANT = re.compile(r"^(conv_dma_kernel<(64|128), (32|64|128), (2, 2|4, 1), [01], (true|false|true, true)>"
-                     r"|conv_wgrad_dma_kernel<(64|128), (64|128), (true|false)> splitk=\d+"
+                     r"|conv_wgrad_dma_kernel<(64|128), (64|128), (true|false)(, true)?> splitk=\d+"
                      r"|conv_gather_kernel<128, (32|64|128), (16|32), (2, 2|4, 1), [01]>"
                      r"|conv_wgrad_kernel<(64|128), (64|128), 32, 2, 2> splitk=\d+)$")
 
@@ -128,7 +128,7 @@ def test_winograd_plans_are_consistent(d):
     assert lib.segmi_conv2d_winograd_wgrad_ok(d) == 1
     buf = ctypes.create_string_buffer(128)
     assert lib.segmi_conv2d_winograd_wgrad_variant(d, buf, 128) == 0
-    m = re.match(r"^winograd_f2x2_3x3 wgrad: 16 x conv_wgrad_dma_kernel<(64|128), (64|128), true> splitk=(\d+)$", buf.value.decode())
+    m = re.match(r"^winograd_f2x2_3x3 wgrad: 16 x conv_wgrad_dma_kernel<(64|128), (64|128), true, true> splitk=(\d+)$", buf.value.decode())
     assert m, buf.value
     ns = int(m.group(3))
     assert 1 <= ns <= 512 and ns <= Tp // 32                                   # every split owns at least one 32-row chunk of tiles

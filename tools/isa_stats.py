@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "pytorch-segmentation_amd", "csrc", "conv_igemm.hip")
 ASM = "/tmp/segmi_conv_igemm.s"
-DEFAULT = ["conv_dma_kernel<128, 128, 2, 2, 0, true>", "conv_dma_kernel<128, 128, 2, 2, 1, true>", "conv_wgrad_dma_kernel<128, 128, true>"]
+DEFAULT = ["conv_dma_kernel<128, 128, 2, 2, 0, true, true>", "conv_dma_kernel<128, 128, 2, 2, 1, true, true>", "conv_wgrad_dma_kernel<128, 128, true, true>"]
 
 
 def demangle(n):
