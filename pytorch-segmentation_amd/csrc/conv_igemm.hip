@@ -282,7 +282,7 @@ __device__ __forceinline__ void dma16s(const i32x4& rsrc, unsigned voffset, unsi
 // the DMA instruction alone.  Measured with the address arithmetic in place but no DMA (tools/experiments/r06t.sh,
 // profiles/r06_conv_loop_ablation.txt): the ~6 VALU instructions per piece, not the loads, were what the matrix pipe waited for.
 template <int BM, int BN, int WM, int WN, int MODE, bool FAST, bool PW = false>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsigned src_bytes, unsigned wgt_bytes, unsigned dst_bytes) {
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;      // wave-instructions per wave per tile (8 rows each, 4 waves)
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
                 }
     };
     int it = it0;
+    bool flushed = false;                                    // (reductions of <= FLUSH chunks never flush: their tiles skip the final add)
     auto chunk = [&](const int B) __attribute__((always_inline)) {   // one K chunk out of stage B (a constant at both call sites)
         const int STG = B, OTH = B ^ 1;
         static_assert(BK / 8 == 4, "four k-steps per chunk");
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         ++it;
     }
         if (it < T && !(p.dbg & 32)) {
+            flushed = true;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -642,12 +644,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the dead read behind the last chunk, before its registers are reused)
+    if (flushed) {
+        asm volatile("" ::: "memory");                       // (a real branch: if-converted, the add AND a select per element ran always)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] += total[i][j][e];
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += total[i][j][e];
+    }
     }
 
     // ---- epilogue (same C/D mapping as the register-staged kernel)
@@ -676,19 +681,23 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     constexpr int NQ = TM * 4;                            // 8-row store steps of the wave's TM*32 rows
     float* stage = smem + wave * (TM * 32 * EP);          // TM*32 rows x 32 columns per pass
     const int er = lane >> 3, ec = (lane & 7) * 4;        // store role: row er (+8 per step), channels ec..ec+3
-    // destination row of every store step, once for all column passes (-1: row past M)
-    long roff[NQ];
+    // Byte offset of every store step's 16 bytes in column pass 0, once for all passes (OOB: row past M).  The tile leaves through
+    // buffer stores on a descriptor of the destination (< 4 GiB, checked by the dispatcher): the pass's channel offset is the
+    // instruction's scalar offset, rows past M are out-of-range offsets the hardware drops — no 64-bit address arithmetic and no
+    // exec-masked branch per store (round 6: the epilogue's VALU instructions compete with the partner workgroup's MFMAs for issue).
+    const i32x4 dst_rsrc = make_rsrc(dst_base, dst_bytes);
+    unsigned voff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int m = m0 + wm0 + q * 8 + er;
-        long pix = m;
+        unsigned pix = (unsigned)m;
         if (subm) {                                       // parity-class launch: row -> (n, hc*os + ph, wc*os + pw)
             const int hw = p.Hc * p.Wc;
             const int n = m / hw, rem = m - n * hw;
             const int hc = rem / p.Wc, wc = rem - hc * p.Wc;
-            pix = ((long)n * p.Hd + (hc * p.os + p.ph)) * p.Wd + (wc * p.os + p.pw);
+            pix = (unsigned)((n * p.Hd + (hc * p.os + p.ph)) * p.Wd + (wc * p.os + p.pw));
         }
-        roff[q] = m < p.M ? pix * p.ldd : -1;
+        voff[q] = m < p.M ? (pix * (unsigned)p.ldd + (unsigned)ec) * 4u : OOB;
     }
     // accumulate (dgrad into the gradient the residual branch already wrote): ALL of the tile's previous values are requested
     // here, before the LDS transposition — issued one by one between the stores, as a load-wait-add-store chain per step, the
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         for (int j = 0; j < TN; ++j) {
             const int k = n0 + wn0 + j * 32 + ec;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) prev[j][q] = (k < cd4 && roff[q] >= 0) ? ld4(dst_base + roff[q] + k) : zero4();
+            for (int q = 0; q < NQ; ++q) prev[j][q] = (k < cd4 && voff[q] != OOB) ? ld4(dst_base + (size_t)(voff[q] >> 2) + (k - ec)) : zero4();
         }
     }
 #pragma unroll
@@ -718,17 +727,40 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
         float4 v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[q] = ld4(stage + (q * 8 + er) * EP + ec);   // same wave wrote it: LDS is in order per wave
+        if (p.bias) {                                        // (uniform real branches: BN-fed layers have no bias, forward passes no accumulate)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { v[q].x += bv.x; v[q].y += bv.y; v[q].z += bv.z; v[q].w += bv.w; }
+        }
+        if (p.accumulate) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { v[q].x += prev[j][q].x; v[q].y += prev[j][q].y; v[q].z += prev[j][q].z; v[q].w += prev[j][q].w; }
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            v[q].x += bv.x; v[q].y += bv.y; v[q].z += bv.z; v[q].w += bv.w;
-            if (p.accumulate) { v[q].x += prev[j][q].x; v[q].y += prev[j][q].y; v[q].z += prev[j][q].z; v[q].w += prev[j][q].w; }
             // pin the finished value HERE, in straight-line code: sunk into the predicated store blocks below, every block would
             // wait for its own operand with s_waitcnt vmcnt(0) — which on gfx9 also waits for the PREVIOUS STORE to be acknowledged
             asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
         }
+        if (!(p.dbg & 1)) {
+            const unsigned soff = (unsigned)(n0 + wn0 + j * 32) * 4u;                 // (wave-uniform)
+            const bool ragged = n0 + wn0 + j * 32 + 32 > cd4;                         // (wave-uniform: only the last n-tile of a ragged K)
+            typedef float f32x4s __attribute__((ext_vector_type(4)));
+            if (!ragged) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (kok && roff[q] >= 0 && !(p.dbg & 1)) st4(dst_base + roff[q] + k, v[q]);
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4s d; d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(d), "v"(voff[q]), "s"(dst_rsrc), "s"(soff) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4s d; d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(d), "v"(kok ? voff[q] : OOB), "s"(dst_rsrc), "s"(soff) : "memory");
+                }
+            }
+        }
         if (MODE == MODE_FPROP && p.stats) {
             // BN statistics of the tile while its values are in registers: a lane holds NQ rows x 4 channels — exact two-pass
             // {count, mean, M2} per lane, Chan merge across the 8 lanes that share the channel group (lane bits 3..5), then the
@@ -737,12 +769,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
             float4 sum = zero4();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (roff[q] >= 0) { cnt += 1.f; sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
+                if (voff[q] != OOB) { cnt += 1.f; sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
             const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
             float4 mean = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv), m2 = zero4();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (roff[q] >= 0) {
+                if (voff[q] != OOB) {
                     const float dx = v[q].x - mean.x, dy = v[q].y - mean.y, dz = v[q].z - mean.z, dw = v[q].w - mean.w;
                     m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
                 }
@@ -1359,7 +1391,7 @@ int conv_bk() {
 static bool dma_pointwise(bool fast, int RS, int Cs, int sub) { (void)Cs; return fast && RS == 1 && !sub; }
 
 template <int BM, int BN, int WM, int WN, int MODE>
-int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStream_t st) {
+int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, unsigned dst_bytes, hipStream_t st) {
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SEGMI_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     p.tiles_m = segmi_cdiv(p.M, BM);
     p.tiles_n = segmi_cdiv(p.Cd, BN);
@@ -1378,9 +1410,9 @@ int launch_dma(GatherParams& p, unsigned src_bytes, unsigned wgt_bytes, hipStrea
     if (p.ksplit <= 1) { p.ksplit = 1; p.its_per_split = Tall > 0 ? Tall : 1; }
     const dim3 grid((unsigned)p.tiles_m * p.tiles_n, (unsigned)(p.batch > 1 ? p.batch : p.ksplit));
     const bool pw = dma_pointwise(fast, p.R * p.S, p.Cs, p.sub);
-    if (pw)        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    else if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
-    else           hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes);
+    if (pw)        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes, dst_bytes);
+    else if (fast) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes, dst_bytes);
+    else           hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), lds, st, p, src_bytes, wgt_bytes, dst_bytes);
     if (p.ksplit > 1) {
         const long n4 = (long)p.M * p.ldd / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -1432,11 +1464,12 @@ template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
     const unsigned wb = span32((long)p.Cd * (p.sub ? p.wRS : p.R * p.S) * p.Cs);   // parity-class launches index the whole filter
-    if (conv_dma() && sb && wb) {
+    const unsigned db = span32((long)p.N * p.Hd * p.Wd * p.ldd);                  // the tile leaves through buffer stores
+    if (conv_dma() && sb && wb && db) {
         const bool half_m = dma_half_m(p.M, p.Cd, p.batch);              // (a batched launch has batch x the tiles)
-        if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, st);
-        if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, st);
-        return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, st);
+        if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, db, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, db, st);
+        if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, db, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, db, st);
+        return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, db, st);
     }
     const bool bk32 = conv_bk() == 32 && p.Cs >= 32;
     if (p.Cd > 64) return bk32 ? launch_gather<128, 128, 32, 2, 2, MODE>(p, st) : launch_gather<128, 128, 16, 2, 2, MODE>(p, st);
@@ -1531,7 +1564,8 @@ FwdSplit plan_fwd_split(const segmi_conv_desc* d) {
     return f;
 }
 bool dma_eligible_fwd(const segmi_conv_desc* d) {
-    return conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->K * d->R * d->S * d->C);
+    return conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->K * d->R * d->S * d->C) &&
+           span32((long)d->N * d->P * d->Q * d->ldy);
 }
 
 bool wgrad_dma_desc(const segmi_conv_desc* d) {
@@ -1743,7 +1777,8 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     const int Cs = op == 0 ? d->C : ((d->K + 3) & ~3), Cd = op == 0 ? d->K : d->C;
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
     const long src_elems = op == 0 ? (long)d->N * d->H * d->W * d->ldx : (long)d->N * d->P * d->Q * d->ldy;
-    if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs)) {
+    const long dst_elems = op == 0 ? (long)d->N * d->P * d->Q * d->ldy : (long)d->N * d->H * d->W * d->ldx;
+    if (conv_dma() && span32(src_elems) && span32((long)Cd * d->R * d->S * Cs) && span32(dst_elems)) {
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
         const bool pw = dma_pointwise(fast, d->R * d->S, Cs, op == 1 && d->stride > 1);
@@ -1866,5 +1901,5 @@ int segmi_internal_wgrad_batched_variant(int M, int C, int K, int batch, char* b
 
 bool segmi_internal_gemm_ok(long M, int lda, int Cs, int Cd) {
     return M > 0 && M < (1L << 31) && Cs > 0 && Cd > 0 && !(Cs & 3) && !(lda & 3) && lda >= Cs && conv_dma() && span32(M * lda) &&
-           span32((long)Cd * Cs);
+           span32((long)Cd * Cs) && span32(M * (long)((Cd + 3) & ~3));      // (the product's rows are Cd rounded up to 4 wide)
 }
