@@ -1769,8 +1769,8 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
     if (op == 2) {
         WgradPlan pl = plan_wgrad(d);
         const bool dma = conv_dma() && span32((long)d->N * d->H * d->W * d->ldx) && span32((long)d->N * d->P * d->Q * d->ldy);
-        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s%s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false",
-                          wgrad_pointwise(d->R, d->S, d->stride, d->pad, 0, pl.pack4) ? ", true" : "", pl.nsplit);
+        if (dma) snprintf(buf, len, "conv_wgrad_dma_kernel<%d, %d, %s, %s> splitk=%d", pl.bm, pl.bn, d->Q % WG_BKP == 0 ? "true" : "false",
+                          wgrad_pointwise(d->R, d->S, d->stride, d->pad, 0, pl.pack4) ? "true" : "false", pl.nsplit);
         else snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, 2, 2> splitk=%d", pl.bm, pl.bn, WG_BKP, pl.nsplit);
         return SEGMI_OK;
     }
@@ -1782,7 +1782,7 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
         const bool pw = dma_pointwise(fast, d->R * d->S, Cs, op == 1 && d->stride > 1);
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s%s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false", pw ? ", true" : "");
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false", pw ? "true" : "false");
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;
@@ -1853,7 +1853,7 @@ int segmi_internal_gemm_variant(int M, int Cs, int Cd, char* buf, size_t len) {
     if (!buf || len < 64) return SEGMI_ERR_BADARG;
     const int bn = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
     const int bm = dma_half_m(M, Cd, 16) ? 64 : 128;                         // the 16 batched contractions of a Winograd pass
-    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true%s>", bm, bn, bn == 32 ? "4, 1" : "2, 2", dma_pointwise(true, 1, Cs, 0) ? ", true" : "");
+    snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, 0, true, %s>", bm, bn, bn == 32 ? "4, 1" : "2, 2", dma_pointwise(true, 1, Cs, 0) ? "true" : "false");
     return SEGMI_OK;
 }
 

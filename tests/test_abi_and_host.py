@@ -77,9 +77,9 @@ def test_variant_names_and_the_retired_second_arithmetic():
     from segmi._lib import ConvDesc
     d = ConvDesc(8, 64, 64, 512, 512, 3, 3, 64, 64, 1, 2, 2, 512, 512)
     assert lib.segmi_abi_version() >= 9
-    assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true>"
-    assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true>"
-    assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true>")
+    assert ops.conv_variant(d, 0) == "conv_dma_kernel<128, 128, 2, 2, 0, true, false>"
+    assert ops.conv_variant(d, 1) == "conv_dma_kernel<128, 128, 2, 2, 1, true, false>"
+    assert ops.conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<128, 128, true, false>")
     for gone in ("segmi_conv_set_math", "segmi_conv_get_math", "segmi_filter_presplit", "segmi_conv2d_fwd_presplit"):
         assert not hasattr(lib, gone), gone
     assert not hasattr(ops, "set_conv_math")

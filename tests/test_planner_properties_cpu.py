@@ -24,8 +24,8 @@ descs = st.builds(_desc, st.integers(1, 16), st.integers(1, 200), st.integers(1,
                   st.sampled_from([2, 19, 21, 32, 48, 64, 150, 256, 512, 728]), st.sampled_from([1, 3, 7]), st.sampled_from([1, 2]),
                   st.sampled_from([1, 2, 4, 6, 12, 18])).filter(lambda d: d is not None)
 
-VARIANT = re.compile(r"^(conv_dma_kernel<(64|128), (32|64|128), (2, 2|4, 1), [01], (true|false|true, true)>"
-                     r"|conv_wgrad_dma_kernel<(64|128), (64|128), (true|false)(, true)?> splitk=\d+"
+VARIANT = re.compile(r"^(conv_dma_kernel<(64|128), (32|64|128), (2, 2|4, 1), [01], (true|false), (true|false)>"
+                     r"|conv_wgrad_dma_kernel<(64|128), (64|128), (true|false), (true|false)> splitk=\d+"
                      r"|conv_gather_kernel<128, (32|64|128), (16|32), (2, 2|4, 1), [01]>"
                      r"|conv_wgrad_kernel<(64|128), (64|128), 32, 2, 2> splitk=\d+)$")
 
