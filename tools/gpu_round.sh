@@ -4,7 +4,7 @@
 #   bench     the driver's default bench line (cfg2, every leg)                    benchall  one line per BASELINE config (with cpu_baseline)
 #   prof      rocprofv3 --kernel-trace --stats of cfg2 (side stream on / in order) pmc       FETCH_SIZE / WRITE_SIZE passes -> conv traffic json
 #   layers    per-layer conv table (tools/conv_layers.py)                          membound  HBM-bound call table per config
-#   profcfg   rocprofv3 stats, in order, for cfg1 cfg3 cfg5
+#   profcfg   rocprofv3 stats, in order, for cfg1 cfg3 cfg5                           sqpmc     SQ counters (MfmaUtil ...) of 1x1 layers, base vs this tree
 # (the per-round recipes of rounds 1-5, incl. the retired bf16x3 arithmetic's, are in this file's git history)
 set -u
 cd "$GRAFT_REPO_ROOT"
@@ -53,6 +53,21 @@ pmc)
   find gpurun_out/pmc_f32 -name "*kernel_trace*" -delete; find gpurun_out/pmc_f32 -name "*.csv" -size +8M -delete ;;
 layers)
   ( timeout 300 python tools/conv_layers.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${T}_cfg2_conv_layers_f32.txt; tail -1 gpurun_out/${T}_cfg2_conv_layers_f32.txt ;;
+sqpmc)
+  # matrix-pipe counters (MfmaUtil, wait shares, effective clock) of one 1x1 layer per reduction length, all three passes, under the
+  # library of 442b3b4 (tools/experiments/libsegmi_base.so, if present) and under this tree's: --pmc with --kernel-trace only
+  L=pytorch-segmentation_amd/segmi/libsegmi.so; cp $L /tmp/cur.so
+  for v in base cur; do
+    [ $v = base ] && { [ -f tools/experiments/libsegmi_base.so ] || continue; cp tools/experiments/libsegmi_base.so $L; }
+    [ $v = cur ] && cp /tmp/cur.so $L
+    rm -rf gpurun_out/sqpmc_$v
+    ( timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+        --output-format csv -d gpurun_out/sqpmc_$v/sq -o r -- python tools/conv_bench.py l4_1x1_up l4_1x1_down l3_1x1_up --iters 5 2>&1 | grep -v amdgpu.ids | tail -12 ) > gpurun_out/sqpmc_$v.log
+    for d in gpurun_out/sqpmc_$v/*/; do f=$(find $d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $d/r_counter_collection.csv 2>/dev/null; f=$(find $d -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp "$f" $d/r_kernel_trace.csv 2>/dev/null; done
+    ( echo "=== library: $v"; cat gpurun_out/sqpmc_$v.log; python tools/pmc_summary.py gpurun_out/sqpmc_$v/sq r conv_dma conv_wgrad 2>&1 | head -120 ) > gpurun_out/${T}_conv_pmc_$v.txt
+    rm -rf gpurun_out/sqpmc_$v
+  done
+  cp /tmp/cur.so $L; grep -h "MfmaUtil\|launches=" gpurun_out/${T}_conv_pmc_*.txt | head -40 ;;
 membound)
   for c in ${CFGS:-cfg2 cfg5}; do ( timeout 300 python tools/membound_ops.py $c 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${T}_${c}_membound_ops.txt; tail -2 gpurun_out/${T}_${c}_membound_ops.txt; done ;;
 esac
