@@ -325,13 +325,14 @@ def main():
         tag = "f32" + ("" if wino_default else "_direct")
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_cfg2_conv_traffic_%s.json" % tag))
         if args.config == "cfg2" and cands:
-            tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-            rec = tj.get("per_kernel", {}).get(top_name.split(" splitk=")[0])
-            if rec is None or tj.get("conv_winograd", False) != bool(wino_default):
-                tnote = "profiles/%s does not describe kernel %r under the current conv algorithm (stale profile: re-run tools/gpu_round.sh pmc)" % (cands[-1], top_name)
-            else:
-                traffic, step_traffic = rec["traffic_bytes_per_launch"], tj["traffic_bytes_per_step"]
-                tnote = "HBM+MALL bytes per launch from the rocprofv3 PMC passes (profiles/%s)" % cands[-1]
+            tnote = "no profile under profiles/ describes kernel %r under the current conv algorithm (stale profiles: re-run tools/gpu_round.sh pmc)" % top_name
+            for cand in reversed(cands):                              # newest name first; only a profile that knows the kernel counts
+                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                rec = tj.get("per_kernel", {}).get(top_name.split(" splitk=")[0])
+                if rec is not None and tj.get("conv_winograd", False) == bool(wino_default):
+                    traffic, step_traffic = rec["traffic_bytes_per_launch"], tj["traffic_bytes_per_step"]
+                    tnote = "HBM+MALL bytes per launch from the rocprofv3 PMC passes (profiles/%s)" % cand
+                    break
         step_s = nb * world / value                                   # seconds per step of the timed loop
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
