@@ -41,6 +41,11 @@ CONV_CASES = [
     (2, 64, 16, 16, 128, 1, 2, 0, 1, False),
     (3, 512, 6, 6, 128, 3, 1, 6, 6, False),
     (2, 304, 9, 9, 256, 3, 1, 1, 1, False),
+    # pointwise K-loop forms with ragged reductions (round 6): channel counts that are no multiple of 32 (fprop / dgrad: the partial last
+    # chunk goes through the masked piece), pixel counts that are no multiple of 32 (filter gradient), Xception's 728 channels
+    (2, 72, 9, 11, 40, 1, 1, 0, 1, False),
+    (1, 728, 8, 8, 728, 1, 1, 0, 1, False),
+    (3, 96, 7, 5, 200, 1, 1, 0, 1, True),
 ]
 
 
