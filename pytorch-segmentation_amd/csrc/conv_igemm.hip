@@ -1460,6 +1460,18 @@ bool dma_half_m(int M, int Cd, int batch = 1) {      // batch: the 16 contractio
     return rem > 0 && rem <= SEGMI_NUM_CU / 2;
 }
 
+// 64 x 64 tiles (five resident per CU at 32 KB of LDS each) for launches whose 64 x 128 tiling leaves the chip's 768 slots under-filled
+// (round 6; DeepLab-R101's 1024 -> 256 1x1 on 16 x 33x33 maps: 546 tiles of 64 x 128 work at 2.1 tiles per CU with a maximum of 3 —
+// 1092 tiles of 64 x 64 at 4.3 of 5: 85.3 -> 94.2 TF/s forward, profiles/r06_quarter_tiles_ab.txt).  SEGMI_CONV_QUARTER: fill threshold in
+// percent of the 768 slots (default 75, 0 = never).
+int g_quarter = -1;
+bool dma_quarter(int M, int Cd, int batch) {
+    if (g_quarter < 0) { const char* e = getenv("SEGMI_CONV_QUARTER"); g_quarter = (e && *e) ? atoi(e) : 75; }
+    if (g_quarter <= 0 || batch > 1) return false;
+    const long tiles = (long)segmi_cdiv(M, 64) * segmi_cdiv(Cd, 128);
+    return tiles * 100 <= (long)g_quarter * 3 * SEGMI_NUM_CU;
+}
+
 template <int MODE>
 int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned sb = span32((long)p.N * p.Hs * p.Ws * p.lds);
@@ -1467,6 +1479,7 @@ int dispatch_gather(GatherParams& p, hipStream_t st) {
     const unsigned db = span32((long)p.N * p.Hd * p.Wd * p.ldd);                  // the tile leaves through buffer stores
     if (conv_dma() && sb && wb && db) {
         const bool half_m = dma_half_m(p.M, p.Cd, p.batch);              // (a batched launch has batch x the tiles)
+        if (p.Cd > 64 && half_m && dma_quarter(p.M, p.Cd, p.batch)) return launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, db, st);
         if (p.Cd > 64) return half_m ? launch_dma<64, 128, 2, 2, MODE>(p, sb, wb, db, st) : launch_dma<128, 128, 2, 2, MODE>(p, sb, wb, db, st);
         if (p.Cd > 32) return half_m ? launch_dma<64, 64, 2, 2, MODE>(p, sb, wb, db, st) : launch_dma<128, 64, 2, 2, MODE>(p, sb, wb, db, st);
         return launch_dma<128, 32, 4, 1, MODE>(p, sb, wb, db, st);
@@ -1782,7 +1795,9 @@ int segmi_conv2d_variant(const segmi_conv_desc* d, int op, char* buf, size_t len
         const int M = op == 0 ? d->N * d->P * d->Q : d->N * d->H * d->W;
         const bool fast = !(op == 0 && Cs == 4 && d->R * d->S > 1) && d->R * d->S <= 32 && (op == 0 || d->stride == 1 || d->R * d->S <= 16);
         const bool pw = dma_pointwise(fast, d->R * d->S, Cs, op == 1 && d->stride > 1);
-        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %s>", dma_half_m(M, Cd) ? 64 : 128, bn, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false", pw ? "true" : "false");
+        const bool half = dma_half_m(M, Cd);
+        const int bnq = (Cd > 64 && half && dma_quarter(M, Cd, 1)) ? 64 : bn;
+        snprintf(buf, len, "conv_dma_kernel<%d, %d, %s, %d, %s, %s>", half ? 64 : 128, bnq, bn == 32 ? "4, 1" : "2, 2", op, fast ? "true" : "false", pw ? "true" : "false");
         return SEGMI_OK;
     }
     const int bk = (conv_bk() == 32 && Cs >= 32) ? 32 : 16;

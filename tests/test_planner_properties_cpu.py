@@ -73,16 +73,16 @@ def test_baseline_shapes_take_the_lds_dma_kernels(shape):
     assert conv_variant(d, 2).startswith("conv_wgrad_dma_kernel<")
 
 
-@pytest.mark.parametrize("shape,op,bm", [
-    ((16, 33, 33, 256, 1024, 1, 1, 1), 0, 64),     # cfg3 layer3 256 -> 1024: 1096 tiles of 128 rows, fifth per-CU round holds 72 -> 64-row tiles
-    ((16, 33, 33, 1024, 256, 1, 1, 1), 0, 64),     # 274 tiles: under-filled (the round-4 rule)
-    ((16, 33, 33, 512, 2048, 1, 1, 1), 1, 64),     # dgrad, Cd = 512: 548 tiles, 36 in the third round
-    ((16, 33, 33, 1024, 2048, 1, 1, 1), 0, 128),   # 2192 tiles: the last round is more than half full -> 128 rows stay
-    ((8, 64, 64, 512, 2048, 1, 1, 1), 0, 128),     # cfg2 layer4: 4096 tiles = 16 full rounds
-    ((8, 64, 64, 256, 256, 1, 1, 1), 1, 128),      # 512 tiles = 2 full rounds (64-row tiles measured 11 % slower here)
-    ((8, 32, 32, 728, 728, 1, 1, 1), 0, 64),       # Xception middle flow: 384 tiles, under-filled
+@pytest.mark.parametrize("shape,op,bm,bn", [
+    ((16, 33, 33, 256, 1024, 1, 1, 1), 0, 64, 128),     # cfg3 layer3 256 -> 1024: 1096 tiles of 128 rows, fifth per-CU round holds 72 -> 64-row tiles
+    ((16, 33, 33, 1024, 256, 1, 1, 1), 0, 64, 64),      # 274 tiles: under-filled (the round-4 rule); 546 tiles of 64 x 128 fill 71 % of the 768 slots -> 64 x 64 (round 6)
+    ((16, 33, 33, 512, 2048, 1, 1, 1), 1, 64, 128),     # dgrad, Cd = 512: 548 tiles, 36 in the third round
+    ((16, 33, 33, 1024, 2048, 1, 1, 1), 0, 128, 128),   # 2192 tiles: the last round is more than half full -> 128 rows stay
+    ((8, 64, 64, 512, 2048, 1, 1, 1), 0, 128, 128),     # cfg2 layer4: 4096 tiles = 16 full rounds
+    ((8, 64, 64, 256, 256, 1, 1, 1), 1, 128, 128),      # 512 tiles = 2 full rounds (64-row tiles measured 11 % slower here)
+    ((8, 32, 32, 728, 728, 1, 1, 1), 0, 64, 128),       # Xception middle flow: 384 tiles, under-filled; 768 tiles of 64 x 128 = every slot
 ])
-def test_tile_height_follows_the_per_cu_round_rule(shape, op, bm):
+def test_tile_height_follows_the_per_cu_round_rule(shape, op, bm, bn):
     """Round 5 (csrc/conv_igemm.hip dma_half_m, profiles/r05_half_m_layers.txt): 64-row tiles for under-filled launches (< 512 tiles
     of 128 rows) and when the last per-CU round of the 128-row tiling is less than half full (tiles mod 256 in (0, 128]); the BN
     statistics epilogue emits one partial per row tile of the tiling actually launched."""
@@ -90,8 +90,9 @@ def test_tile_height_follows_the_per_cu_round_rule(shape, op, bm):
     from segmi.ops import conv_variant
     d = _desc(*shape)
     name = conv_variant(d, op)
-    assert name.startswith("conv_dma_kernel<%d, 128, " % bm), name
+    assert name.startswith("conv_dma_kernel<%d, %d, " % (bm, bn)), name
     M, Cd = d.N * d.H * d.W, (d.K if op == 0 else d.C)
+    assert (bn == 64) == (bm == 64 and -(-M // 64) * -(-Cd // 128) * 100 <= 75 * 768)   # round 6: quarter tiles below 75 % of the slots
     tiles = -(-M // 128) * -(-Cd // 128)
     want64 = tiles < 512 or 0 < tiles % 256 <= 128
     assert (bm == 64) == want64

@@ -31,6 +31,10 @@ PROBLEMS = {
     "stem2": (8, 64, 256, 256, 64, 3, 1, 1, 1),
     "stem3": (8, 64, 256, 256, 128, 3, 1, 1, 1),
     "aux_3x3": (8, 1024, 64, 64, 512, 3, 1, 1, 1),
+    # DeepLab-R101 cfg3 (16 x 513^2, output stride 16): layer3's bottleneck 1x1 layers on 33x33 maps
+    "r101_l3_down": (16, 1024, 33, 33, 256, 1, 1, 0, 1),
+    "r101_l3_up": (16, 256, 33, 33, 1024, 1, 1, 0, 1),
+    "r101_l4_down": (16, 2048, 33, 33, 512, 1, 1, 0, 1),
 }
 
 ap = argparse.ArgumentParser()
