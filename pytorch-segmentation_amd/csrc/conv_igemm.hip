@@ -448,13 +448,46 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(GatherParams p, unsign
     const bool pk = MODE == MODE_FPROP && !FAST && p.pack4;
     const int RSl = pk ? 1 : (RS > 0 ? RS : 1);          // taps folded into the chunk axis when packed (RS == 0: empty parity class)
     const int nchunk = ((pk ? RS * 4 : p.Cs) + BK - 1) / BK;
-    const int Tall = nchunk * RSl;
+    // (round 6) Taps that are out of the image for EVERY row of this tile are skipped: a dilation-18 3x3 layer on a 33x33 map (DeepLab's
+    // ASPP, the dilations of which are too wide for the Winograd sub-grids) reaches its upper taps from 15 of 33 image rows only, and a
+    // 64-row tile covers two image rows — the zero chunks were a quarter of those launches.  tapmask = OR of the rows' tap-validity
+    // masks over the workgroup; the iteration space is (channel chunk) x (set bits of tapmask).  Unsplit tap-mask launches only.
+    unsigned tapmask = 0xFFFFFFFFu;
+    const bool skiptaps = FAST && !PW && !subm && p.ksplit <= 1 && RS > 1;
+    if (FAST && !PW) {
+        __shared__ unsigned s_tapmask[4];
+        if (skiptaps) {                                      // (workgroup-uniform)
+            unsigned mk = 0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) mk |= a_mask[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mk |= (unsigned)__shfl_xor((int)mk, off);
+            if (lane == 0) s_tapmask[wave] = mk;
+            __syncthreads();
+            tapmask = __builtin_amdgcn_readfirstlane(s_tapmask[0] | s_tapmask[1] | s_tapmask[2] | s_tapmask[3]);
+        }
+    }
+    const int nvalid = skiptaps ? __builtin_popcount(tapmask & (RS >= 32 ? 0xFFFFFFFFu : ((1u << RS) - 1u))) : RSl;
+    const int Tall = nchunk * nvalid;
     const int it0 = bidy * p.its_per_split;              // split-K slice of the (chunk, tap) iteration space (whole range if ksplit == 1)
     const int T = min(Tall, it0 + p.its_per_split);
     const int Sl = p.S > 0 ? p.S : 1;
     int c0 = (it0 / RSl) * BK, r = (it0 % RSl) / Sl, s = (it0 % RSl) % Sl;  // channel chunk outer, taps inner: a pixel row's taps reuse L1/L2 lines
+    int tcur = 0;                                        // skiptaps: current tap index (a set bit of tapmask)
+    auto next_tap = [&](int from) {                      // first set bit of tapmask at or after `from`, RS if none
+        const unsigned rest = from < 32 ? (tapmask >> from) << from : 0u;
+        const int t = rest ? __builtin_ctz(rest) : 32;
+        return t < RS ? t : RS;
+    };
+    if (skiptaps) { tcur = next_tap(0); if (tcur >= RS) tcur = 0; r = tcur / Sl; s = tcur - r * Sl; }
     auto advance = [&]() {
         if (pk) { c0 += BK; return; }
+        if (skiptaps) {
+            int t = next_tap(tcur + 1);
+            if (t >= RS) { t = next_tap(0); c0 += BK; }
+            tcur = t; r = t / Sl; s = t - r * Sl;
+            return;
+        }
         if (++s == p.S) { s = 0; if (++r == p.R) { r = 0; c0 += BK; } }
     };
 
@@ -840,6 +873,7 @@ struct WgradParams {
     // results lie bs_x / bs_dy / bs_out floats apart (the 16 transform-domain contractions of a Winograd filter gradient)
     int batch;
     long bs_x, bs_dy, bs_out;
+    int skiprows;  // 1 (generic form, Q >= 32): pixel chunks whose image rows are all outside the image for the workgroup's tap are skipped
     int flat;  // 1: (tile, split) from the linear workgroup id through xcd_swizzle, split-major (see conv_wgrad_dma_kernel); 0: blockIdx.y = split
 };
 
@@ -1077,9 +1111,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
     unsigned q_achunk = 0, q_bchunk = 0;
     int q_rowbase = 0, q_wq = 0, q_mb = 0;
     bool q_hok = false, q_tail = false;
-    auto prep = [&](int mb) {
+    auto prep = [&](int mb, int jump = 0) {                      // jump: pixels skipped since the last issued chunk (generic form)
         q_mb = mb;
         q_tail = mb + BKP > mend;                                // (PW: the one chunk with rows past the last pixel)
+        if (!PW && !ROWQ && jump) {                              // (scalar branch)
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                b_q[i] += jump;
+                while (b_q[i] >= p.Q) {
+                    b_q[i] -= p.Q;
+                    if (++b_p[i] == p.P) { b_p[i] = 0; ++b_n[i]; }
+                }
+            }
+        }
         if (PW) { q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u; q_bchunk = (unsigned)mb * (unsigned)p.ldx * 4u; return; }
         if (ROWQ) {
             q_achunk = (unsigned)mb * (unsigned)p.ldy * 4u;                                     // scalar
@@ -1139,8 +1183,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (mbeg < mend) {
-        prep(mbeg);
+    // (round 6) Generic form, dilated 3x3 on small maps (DeepLab's ASPP: dilation 18 on 33x33 reaches its upper taps from 15 of the
+    // 33 image rows): a 32-pixel chunk covers at most two image rows when Q >= 32, and a chunk both rows of which are outside the
+    // image for this workgroup's tap contributes zeros — skipped.  (sp, sq) = image row / column of the candidate chunk's first
+    // pixel, carried in scalars; next_chunk() moves the candidate to the first chunk at or after it that has work.
+    const bool skip = !PW && !ROWQ && p.skiprows;
+    int sp = 0, sq = 0;
+    if (skip) {
+        const int mm = mbeg < p.M ? mbeg : 0;
+        const int rem = mm - (mm / PQ) * PQ;
+        sp = __builtin_amdgcn_readfirstlane(rem / p.Q);
+        sq = __builtin_amdgcn_readfirstlane(rem - sp * p.Q);
+    }
+    auto next_chunk = [&](int mb) {
+        if (!skip) return mb;
+        while (mb < mend) {
+            const int p1 = sp + 1 == p.P ? 0 : sp + 1;
+            const bool v0 = (unsigned)(sp * p.stride + tap_h) < (unsigned)p.H;
+            const bool v1 = sq + BKP > p.Q && (unsigned)(p1 * p.stride + tap_h) < (unsigned)p.H;
+            if (v0 || v1) break;
+            mb += BKP; sq += BKP;
+            if (sq >= p.Q) { sq -= p.Q; sp = p1; }
+        }
+        return mb;
+    };
+    auto step_chunk = [&]() { sq += BKP; if (sq >= p.Q) { sq -= p.Q; if (++sp == p.P) sp = 0; } };
+    const int mfirst = next_chunk(mbeg);
+    if (mfirst < mend) {
+        prep(mfirst, mfirst - mbeg);
 #pragma unroll
         for (int q = 0; q < NP; ++q) piece(q, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1180,9 +1250,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradParams p, unsi
         };
         fetch(a_lane, b_lane, 0, 0);
         fetch(a_lane, b_lane, 1, 1);
-        for (int mb = mbeg; mb < mend; mb += BKP) {
-            const bool have = mb + BKP < mend;
-            if (have) prep(mb + BKP);
+        for (int mb = mfirst, mnext; mb < mend; mb = mnext) {
+            if (skip) step_chunk();
+            mnext = next_chunk(mb + BKP);
+            const bool have = mnext < mend;
+            if (have) prep(mnext, mnext - (mb + BKP));
             const unsigned abase = a_lane + (unsigned)buf * (STAGE * 4), bbase = b_lane + (unsigned)buf * (STAGE * 4);
 #pragma unroll
             for (int kk = 0; kk < KS - 2; ++kk) {
@@ -1605,9 +1677,19 @@ int wgrad_flat() {
     return g_wgrad_flat;
 }
 
+int g_wgrad_skiprows = -1;  // SEGMI_WGRAD_SKIPROWS=0: every chunk is issued (A/B hook)
+int wgrad_skiprows() {
+    if (g_wgrad_skiprows < 0) {
+        const char* e = getenv("SEGMI_WGRAD_SKIPROWS");
+        g_wgrad_skiprows = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_wgrad_skiprows;
+}
+
 template <int BM, int BN>
 int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     p.flat = wgrad_flat();
+    p.skiprows = 0;
     const size_t lds = (size_t)2 * WG_BKP * (BM + BN) * sizeof(float);
     dim3 grid((unsigned)(pl.tiles_k * pl.tiles_c * (pl.pack4 ? 1 : p.R * p.S)), (unsigned)pl.nsplit, (unsigned)(p.batch > 1 ? p.batch : 1));
     unsigned xb, dyb;
@@ -1620,7 +1702,10 @@ int launch_wgrad(WgradParams& p, const WgradPlan& pl, hipStream_t st) {
             else      hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, p, xb, dyb);
         }
         else if (rowq) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, true>), grid, dim3(256), lds, st, p, xb, dyb);
-        else           hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
+        else {
+            p.skiprows = wgrad_skiprows() && p.Q >= WG_BKP && p.R * p.S > 1 && !p.pack4 && p.pad > 0;
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, false>), grid, dim3(256), lds, st, p, xb, dyb);
+        }
     }
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WG_BKP, 2, 2>), grid, dim3(256), lds, st, p);
     return segmi_launch_status();

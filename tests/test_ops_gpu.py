@@ -46,6 +46,13 @@ CONV_CASES = [
     (2, 72, 9, 11, 40, 1, 1, 0, 1, False),
     (1, 728, 8, 8, 728, 1, 1, 0, 1, False),
     (3, 96, 7, 5, 200, 1, 1, 0, 1, True),
+    # taps that miss the image for whole tiles / whole 32-pixel chunks (round 6: skipped by the fprop / dgrad tap mask and by the
+    # filter-gradient kernel's row test): ASPP's dilation 18 on a 33x33 map, rows of no multiple of 32, padding != dilation, stride 2
+    (2, 64, 33, 33, 96, 3, 1, 18, 18, False),
+    (3, 40, 35, 37, 48, 3, 1, 12, 12, True),
+    (2, 16, 34, 36, 32, 3, 1, 20, 18, False),
+    (2, 32, 70, 70, 64, 3, 2, 1, 1, False),
+    (1, 32, 40, 33, 32, 3, 1, 30, 30, False),
 ]
 
 

@@ -92,6 +92,10 @@ def test_unet_frozen_bn_all_gradients_match_oracle(cuda):
         mx = (g - r).abs().max().item() / (r.abs().max().item() + 1e-30)
         l64 = (g - ref64[k].grad).norm().item() / (ref64[k].grad.norm().item() + 1e-30)
         worst32, worst64 = max(worst32, l2), max(worst64, l64)
-        assert l2 <= 1e-3 and mx <= 5e-3, (k, l2, mx)           # per-tensor bound against the torch-CPU fp32 oracle
+        # per-tensor bound against the torch-CPU fp32 oracle.  Where that oracle is itself more than 5e-4 from fp64 (down4 / middle:
+        # 7-9e-4), the fp32-to-fp32 distance measures the oracle's rounding as much as ours and sits at 0.93-1.21e-3 depending on the
+        # tile plan's summation order; there the criterion is the stricter statement that HIP is no farther from fp64 than the oracle is.
+        floor_k = ((r - ref64[k].grad).norm() / (ref64[k].grad.norm() + 1e-30)).item()
+        assert mx <= 5e-3 and (l2 <= 1e-3 or (floor_k > 5e-4 and l64 <= floor_k)), (k, l2, mx, l64, floor_k)
         assert l64 <= 2.0 * floor + 1e-4, (k, l64, floor)      # and at most twice the fp32 oracle's own distance from fp64
     print("UNet gradients: worst rel-L2 vs torch-CPU fp32 %.2e, vs fp64 %.2e; torch-CPU fp32 vs fp64 %.2e" % (worst32, worst64, floor))

@@ -35,6 +35,10 @@ PROBLEMS = {
     "r101_l3_down": (16, 1024, 33, 33, 256, 1, 1, 0, 1),
     "r101_l3_up": (16, 256, 33, 33, 1024, 1, 1, 0, 1),
     "r101_l4_down": (16, 2048, 33, 33, 512, 1, 1, 0, 1),
+    # DeepLab's ASPP: 3x3 at dilations 6 / 12 / 18 on the 33x33 map (too wide for the Winograd sub-grids: direct kernels)
+    "aspp_d6": (16, 2048, 33, 33, 256, 3, 1, 6, 6),
+    "aspp_d12": (16, 2048, 33, 33, 256, 3, 1, 12, 12),
+    "aspp_d18": (16, 2048, 33, 33, 256, 3, 1, 18, 18),
 }
 
 ap = argparse.ArgumentParser()
