@@ -21,7 +21,9 @@ def _dot(a, b):
 
 # (N, C, H, W, K, R, stride, pad, dil): the PSP bottleneck, a dilated layer4 3x3, the strided layer2 3x3, a 1x1 expansion, stem
 FULL_CONVS = [(8, 4096, 64, 64, 512, 3, 1, 1, 1), (8, 512, 64, 64, 512, 3, 1, 4, 4), (8, 128, 128, 128, 128, 3, 2, 1, 1),
-              (8, 256, 64, 64, 1024, 1, 1, 0, 1), (8, 3, 512, 512, 64, 3, 2, 1, 1)]
+              (8, 256, 64, 64, 1024, 1, 1, 0, 1), (8, 3, 512, 512, 64, 3, 2, 1, 1),
+              # cfg3: DeepLab's ASPP branch at dilation 18 on the 33x33 map (taps / pixel chunks that miss the image are skipped per tile)
+              (16, 2048, 33, 33, 256, 3, 1, 18, 18)]
 
 
 @pytest.mark.parametrize("case", FULL_CONVS)
@@ -46,7 +48,11 @@ def test_conv_adjoint_identities_and_definition_at_full_size(cuda, case):
     # a strided sample of output pixels against the definition in fp64 (incl. corners: zero padding, dilation)
     P, Q = y.shape[2], y.shape[3]
     xs, ws = x.detach().double(), w.detach().double()
-    for (n, p, q) in [(0, 0, 0), (N - 1, P - 1, Q - 1), (1, P // 2, 0), (N // 2, 1, Q - 2), (2, P - 1, Q // 3)]:
+    pts = [(0, 0, 0), (N - 1, P - 1, Q - 1), (1, P // 2, 0), (N // 2, 1, Q - 2), (2, P - 1, Q // 3)]
+    # the image rows / columns where a filter row or column enters and leaves the image (the edges of the skipped tap ranges)
+    pts += [(e % N, e, (7 * e) % Q) for e in (pad - 1, pad, P - 1 - pad, P - pad) if 0 <= e < P and pad > 1]
+    pts += [((e + 1) % N, (5 * e) % P, e) for e in (pad - 1, pad, Q - 1 - pad, Q - pad) if 0 <= e < Q and pad > 1]
+    for (n, p, q) in pts:
         acc = torch.zeros(K, dtype=torch.float64, device=cuda)
         for r in range(R):
             for s in range(R):
