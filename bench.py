@@ -342,7 +342,8 @@ def main():
                 "flops_per_launch": top["flops"] // top["launches"], "algorithmic_bytes_per_launch": top["bytes"] // top["launches"],
                 "scope": "dominant kernel = the matrix kernel with the largest total time in one step; HIP events per launch on the launch "
                          "stream (for a Winograd pass: the event pair the library records around its ONE batched contraction launch); "
-                         "achieved/frac = EXECUTED FLOPs (the 16 transform-domain contractions of a Winograd launch, 2*16*T*C*K), "
+                         "achieved/frac = EXECUTED FLOPs (the 16 transform-domain contractions of a Winograd launch, 2*16*T*C*K; a direct launch that "
+                         "skips taps / pixel chunks whose operand is all padding counts only the share it issues, segmi.ops._conv_issued), "
                          "effective = the direct-convolution FLOPs those launches stand for; traffic: " + tnote,
                 "all_conv": {"achieved": round(all_ach, 2), "frac": round(all_ach / peak, 4),
                              "effective": round(tot_eff / (tot_ms * 1e-3) / 1e12, 2),

@@ -11,6 +11,7 @@ every arithmetic op below is a libsegmi kernel, and there is no CPU path — CPU
 """
 import ctypes
 import os
+import re
 import weakref
 
 import torch
@@ -261,6 +262,58 @@ def _conv_flops(d, C):
     return 2 * d.N * d.P * d.Q * d.K * d.R * d.S * C
 
 
+def _conv_issued(d, op):
+    """Fraction of a direct launch's (tile x reduction chunk x tap) iteration space that the kernel issues (instrumentation only;
+    1.0 wherever nothing is skipped).  Restates two rules of csrc/conv_igemm.hip: conv_dma_kernel's tap-mask form (FAST, not pointwise,
+    unsplit, stride 1 for the data gradient) walks only the taps that reach the image from SOME row of its tile of BM consecutive
+    pixels; conv_wgrad_dma_kernel's generic form (not ROWQ, not pointwise, Q >= 32, padded, C != 4) skips the 32-pixel chunks both
+    image rows of which miss the image for the workgroup's tap.  Skipped products have a zero-filled operand: they are part of
+    the algorithmic FLOP count (`_conv_flops`) and not of the EXECUTED one."""
+    import numpy as np
+    RS = d.R * d.S
+    v = conv_variant(d, op)
+    m = re.match(r"conv_(wgrad_)?dma_kernel<([^>]*)>", v)
+    if RS <= 1 or m is None:
+        return 1.0
+    args = [a.strip() for a in m.group(2).split(",")]
+    taps_r, taps_s = np.arange(d.R), np.arange(d.S)
+    if op == 2:
+        if args[2] != "false" or args[3] != "false" or d.Q < 32 or d.pad <= 0 or d.C == 4:
+            return 1.0
+        M = d.N * d.P * d.Q
+        m0 = np.arange(0, M, 32)
+        p0, q0 = (m0 % (d.P * d.Q)) // d.Q, m0 % d.Q
+        p1 = np.where(p0 + 1 == d.P, 0, p0 + 1)
+        ok = lambda pr: ((pr[:, None] * d.stride - d.pad + taps_r[None, :] * d.dil >= 0) &
+                         (pr[:, None] * d.stride - d.pad + taps_r[None, :] * d.dil < d.H))
+        issued = ok(p0) | ((q0 + 32 > d.Q)[:, None] & ok(p1))          # [chunks, R]: every tap column of a filter row alike
+        return float(issued.mean())
+    if args[5] != "true" or args[6] != "false" or " splitk=" in v or (op == 1 and d.stride != 1):
+        return 1.0
+    BM = int(args[0])
+    if op == 0:       # rows = output pixels, taps read x at (p * stride - pad + r * dil, ...)
+        Hd, Wd = d.P, d.Q
+        ih = np.arange(Hd)[:, None] * d.stride - d.pad + taps_r[None, :] * d.dil
+        iw = np.arange(Wd)[:, None] * d.stride - d.pad + taps_s[None, :] * d.dil
+        vh, vw = (ih >= 0) & (ih < d.H), (iw >= 0) & (iw < d.W)
+    else:             # rows = input pixels, taps read dy at (h + pad - r * dil, ...)
+        Hd, Wd = d.H, d.W
+        ih = np.arange(Hd)[:, None] + d.pad - taps_r[None, :] * d.dil
+        iw = np.arange(Wd)[:, None] + d.pad - taps_s[None, :] * d.dil
+        vh, vw = (ih >= 0) & (ih < d.P), (iw >= 0) & (iw < d.Q)
+    pix = (vh[:, None, :, None] & vw[None, :, None, :]).reshape(Hd * Wd, RS)       # [pixel of one image, tap]
+    rows = np.tile(pix, (d.N, 1))
+    pad_rows = (-rows.shape[0]) % BM
+    if pad_rows:
+        rows = np.concatenate([rows, np.zeros((pad_rows, RS), dtype=bool)])
+    return float(rows.reshape(-1, BM, RS).any(axis=1).mean())
+
+
+def _conv_exec_flops(d, C, op):
+    """EXECUTED FLOPs of a direct launch, as a callable for `span` (evaluated only while a KernelTimer is active)."""
+    return lambda: int(round(_conv_flops(d, C) * _conv_issued(d, op)))
+
+
 def _conv_bytes(d, C):
     """Algorithmic bytes of one conv pass: each of the three tensors (input, filter, output) crosses HBM once, fp32."""
     return 4 * (d.N * d.H * d.W * C + d.K * d.R * d.S * C + d.N * d.P * d.Q * d.K)
@@ -375,7 +428,7 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
         parts = lib.segmi_conv2d_fwd_stats_parts(d)
         if parts > 0:
             part = torch.empty(parts * 3 * d.K, device=dev, dtype=torch.float32)
-            with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 0), _conv_exec_flops(d, C, 0), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
                 check(lib.segmi_conv2d_fwd_stats(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), part.data_ptr(), st), "conv2d_fwd_stats")
             _BN_FUSE["last"] = (part, parts)
             _BN_FUSE["emitted"] += 1
@@ -383,7 +436,7 @@ def _conv_fwd(d, C, x, w, bias, y, accumulate=0, keep_v=False, bn_stats=False):
     nws = lib.segmi_conv2d_fwd_workspace(d) if (bias is None and not accumulate) else 0
     ws = workspace(nws, dev) if nws else None
     wsp = ws.data_ptr() if ws is not None else None
-    with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+    with span(lambda: conv_variant(d, 0), _conv_exec_flops(d, C, 0), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
         check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), accumulate, wsp, nws, st), "conv2d_fwd")
 
 
@@ -401,7 +454,7 @@ def _conv_wgrad(d, C, x, dy, dwb, v=None):
         return
     nws = lib.segmi_conv2d_wgrad_workspace(d)
     ws = workspace(nws, dev) if nws else None
-    with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+    with span(lambda: conv_variant(d, 2), _conv_exec_flops(d, C, 2), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
         check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr() if ws is not None else None, nws, st),
               "conv2d_wgrad")
 
@@ -514,7 +567,7 @@ def _conv_dgrad(d, C, dy, wt, dx, accumulate=0):
             check(lib.segmi_conv2d_winograd_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, ws.data_ptr(), nws, st),
                   "conv2d_winograd_dgrad")
         return
-    with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+    with span(lambda: conv_variant(d, 1), _conv_exec_flops(d, C, 1), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
         check(lib.segmi_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), accumulate, st), "conv2d_dgrad")
 
 
@@ -931,7 +984,7 @@ class _ConvTranspose2x2Fn(torch.autograd.Function):
         check(lib.segmi_nchw_to_nhwc(weight.contiguous().data_ptr(), w2.data_ptr(), 1, C, K4, 1, C, st), "convT filter")
         t = empty_nhwc(N, K4, H, W, x.device)
         d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(t))
-        with span(lambda: conv_variant(d, 0), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+        with span(lambda: conv_variant(d, 0), _conv_exec_flops(d, C, 0), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
             nws = lib.segmi_conv2d_fwd_workspace(d)
             ws = workspace(nws, x.device) if nws else None
             check(lib.segmi_conv2d_fwd(d, x.data_ptr(), w2.data_ptr(), None, t.data_ptr(), 0, ws.data_ptr() if ws is not None else None, nws, st),
@@ -959,14 +1012,14 @@ class _ConvTranspose2x2Fn(torch.autograd.Function):
             check(lib.segmi_filter_krsc_to_crsk(w2.data_ptr(), wt.data_ptr(), K4, 1, 1, C, K4, st), "krsc_to_crsk")
             dx = empty_nhwc(N, C, H, W, dev)
             d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(dx), ld_of(g))
-            with span(lambda: conv_variant(d, 1), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 1), _conv_exec_flops(d, C, 1), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
                 check(lib.segmi_conv2d_dgrad(d, g.data_ptr(), wt.data_ptr(), dx.data_ptr(), 0, st), "convT conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             d = ConvDesc(N, H, W, C, K4, 1, 1, H, W, 1, 0, 1, ld_of(x), ld_of(g))
             nws = lib.segmi_conv2d_wgrad_workspace(d)
             ws = workspace(nws, dev) if nws else None
             dw2 = torch.empty(K4 * C, device=dev, dtype=torch.float32)
-            with span(lambda: conv_variant(d, 2), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+            with span(lambda: conv_variant(d, 2), _conv_exec_flops(d, C, 2), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
                 check(lib.segmi_conv2d_wgrad(d, x.data_ptr(), g.data_ptr(), dw2.data_ptr(),
                                              ws.data_ptr() if ws is not None else None, nws, st), "convT conv2d_wgrad")
             dw = torch.empty((C, K, 2, 2), device=dev, dtype=torch.float32)
@@ -1593,7 +1646,7 @@ def pyramid_pool(x, bins):
 def _conv_call(kind, d, C, *args):
     """One libsegmi convolution launch wrapped in a roofline span (kind 0 fwd, 1 dgrad, 2 wgrad)."""
     fn = (lib.segmi_conv2d_fwd, lib.segmi_conv2d_dgrad, lib.segmi_conv2d_wgrad)[kind]
-    with span(lambda: conv_variant(d, kind), _conv_flops(d, C), _conv_bytes(d, C), detail=lambda: _geom(d)):
+    with span(lambda: conv_variant(d, kind), _conv_exec_flops(d, C, kind), _conv_bytes(d, C), detail=lambda: _geom(d), eff=_conv_flops(d, C)):
         check(fn(d, *args), ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")[kind])
 
 

@@ -102,9 +102,11 @@ class KernelTimer:
             self._patched = {}
 
     @contextlib.contextmanager
-    def _span(self, name, flops, nbytes, detail=None, inner=None):
+    def _span(self, name, flops, nbytes, detail=None, inner=None, eff=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        rec = {"name": name, "flops": flops, "bytes": nbytes, "a": a, "b": b, "detail": detail, "inner": None}
+        # flops = EXECUTED, eff = the algorithmic FLOPs of the convolution the launch stands for (None: the same — they differ for a
+        # direct launch that skips taps / chunks with zero-filled operands, ops._conv_issued, and for the composite Winograd calls)
+        rec = {"name": name, "flops": flops, "eff": flops if eff is None else eff, "bytes": nbytes, "a": a, "b": b, "detail": detail, "inner": None}
         if inner is not None:
             # composite call (a Winograd pass = transforms + ONE batched contraction launch): the library records a second
             # event pair right around the contraction (segmi_conv2d_winograd_trace), so the MFMA-bound kernel is timed apart
@@ -129,7 +131,7 @@ class KernelTimer:
             r = acc.setdefault((s["name"], s["detail"]), [0, 0.0, 0, 0])
             r[0] += 1
             r[1] += s["a"].elapsed_time(s["b"])
-            r[2] += s["flops"]
+            r[2] += s["eff"]
             r[3] += s["bytes"]
         return sorted(((k[0], k[1], v[0], v[1], v[2], v[3]) for k, v in acc.items()), key=lambda t: -t[3])
 
@@ -149,7 +151,7 @@ class KernelTimer:
                 r["launches"] += 1
                 r["total_ms"] += whole
                 r["flops"] += s["flops"]
-                r["eff_flops"] += s["flops"]
+                r["eff_flops"] += s["eff"]
                 r["bytes"] += s["bytes"]
                 continue
             inn = s["inner"]
@@ -158,7 +160,7 @@ class KernelTimer:
             r["launches"] += 1
             r["total_ms"] += core
             r["flops"] += inn["flops"]
-            r["eff_flops"] += s["flops"]
+            r["eff_flops"] += s["eff"]
             r["bytes"] += inn["bytes"]
             t = out["winograd transforms (" + s["name"].split(":", 1)[0].split()[-1] + ")"]
             t["launches"] += 1
@@ -169,10 +171,11 @@ class KernelTimer:
         return dict(out)
 
 
-def span(name, flops=0, nbytes=0, detail=None, inner=None):
-    """Context manager around one C-ABI launch; `name`/`detail`/`inner` may be callables evaluated only when timing.
-    inner = (executed FLOPs, operand bytes) of the contraction inside a composite Winograd call (see KernelTimer._span)."""
+def span(name, flops=0, nbytes=0, detail=None, inner=None, eff=None):
+    """Context manager around one C-ABI launch; `name`/`flops`/`detail`/`inner` may be callables evaluated only when timing.
+    inner = (executed FLOPs, operand bytes) of the contraction inside a composite Winograd call (see KernelTimer._span);
+    eff = algorithmic FLOPs where they differ from the executed `flops`."""
     if _ACTIVE is None:
         return _NULL
-    return _ACTIVE._span(name() if callable(name) else name, flops, nbytes, detail() if callable(detail) else detail,
-                         inner() if callable(inner) else inner)
+    return _ACTIVE._span(name() if callable(name) else name, flops() if callable(flops) else flops, nbytes,
+                         detail() if callable(detail) else detail, inner() if callable(inner) else inner, eff)

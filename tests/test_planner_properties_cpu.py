@@ -158,3 +158,20 @@ def test_lovasz_workspace_layout(rows, C):
     assert seg >= keys + hist + units
     assert seg - keys - ((hist + 255) & ~255) - ((units + 255) & ~255) < (1 << 20) + C * ((rows + 2047) // 2048) * 12 + 4096
     assert lib.segmi_lovasz_workspace(1 << 24, C) == 0          # fp32-exact rank arithmetic ends at 2^24 pixels, like the reference's cumsums
+
+
+def test_issued_fraction_of_launches_that_skip_taps():
+    """The instrumentation's EXECUTED-FLOP accounting (ops._conv_issued): 1 for pointwise layers and for 3x3 layers whose taps all
+    reach the image from every tile; for DeepLab's ASPP branches on the 33x33 map (dilation 6 / 12 / 18) the share of (tile, tap) pairs /
+    (chunk, tap) pairs the kernels issue — never below the share of (pixel, tap) pairs inside the image, falling with the dilation."""
+    from segmi.ops import _conv_issued
+    assert all(_conv_issued(_desc(8, 64, 64, 512, 2048 // 4, 1, 1, 1), op) == 1.0 for op in (0, 1, 2))
+    prev = [1.0, 1.0, 1.0]
+    for dil in (6, 12, 18):
+        d = _desc(16, 33, 33, 2048, 256, 3, 1, dil)
+        inside = ((1 + 2 * (33 - dil) / 33.0) / 3.0) ** 2          # (pixel, tap) pairs inside the image / all pairs
+        rows_only = (1 + 2 * (33 - dil) / 33.0) / 3.0             # what whole image rows can skip
+        for op in (0, 1, 2):
+            f = _conv_issued(d, op)
+            assert inside < rows_only <= f < prev[op], (dil, op, f, rows_only, prev[op])
+            prev[op] = f
