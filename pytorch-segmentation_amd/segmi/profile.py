@@ -106,7 +106,9 @@ class KernelTimer:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # flops = EXECUTED, eff = the algorithmic FLOPs of the convolution the launch stands for (None: the same — they differ for a
         # direct launch that skips taps / chunks with zero-filled operands, ops._conv_issued, and for the composite Winograd calls)
-        rec = {"name": name, "flops": flops, "eff": flops if eff is None else eff, "bytes": nbytes, "a": a, "b": b, "detail": detail, "inner": None}
+        # (a callable `flops` is evaluated by _resolve() when the spans are read, not here: host work between the launches of the
+        #  instrumented step leaves the GPU idle between kernels and the kernels after such a gap measured 4 % slower)
+        rec = {"name": name, "flops": flops, "eff": eff, "bytes": nbytes, "a": a, "b": b, "detail": detail, "inner": None}
         if inner is not None:
             # composite call (a Winograd pass = transforms + ONE batched contraction launch): the library records a second
             # event pair right around the contraction (segmi_conv2d_winograd_trace), so the MFMA-bound kernel is timed apart
@@ -122,10 +124,18 @@ class KernelTimer:
         b.record()
         self.spans.append(rec)
 
+    def _resolve(self):
+        for s in self.spans:
+            if callable(s["flops"]):
+                s["flops"] = s["flops"]()
+            if s["eff"] is None:
+                s["eff"] = s["flops"]
+
     def by_detail(self):
         """[(name, detail, launches, total_ms, flops, bytes)] grouped by (name, detail), slowest first (synchronises).  Composite
         (Winograd) calls are ONE row each: whole-call time against the ALGORITHMIC (direct-convolution) FLOPs."""
         torch.cuda.synchronize()
+        self._resolve()
         acc = {}
         for s in self.spans:
             r = acc.setdefault((s["name"], s["detail"]), [0, 0.0, 0, 0])
@@ -143,6 +153,7 @@ class KernelTimer:
         that runs it (the batched implicit-GEMM / filter-gradient kernel, executed = 32*T*C*K transform-domain FLOPs, timed by the
         inner event pair) and "winograd transforms" (whole call minus contraction, 0 FLOPs)."""
         torch.cuda.synchronize()
+        self._resolve()
         out = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0, "eff_flops": 0, "bytes": 0})
         for s in self.spans:
             whole = s["a"].elapsed_time(s["b"])
@@ -172,10 +183,11 @@ class KernelTimer:
 
 
 def span(name, flops=0, nbytes=0, detail=None, inner=None, eff=None):
-    """Context manager around one C-ABI launch; `name`/`flops`/`detail`/`inner` may be callables evaluated only when timing.
+    """Context manager around one C-ABI launch; `name`/`detail`/`inner` may be callables evaluated only when timing, a callable
+    `flops` only when the timer's spans are read.
     inner = (executed FLOPs, operand bytes) of the contraction inside a composite Winograd call (see KernelTimer._span);
     eff = algorithmic FLOPs where they differ from the executed `flops`."""
     if _ACTIVE is None:
         return _NULL
-    return _ACTIVE._span(name() if callable(name) else name, flops() if callable(flops) else flops, nbytes,
+    return _ACTIVE._span(name() if callable(name) else name, flops, nbytes,
                          detail() if callable(detail) else detail, inner() if callable(inner) else inner, eff)
