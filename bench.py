@@ -374,6 +374,11 @@ def main():
         from segmi.graph import GraphedStep
         run = GraphedStep(step, warmup=3)       # eager warm-up steps + capture; replays below are the timed steps
     dt, final_loss = timed(run)
+    if os.environ.get("SEGMI_BENCH_MEMSTATS") == "1":          # A/B diagnostics: did the caching allocator reach a steady state?
+        ms_ = torch.cuda.memory_stats(device)
+        print("[bench] memstats: reserved %.2f GB, segments %d, device mallocs %d, retries %d" % (
+            ms_.get("reserved_bytes.all.current", 0) / 1e9, ms_.get("segment.all.current", 0), ms_.get("num_device_alloc", 0),
+            ms_.get("num_alloc_retries", 0)), file=sys.stderr, flush=True)
     ms = 1e3 * dt / args.steps
     value = world * nb * args.steps / dt
     roof = None if args.no_roofline else roofline_of(value)

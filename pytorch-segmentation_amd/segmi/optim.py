@@ -8,7 +8,10 @@ state_dicts interchange with checkpoints written by the reference (buffers that 
 filter are re-laid in the parameter's memory order on the first step).
 """
 import ctypes as C
+import os
+import time
 
+import numpy as np
 import torch
 
 from ._lib import check, lib
@@ -17,6 +20,10 @@ from ._lib import check, lib
 class _Chunk(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum", C.c_void_p), ("count", C.c_long), ("group", C.c_int),
                 ("vec4", C.c_int)]
+
+
+_CHUNK_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("momentum", "<u8"), ("count", "<i8"), ("group", "<i4"), ("vec4", "<i4")])
+assert _CHUNK_DTYPE.itemsize == C.sizeof(_Chunk)
 
 
 def _same_layout(a, b):
@@ -46,6 +53,9 @@ class SGD(torch.optim.Optimizer):
         self.capturable = bool(capturable)
         self._ring = self._ring_events = self._hyper_dev = None
         self._ring_pos = 0
+        self._tab_ring = self._tab_events = self._step_end = None
+        self._tab_pos = 0
+        self._auto, self._drains = None, []       # `auto` upload mode: decided from the drain times of the first steps
 
     def push_hyper(self):
         """Stream-ordered refresh of the device-resident hyper-parameters from `param_groups` (capturable=True only)."""
@@ -98,13 +108,16 @@ class SGD(torch.optim.Optimizer):
         return order, bounds
 
     def _build(self):
-        """Chunk table on the device; rebuilt only if a gradient / parameter / buffer pointer changed."""
+        """Chunk table on the device; rebuilt only if a gradient / parameter / buffer pointer changed.
+
+        The per-step work is the pointer signature alone.  A rebuild — every step when gradients are freshly allocated tensors
+        (`zero_grad(set_to_none=True)` without a reducer's persistent buckets: the allocator hands the side-stream filter gradients
+        different blocks from step to step) — lays the table out with numpy and hands it to `_upload`."""
         ce = lib.segmi_sgd_chunk_elems()
-        entries, sig = [], []
+        sig, first_param = [], []            # first_param[i]: how many live parameters precede parameter i of `order`
         order, bounds = self._ordered()
-        first_chunk = []                 # chunk index at which parameter i of `order` starts
         for gi, p in order:
-            first_chunk.append(len(entries))
+            first_param.append(len(sig))
             if p.grad is None:
                 continue
             st = self.state[p]
@@ -120,26 +133,78 @@ class SGD(torch.optim.Optimizer):
             if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and _same_layout(g, p) and _same_layout(buf, p)):
                 raise RuntimeError("segmi.optim.SGD: parameter, gradient and momentum buffer must be float32 CUDA tensors with "
                                    "identical (dense) strides")
-            n = p.numel()
-            sig.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, gi))
-            for off in range(0, n, ce):
-                cnt = min(ce, n - off)
-                ptrs = [t.data_ptr() + 4 * off for t in (p, g, buf)]
-                entries.append((ptrs[0], ptrs[1], ptrs[2], cnt, gi, int(cnt % 4 == 0 and all(q % 16 == 0 for q in ptrs))))
+            sig.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), gi))
+        first_param.append(len(sig))
         sig = tuple(sig)
-        if sig != self._sig:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("segmi.optim.SGD: a parameter / gradient / momentum pointer changed while a hipGraph is being "
-                                   "captured; the pointer table is uploaded from host memory and cannot be rebuilt inside a capture. "
-                                   "Keep gradients persistent (segmi.distributed.DistributedModel holds them as bucket views, also in a "
-                                   "single process) and run at least one eager step before capturing (segmi.graph.GraphedStep does).")
-            arr = (_Chunk * len(entries))(*[_Chunk(*e) for e in entries])
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self._table = host.to(self.param_groups[0]["params"][0].device)
-            self._n = len(entries)
-            self._sig = sig
-            first_chunk.append(len(entries))
-            self._seg_ranges = [(first_chunk[a], first_chunk[b] - first_chunk[a]) for a, b in bounds] if bounds else [(0, len(entries))]
+        if sig == self._sig:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("segmi.optim.SGD: a parameter / gradient / momentum pointer changed while a hipGraph is being "
+                               "captured; the pointer table is uploaded from host memory and cannot be rebuilt inside a capture. "
+                               "Keep gradients persistent (segmi.distributed.DistributedModel holds them as bucket views, also in a "
+                               "single process) and run at least one eager step before capturing (segmi.graph.GraphedStep does).")
+        a = np.array(sig, dtype=np.int64).reshape(-1, 5)
+        nch = (a[:, 3] + ce - 1) // ce                                   # chunks per live parameter
+        first_chunk = np.concatenate([[0], np.cumsum(nch)])              # chunk index at which live parameter j starts
+        rep = np.repeat(np.arange(len(a)), nch)
+        off = (np.arange(int(first_chunk[-1])) - first_chunk[rep]) * ce  # element offset of each chunk inside its parameter
+        tab = np.zeros(int(first_chunk[-1]), dtype=_CHUNK_DTYPE)
+        tab["param"], tab["grad"], tab["momentum"] = a[rep, 0] + 4 * off, a[rep, 1] + 4 * off, a[rep, 2] + 4 * off
+        tab["count"] = np.minimum(ce, a[rep, 3] - off)
+        tab["group"] = a[rep, 4]
+        tab["vec4"] = (tab["count"] % 4 == 0) & (tab["param"] % 16 == 0) & (tab["grad"] % 16 == 0) & (tab["momentum"] % 16 == 0)
+        self._table = self._upload(tab, self.param_groups[0]["params"][0].device)
+        self._n = len(tab)
+        self._sig = sig
+        fc = [int(first_chunk[j]) for j in first_param]
+        self._seg_ranges = [(fc[lo], fc[hi] - fc[lo]) for lo, hi in bounds] if bounds else [(0, len(tab))]
+
+    def _upload(self, tab, device):
+        """The table as a device tensor.
+
+        `tensor.to(device)` from pageable memory (rounds 1-5) blocks the host until everything queued before it has run — the end
+        of backward.  On a GPU-paced step the host then starts the next step's launches on an idle GPU: 1.1 ms of every cfg2 step,
+        2 ms of cfg3, 2-4 ms of cfg5 (profiles/r06_gpu_gaps.txt).  `throttled`: a stream-ordered copy out of a ring of pinned staging
+        slots (a slot is reused only after the event of its previous copy has completed) and ONE wait per step on the event behind
+        the PREVIOUS step's update, so the host stays within one step of the GPU (with no bound at all the caching allocator
+        holds three generations of activations: cfg2 19 -> 61 GB reserved; one step ahead: 31 GB).  On a LAUNCH-paced step (cfg1:
+        6.3 ms of kernels in a 7 ms step) draining the queue once per step measured FASTER than never draining it (7.0 against
+        11.5 ms per step, profiles/r06_sgd_table_upload_ab.txt), so `auto` (default) times the drain of its first steps and keeps
+        the blocking upload when the GPU is within 2 ms of the host.  SEGMI_SGD_TABLE_UPLOAD=blocking|throttled|auto."""
+        raw = torch.from_numpy(tab.view(np.uint8).reshape(-1))
+        mode = os.environ.get("SEGMI_SGD_TABLE_UPLOAD", "auto")
+        if device.type != "cuda":
+            return raw.to(device)
+        if mode == "auto":
+            if self._auto is None:
+                t0 = time.perf_counter()
+                torch.cuda.current_stream(device).synchronize()
+                self._drains.append(time.perf_counter() - t0)
+                if len(self._drains) >= 4:                       # the first sample is the cold step
+                    rest = sorted(self._drains[1:])
+                    self._auto = "throttled" if rest[len(rest) // 2] > 2e-3 else "blocking"
+                return raw.to(device)
+            mode = self._auto
+        if mode != "throttled":
+            return raw.to(device)
+        if self._step_end is not None:
+            self._step_end.synchronize()         # the host runs at most one step ahead of the GPU (see _mark_step_end)
+        if self._tab_ring is None:
+            self._tab_ring, self._tab_events, self._tab_pos = [None] * self._RING, [None] * self._RING, 0
+        i = self._tab_pos
+        self._tab_pos = (i + 1) % self._RING
+        if self._tab_events[i] is not None:
+            self._tab_events[i].synchronize()
+        if self._tab_ring[i] is None or self._tab_ring[i].numel() < raw.numel():
+            self._tab_ring[i] = torch.empty(max(raw.numel(), 1 << 16), dtype=torch.uint8).pin_memory()
+        stage = self._tab_ring[i][:raw.numel()]
+        stage.copy_(raw)
+        dev = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
+        dev.copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._tab_events[i] = ev
+        return dev
 
     @torch.no_grad()
     def step_segment(self, i):
@@ -150,6 +215,8 @@ class SGD(torch.optim.Optimizer):
         start, count = self._seg_ranges[i]
         if count:
             self._launch(start, count)
+        if i == len(self._seg_ranges) - 1:
+            self._mark_step_end()
 
     @property
     def num_segments(self):
@@ -165,7 +232,15 @@ class SGD(torch.optim.Optimizer):
         if not self._n:
             return loss
         self._launch(0, self._n)
+        self._mark_step_end()
         return loss
+
+    def _mark_step_end(self):
+        """Event behind the iteration's last update: a throttled `_upload` of the NEXT iteration waits for it."""
+        if self._tab_ring is not None and not torch.cuda.is_current_stream_capturing():
+            if self._step_end is None:
+                self._step_end = torch.cuda.Event()
+            self._step_end.record()
 
     def _launch(self, start, count):
         loss = None
