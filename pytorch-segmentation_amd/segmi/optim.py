@@ -169,34 +169,37 @@ class SGD(torch.optim.Optimizer):
         the PREVIOUS step's update, so the host stays within one step of the GPU (with no bound at all the caching allocator
         holds three generations of activations: cfg2 19 -> 61 GB reserved; one step ahead: 31 GB).  On a LAUNCH-paced step (cfg1:
         6.3 ms of kernels in a 7 ms step) draining the queue once per step measured FASTER than never draining it (7.0 against
-        11.5 ms per step, profiles/r06_sgd_table_upload_ab.txt), so `auto` (default) times the drain of its first steps and keeps
+        11.5 ms per step, profiles/r06_sgd_table_upload_ab.txt), so `auto` (default) times the drain of its first three rebuilds and keeps
         the blocking upload when the GPU is within 2 ms of the host.  SEGMI_SGD_TABLE_UPLOAD=blocking|throttled|auto."""
         raw = torch.from_numpy(tab.view(np.uint8).reshape(-1))
         mode = os.environ.get("SEGMI_SGD_TABLE_UPLOAD", "auto")
         if device.type != "cuda":
             return raw.to(device)
+        if mode != "blocking" and self._tab_ring is None:
+            # every staging slot up front, in the first step: pinning host memory synchronises with the device and can take
+            # milliseconds — it must not happen in the middle of a run when `auto` changes its mind
+            cap = max(2 * raw.numel(), 1 << 16)
+            self._tab_ring = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(self._RING)]
+            self._tab_events, self._tab_pos = [None] * self._RING, 0
         if mode == "auto":
             if self._auto is None:
                 t0 = time.perf_counter()
                 torch.cuda.current_stream(device).synchronize()
                 self._drains.append(time.perf_counter() - t0)
-                if len(self._drains) >= 4:                       # the first sample is the cold step
-                    rest = sorted(self._drains[1:])
-                    self._auto = "throttled" if rest[len(rest) // 2] > 2e-3 else "blocking"
+                if len(self._drains) >= 3:                       # (the first sample is the cold step)
+                    self._auto = "throttled" if min(self._drains[1:]) > 2e-3 else "blocking"
                 return raw.to(device)
             mode = self._auto
         if mode != "throttled":
             return raw.to(device)
         if self._step_end is not None:
             self._step_end.synchronize()         # the host runs at most one step ahead of the GPU (see _mark_step_end)
-        if self._tab_ring is None:
-            self._tab_ring, self._tab_events, self._tab_pos = [None] * self._RING, [None] * self._RING, 0
         i = self._tab_pos
         self._tab_pos = (i + 1) % self._RING
         if self._tab_events[i] is not None:
             self._tab_events[i].synchronize()
-        if self._tab_ring[i] is None or self._tab_ring[i].numel() < raw.numel():
-            self._tab_ring[i] = torch.empty(max(raw.numel(), 1 << 16), dtype=torch.uint8).pin_memory()
+        if self._tab_ring[i].numel() < raw.numel():
+            self._tab_ring[i] = torch.empty(2 * raw.numel(), dtype=torch.uint8).pin_memory()
         stage = self._tab_ring[i][:raw.numel()]
         stage.copy_(raw)
         dev = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
