@@ -23,14 +23,11 @@ lo, hi = sgd[1], sgd[-1]                 # from the end of the 2nd step's optimi
 steps = len(sgd) - 2
 seg = rows[lo:hi + 1]
 t_begin, t_end = seg[0][1], seg[-1][1]
-busy, gaps, cur_end, last = 0, [], seg[0][1], seg[0][2]
+gaps, cur_end, last = [], seg[0][1], seg[0][2]      # cur_end: end of the union of the intervals so far; last: the kernel that set it
 for s, e, n in seg[1:]:
     if s > cur_end:
         gaps.append((s - cur_end, last, n))
-        busy += 0
-        cur_start = s
     if e > cur_end:
-        busy += e - max(s, cur_end)
         cur_end, last = e, n
 wall = t_end - t_begin
 idle = sum(g[0] for g in gaps)
