@@ -456,6 +456,8 @@ def main():
                        "conv_algorithm": ("winograd_f2x2_3x3 (fwd, dgrad, wgrad) for the 3x3 stride-1 layers with >= %d channels, direct implicit "
                                           "GEMM elsewhere" % segmi_ops.get_conv_winograd()["min_channels"]) if wino_default else "direct implicit GEMM",
                        "hip_graph": bool(args.graph), "wgrad_side_stream": bool(segmi_ops.get_wgrad_stream()["on"]),
+                       # how the fused SGD sent its chunk table up during the timed steps (segmi/optim.py _upload; None: built once)
+                       "sgd_table_upload": os.environ.get("SEGMI_SGD_TABLE_UPLOAD") or getattr(opt, "_auto", None),
                        "bn_stats_from_conv_epilogue": bool(segmi_ops.get_conv_bn_stats()["on"]),
                        "grad_buckets_mb": ([round(b["buf"].numel() * 4 / 2 ** 20, 1) for b in dm.reducer.buckets] if dm is not None else None),
                        "syncbn_collectives_per_step": syncbn_per_step,
